@@ -1,0 +1,231 @@
+/*
+ * vllm_omni_amd.h — C ABI of the MI355X (gfx950) decode hot path.
+ *
+ * This is the drop-in boundary underneath the Python plugin surface.  Every
+ * entry point is `extern "C"`, takes raw device pointers, plain integer sizes
+ * and strides (in ELEMENTS unless the name says bytes), a dtype enum and a
+ * `hipStream_t` passed as `void*`.  Nothing here allocates device memory,
+ * synchronises the device or throws: the return value is 0 on success or a
+ * negative MI_ERR_* code, so every call is hipGraph-capturable on the stream
+ * it is given.
+ *
+ * The reference (lishunyang12/vllm-omni) contains no native code; each entry
+ * point replaces an *upstream vLLM call site reached from the reference*.
+ * The comment above each declaration cites that call site (paths relative to
+ * the reference root) and the SURVEY.md §8a row.
+ */
+#ifndef VLLM_OMNI_AMD_H_
+#define VLLM_OMNI_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+/* dtype enum shared by every entry point */
+enum {
+  MI_DTYPE_F16 = 0,
+  MI_DTYPE_BF16 = 1,
+  MI_DTYPE_F32 = 2,
+};
+
+/* error codes (negative); 0 == success */
+enum {
+  MI_OK = 0,
+  MI_ERR_INVALID_ARG = -1,    /* null pointer, negative size, misaligned stride */
+  MI_ERR_UNSUPPORTED = -2,    /* head_dim / group size / block size / dtype not built */
+  MI_ERR_WORKSPACE = -3,      /* workspace too small */
+  MI_ERR_LAUNCH = -4,         /* hipLaunchKernel reported an error */
+  MI_ERR_EXHAUSTED = -5,      /* block pool has no free block (allocator -> None) */
+  MI_ERR_STATE = -6,          /* double free / unknown handle */
+};
+
+int mi_abi_version(void);
+const char* mi_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * A4 — paged KV-cache write.
+ * Replaces the KV-write half of upstream `Attention.forward(q,k,v)` called at
+ * vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:154 (layout
+ * contract: vllm_omni/distributed/omni_connectors/utils/kv_utils.py:378-450).
+ *   cache[slot / block_size][slot % block_size][head][:] = src[t][head][:]
+ * for every token t with slot_mapping[t] >= 0 (negative slots are padding and
+ * are skipped).  Pure copy: bit-exact.
+ * Strides are in elements; head_dim is contiguous everywhere.
+ * ---------------------------------------------------------------------- */
+int mi_reshape_and_cache(const void* k, const void* v, void* k_cache, void* v_cache,
+                         const int64_t* slot_mapping, int32_t num_tokens,
+                         int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                         int64_t k_token_stride, int64_t v_token_stride,
+                         int64_t cache_block_stride, int64_t cache_token_stride,
+                         int64_t cache_head_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A7 / A7b / A4 fused — (optional per-head RMSNorm) -> neox RoPE -> KV write.
+ * Replaces `self.rotary_pos_emb(positions, q, k)` + the KV write of
+ * `self.attn(q, k, v)` (qwen2_old.py:153-154) and, for the Qwen3 family, the
+ * q_norm/k_norm that precede RoPE.
+ *  - q [T, num_q_heads*head_dim], k [T, num_kv_heads*head_dim] are rotated
+ *    IN PLACE (first rot_dim dims of every head, rotate-half pairing
+ *    (i, i + rot_dim/2)); arithmetic in fp32, one rounding to `dtype`.
+ *  - cos_sin_cache is fp32 [max_position, rot_dim]: cos in [0, rot_dim/2),
+ *    sin in [rot_dim/2, rot_dim) — the table layout of upstream `get_rope`.
+ *  - positions is int64 [T] (mrope_section == NULL) or int64 [3, T] with row
+ *    stride `positions_row_stride` and mrope_section[3] (sum == rot_dim/2):
+ *    half-dim index j takes its angle from row 0/1/2 according to the section
+ *    it falls in (M-RoPE rule).
+ *  - q_norm_weight / k_norm_weight (dtype, [head_dim]) may be NULL (Qwen2).
+ *  - k_cache == NULL skips the cache write (plain RoPE).  v may be NULL then.
+ * ---------------------------------------------------------------------- */
+int mi_rope_neox_and_cache(void* q, void* k, const void* v, const int64_t* positions,
+                           int64_t positions_row_stride, const int32_t* mrope_section,
+                           const float* cos_sin_cache, int32_t max_position, int32_t rot_dim,
+                           const void* q_norm_weight, const void* k_norm_weight, float norm_eps,
+                           void* k_cache, void* v_cache, const int64_t* slot_mapping,
+                           int32_t num_tokens, int32_t num_q_heads, int32_t num_kv_heads,
+                           int32_t head_dim, int32_t block_size, int64_t q_token_stride,
+                           int64_t k_token_stride, int64_t v_token_stride,
+                           int64_t cache_block_stride, int64_t cache_token_stride,
+                           int64_t cache_head_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A5 — paged-attention decode (q_len == 1).
+ * Replaces the decode half of upstream `Attention.forward` (TRITON_ATTN on
+ * ROCm: vllm_omni/engine/stage_init_utils.py:282-293) called at
+ * qwen2_old.py:154.
+ *   out[s,h] = softmax(q[s,h] . K[s, kv(h), :len_s]^T * scale) . V[s, kv(h), :len_s]
+ *   kv(h) = h / (num_q_heads / num_kv_heads); token t of sequence s lives at
+ *   cache[block_table[s, t / block_size]][t % block_size][kv(h)].
+ * fp32 scores / softmax statistics / accumulators; one rounding to out_dtype.
+ * The context is split into partitions of `partition_size` tokens (0 = pick
+ * automatically); partial (m, l, O) triples go through `workspace` and are
+ * merged by a second small kernel.  `max_seq_len` is a host-side upper bound
+ * on seq_lens[] that sizes the grid, so the launch is graph-replayable while
+ * sequences grow.  seq_lens[s] == 0 writes zeros.
+ * out_dtype: MI_DTYPE_F32 is accepted for parity measurement.
+ * ---------------------------------------------------------------------- */
+int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
+                                             int32_t head_dim, int32_t max_seq_len,
+                                             int32_t partition_size);
+int mi_paged_attn_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                         const int32_t* block_table, const int32_t* seq_lens,
+                         int32_t num_seqs, int32_t num_q_heads, int32_t num_kv_heads,
+                         int32_t head_dim, int32_t block_size, int32_t block_table_stride,
+                         int32_t max_seq_len, float scale, int64_t q_token_stride,
+                         int64_t out_token_stride, int64_t cache_block_stride,
+                         int64_t cache_token_stride, int64_t cache_head_stride,
+                         int32_t partition_size, void* workspace, int64_t workspace_bytes,
+                         int dtype, int out_dtype, void* stream);
+/* Partition size the auto heuristic would pick (exposed for bench/DESIGN). */
+int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
+                                            int32_t max_seq_len);
+
+/* ------------------------------------------------------------------------
+ * A6 — paged-attention prefill / chunked prefill (q_len >= 1, varlen, causal
+ * with context offset), MFMA bf16/f16.
+ * Replaces the prefill half of upstream `Attention.forward` (same call site).
+ *   query tokens of sequence s are rows [query_start_loc[s], query_start_loc[s+1]);
+ *   query row i (0-based inside the chunk) sits at absolute position
+ *   seq_lens[s] - q_len_s + i and attends to cache positions [0, that position].
+ * K/V (including this chunk's own tokens) are read from the paged cache, so
+ * the KV write (A4) must precede this call on the same stream.
+ * ---------------------------------------------------------------------- */
+int mi_paged_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
+                          const int32_t* block_table, const int32_t* seq_lens,
+                          const int32_t* query_start_loc, int32_t num_seqs,
+                          int32_t num_tokens, int32_t max_query_len, int32_t num_q_heads,
+                          int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                          int32_t block_table_stride, float scale, int64_t q_token_stride,
+                          int64_t out_token_stride, int64_t cache_block_stride,
+                          int64_t cache_token_stride, int64_t cache_head_stride, int dtype,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
+ * A8 — RMSNorm and fused residual-add RMSNorm.
+ * Replaces upstream `RMSNorm.forward(x[, residual])` at qwen2_old.py:212-216,
+ * 223,325.  Rounding order (recorded in DESIGN.md): r' = round(x + r);
+ * y = round(round(r' * rsqrt(mean(r'^2) + eps)) * w) with an fp32 reduction —
+ * the order of the reference's HF-exact restatement
+ * (vllm_omni/model_executor/models/common/qwen3_code_predictor.py:46-62).
+ *   mi_rms_norm:           out = norm(x) * w            (out may alias x)
+ *   mi_fused_add_rms_norm: residual <- x + residual ; x <- norm(residual) * w
+ * ---------------------------------------------------------------------- */
+int mi_rms_norm(void* out, const void* x, const void* weight, float eps, int32_t num_tokens,
+                int32_t hidden, int64_t x_token_stride, int64_t out_token_stride, int dtype,
+                void* stream);
+int mi_fused_add_rms_norm(void* x, void* residual, const void* weight, float eps,
+                          int32_t num_tokens, int32_t hidden, int64_t x_token_stride,
+                          int64_t residual_token_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A9 — SiLU-gate: out[t, j] = silu(x[t, j]) * x[t, inter + j].
+ * Replaces upstream `SiluAndMul()` at qwen2_old.py:63,67.
+ * ---------------------------------------------------------------------- */
+int mi_silu_and_mul(void* out, const void* x, int32_t num_tokens, int32_t inter,
+                    int64_t x_token_stride, int64_t out_token_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A11 helpers — talker logit masking (`bad_word_processor`,
+ * vllm_omni/model_executor/models/qwen2_5_omni/qwen2_5_omni_talker.py:150-169)
+ * fused with greedy argmax (temperature 0).  Columns in [mask_lo0, mask_hi0),
+ * [mask_lo1, mask_hi1) and the single column `mask_col` (if >= 0) are set to
+ * -1e9 in place; ids[t] = first index of the row maximum afterwards.
+ * logits are fp32 or `dtype`; ids int64.
+ * ---------------------------------------------------------------------- */
+int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_t vocab,
+                          int64_t row_stride, int32_t mask_lo0, int32_t mask_hi0,
+                          int32_t mask_lo1, int32_t mask_hi1, int32_t mask_col, int dtype,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
+ * A13 — W8A8 int8 linear (scheme of vllm_omni/quantization/int8_config.py:
+ * 180-212,323-342,391-418): dynamic symmetric per-token activation quant
+ * (scale_t = absmax(x_t)/127, round-half-even, saturate to [-127,127]... see
+ * DESIGN.md "unpinned"), int8 x int8 -> int32 MFMA GEMM against weight
+ * [N, K] int8 with per-output-channel fp32 scale, dequant + optional bias.
+ * ---------------------------------------------------------------------- */
+int mi_dynamic_int8_quant(int8_t* xq, float* x_scale, const void* x, int32_t num_tokens,
+                          int32_t hidden, int64_t x_token_stride, int dtype, void* stream);
+int mi_int8_gemm_dequant(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq,
+                         const float* w_scale, const void* bias, int32_t m, int32_t n,
+                         int32_t k, int64_t out_row_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A1 — KV block pool (host side, no GPU).  The allocator underneath the
+ * `KVCacheManager`-shaped façade the schedulers call
+ * (vllm_omni/core/sched/omni_ar_scheduler.py:183-193,480,528,628;
+ *  vllm_omni/core/sched/omni_generation_scheduler.py:49,100-110,167-177,210,256).
+ * Free list is FIFO over block ids (blocks return to the TAIL in the order
+ * they are freed), reference counted; block id 0 is reserved as the null
+ * block and never handed out.  Thread-compatible: caller serialises.
+ *   alloc: pops `n` ids into out_ids, or returns MI_ERR_EXHAUSTED and pops
+ *          nothing (the façade turns that into `None`).
+ *   ref:   +1 on an allocated block (prefix sharing).
+ *   free:  -1; at zero the block goes back to the free list.
+ * ---------------------------------------------------------------------- */
+typedef struct mi_blockpool mi_blockpool;
+mi_blockpool* mi_blockpool_create(int32_t num_blocks);
+void mi_blockpool_destroy(mi_blockpool* pool);
+int32_t mi_blockpool_num_free(const mi_blockpool* pool);
+int32_t mi_blockpool_num_blocks(const mi_blockpool* pool);
+int mi_blockpool_alloc(mi_blockpool* pool, int32_t n, int32_t* out_ids);
+int mi_blockpool_ref(mi_blockpool* pool, const int32_t* ids, int32_t n);
+int mi_blockpool_free(mi_blockpool* pool, const int32_t* ids, int32_t n);
+int32_t mi_blockpool_refcount(const mi_blockpool* pool, int32_t id);
+
+/* A3 — slot mapping on the host: slot[t] = block_table[req, pos/bs]*bs + pos%bs
+ * for the tokens scheduled this step (vectorised restatement of upstream's
+ * numpy path reached from vllm_omni/worker/gpu_ar_model_runner.py:437-442).
+ * req_indices[T] / positions[T] are int32 / int64; out is int64 [T].
+ * Returns MI_ERR_INVALID_ARG if a position indexes past block_table_stride. */
+int mi_compute_slot_mapping(int64_t* slot_mapping, const int32_t* block_table,
+                            int32_t block_table_stride, const int32_t* req_indices,
+                            const int64_t* positions, int32_t num_tokens, int32_t block_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLLM_OMNI_AMD_H_ */

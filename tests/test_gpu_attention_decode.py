@@ -1,0 +1,212 @@
+"""GPU parity: paged-attention decode vs the CPU oracle, through the C ABI.
+
+Tolerances (north_star: "fp16/bf16 logits within 1e-3 rtol"): the kernel is asked for an
+fp32 output so accumulation accuracy is measured without the final 16-bit rounding:
+  * default kernel (P rounded to the cache dtype before PV, as flash kernels do) vs the
+    oracle with the same rounding point: rtol 1e-3, atol 1e-3 (|out| <= max|V| ~ 4);
+  * vs the pure-fp32 oracle: rtol 1e-3 + atol 4e-3 (bf16) — the P rounding itself is
+    worth up to 2^-9 relative per term;
+  * 16-bit output == round(fp32 output) bit-exactly.
+Block-table indexing is checked bit-exactly with integer-valued V (one-hot attention).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk_case(S, nq, nkv, d, bs, seq_lens, dtype, seed=0, nb_extra=7, layout="nb2"):
+    g = torch.Generator().manual_seed(seed)
+    max_blocks = max(1, max((n + bs - 1) // bs for n in seq_lens))
+    nb = S * max_blocks + nb_extra + 1
+    if layout == "nb2":      # [nb, 2, bs, H, d]  (K/V at dim 1)
+        kv = torch.randn(nb, 2, bs, nkv, d, generator=g).to(dtype)
+        kb, vb = kv[:, 0], kv[:, 1]
+    elif layout == "2nb":    # [2, nb, bs, H, d]  (K/V at dim 0)
+        kv = torch.randn(2, nb, bs, nkv, d, generator=g).to(dtype)
+        kb, vb = kv[0], kv[1]
+    else:                    # head-major physical layout, exposed as the same logical view
+        kv = torch.randn(nb, 2, nkv, bs, d, generator=g).to(dtype)
+        kb, vb = kv[:, 0].permute(0, 2, 1, 3), kv[:, 1].permute(0, 2, 1, 3)
+    perm = torch.randperm(nb - 1, generator=g)[: S * max_blocks] + 1  # block 0 = null block
+    table = perm.view(S, max_blocks).to(torch.int32)
+    q = torch.randn(S, nq, d, generator=g).to(dtype)
+    return kv, kb, vb, table, q, torch.tensor(seq_lens, dtype=torch.int32)
+
+
+def _run(dev, kv, layout, table, q, seq_lens, out_dtype, partition_size=0, max_seq_len=None):
+    from vllm_omni_amd import ops
+
+    kvg = kv.to(dev)
+    if layout == "nb2":
+        kb, vb = kvg[:, 0], kvg[:, 1]
+    elif layout == "2nb":
+        kb, vb = kvg[0], kvg[1]
+    else:
+        kb, vb = kvg[:, 0].permute(0, 2, 1, 3), kvg[:, 1].permute(0, 2, 1, 3)
+    S, nq, d = q.shape
+    out = torch.full((S, nq * d), float("nan"), dtype=out_dtype, device=dev)
+    msl = int(seq_lens.max()) if max_seq_len is None else max_seq_len
+    ops.paged_attn_decode(out, q.view(S, nq * d).to(dev), kb, vb, table.to(dev), seq_lens.to(dev),
+                          max(msl, 1), d ** -0.5, partition_size=partition_size)
+    torch.cuda.synchronize()
+    return out.cpu().view(S, nq, d)
+
+
+CASES = [
+    # S, nq, nkv, d, bs, seq_lens                      (golden-vector shapes of SURVEY §8c ii)
+    (3, 8, 2, 128, 16, [1, 17, 40]),
+    (3, 8, 2, 64, 16, [1, 17, 40]),
+    (4, 28, 4, 128, 16, [5, 16, 33, 300]),             # S-A head geometry (G = 7)
+    (2, 16, 2, 64, 16, [64, 129]),                     # S-B head geometry (G = 8, d = 64)
+    (2, 7, 1, 128, 16, [31, 257]),                     # S-A at TP=4
+    (3, 4, 4, 128, 8, [9, 8, 23]),                     # MHA, block 8
+    (2, 12, 2, 128, 32, [70, 33]),                     # G = 6, block 32
+    (2, 32, 2, 128, 16, [18, 47]),                     # G = 16 -> two waves of 8 heads per KV head
+    (2, 5, 1, 64, 8, [3, 41]),                         # G = 5, d = 64, block 8
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CASES)
+def test_decode_matches_oracle(dev, case, dtype):
+    S, nq, nkv, d, bs, lens = case
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, dtype)
+    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32)
+    ref_matched = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5, p_round_to=dtype)
+    ref_f32 = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
+    torch.testing.assert_close(got, ref_matched, rtol=1e-3, atol=1e-3)
+    atol = 4e-3 if dtype == torch.bfloat16 else 1e-3
+    torch.testing.assert_close(got, ref_f32, rtol=1e-3, atol=atol)
+    # production output dtype: exactly the rounding of the fp32 result
+    got16 = _run(dev, kv, "nb2", table, q, seq_lens, dtype)
+    assert torch.equal(got16, got.to(dtype))
+
+
+@pytest.mark.parametrize("layout", ["nb2", "2nb", "head_major"])
+def test_decode_cache_layouts(dev, layout):
+    """The three physical layouts behind the reference's accepted views (kv_utils.py:378-450)."""
+    S, nq, nkv, d, bs, lens = 3, 8, 2, 128, 16, [1, 17, 40]
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, torch.bfloat16, seed=3, layout=layout)
+    got = _run(dev, kv, layout, table, q, seq_lens, torch.float32)
+    ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5, p_round_to=torch.bfloat16)
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("partition_size", [16, 32, 64, 256, 1024])
+def test_decode_partitions_agree(dev, partition_size):
+    """Split-context + merge must not change the answer (beyond fp32 reassociation)."""
+    S, nq, nkv, d, bs = 3, 28, 4, 128, 16
+    lens = [1, 130, 517]
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, torch.bfloat16, seed=5)
+    one = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=1024)
+    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=partition_size)
+    torch.testing.assert_close(got, one, rtol=1e-4, atol=1e-4)
+    # a launch sized for a longer bound (graph replay while sequences grow) gives the same result
+    got2 = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=partition_size,
+                max_seq_len=2048)
+    torch.testing.assert_close(got2, one, rtol=1e-4, atol=1e-4)
+
+
+def test_decode_block_table_indexing_bit_exact(dev):
+    """One-hot attention over integer-valued V: the output IS the row the block table points at."""
+    S, nq, nkv, d, bs = 4, 8, 2, 128, 16
+    lens = [16, 17, 63, 100]
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, torch.bfloat16, seed=7)
+    kv.zero_()
+    g = torch.Generator().manual_seed(11)
+    targets = [int(torch.randint(0, n, (1,), generator=g)) for n in lens]
+    q.zero_()
+    q[..., 0] = 64.0  # score = 64 * k[0] * d^-0.5
+    for s, (n, tgt) in enumerate(zip(lens, targets)):
+        for t in range(n):
+            blk, off = int(table[s, t // bs]), t % bs
+            vb[blk, off] = torch.randint(-8, 8, (nkv, d), generator=g).to(torch.bfloat16)
+            kb[blk, off, :, 0] = 200.0 if t == tgt else -200.0
+    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.bfloat16)
+    for s, tgt in enumerate(targets):
+        blk, off = int(table[s, tgt // bs]), tgt % bs
+        exp = vb[blk, off].repeat_interleave(nq // nkv, dim=0)
+        assert torch.equal(got[s], exp), f"seq {s}: wrong row gathered"
+
+
+def test_decode_ignores_garbage_past_seq_len(dev):
+    """NaN/Inf in cache rows beyond seq_len (same block, or unallocated table entries) must not leak."""
+    S, nq, nkv, d, bs = 2, 8, 2, 128, 16
+    lens = [5, 37]
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, torch.bfloat16, seed=9)
+    ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5, p_round_to=torch.bfloat16)
+    for s, n in enumerate(lens):
+        blk = int(table[s, (n - 1) // bs])
+        kb[blk, n % bs:] = float("nan")
+        vb[blk, n % bs:] = float("inf")
+    table[0, 1:] = -12345  # never-allocated entries: must not be dereferenced
+    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=16, max_seq_len=64)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+
+
+def test_decode_empty_and_zero_len(dev):
+    from vllm_omni_amd import ops
+
+    S, nq, nkv, d, bs = 3, 8, 2, 128, 16
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, [0, 20, 0], torch.bfloat16)
+    for ps in (0, 16):
+        got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=ps, max_seq_len=64)
+        assert torch.equal(got[0], torch.zeros(nq, d)) and torch.equal(got[2], torch.zeros(nq, d))
+        ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5, p_round_to=torch.bfloat16)
+        torch.testing.assert_close(got[1], ref[1], rtol=1e-3, atol=1e-3)
+    # zero sequences: no launch, no error
+    e = torch.empty(0, nq * d, dtype=torch.bfloat16, device=dev)
+    ops.paged_attn_decode(e, e, kv.to(dev)[:, 0], kv.to(dev)[:, 1], torch.empty(0, 4, dtype=torch.int32, device=dev),
+                          torch.empty(0, dtype=torch.int32, device=dev), 16, 1.0)
+
+
+def test_decode_softmax_extremes(dev):
+    """Running-max rescale path: a late, much larger score must take over exactly (rule 26)."""
+    S, nq, nkv, d, bs = 1, 8, 2, 128, 16
+    n = 200
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, [n], torch.bfloat16, seed=13)
+    # spike key at a late token so every earlier tile is rescaled by ~exp(-large)
+    for t in (150, 199):
+        blk, off = int(table[0, t // bs]), t % bs
+        kb[blk, off] = (q[0, ::nq // nkv] * 3.0).to(torch.bfloat16)
+    ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5, p_round_to=torch.bfloat16)
+    for ps in (16, 64, 1024):
+        got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=ps)
+        assert torch.isfinite(got).all()
+        torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+
+
+def test_decode_rejects_bad_arguments(dev):
+    from vllm_omni_amd import _C, ops
+
+    S, nq, nkv, d, bs = 2, 8, 2, 128, 16
+    kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, [4, 4], torch.bfloat16)
+    kvg = kv.to(dev)
+    out = torch.empty(S, nq * d, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError):  # CPU tensors: no fallback
+        ops.paged_attn_decode(out.cpu(), q.view(S, -1), kb, vb, table, seq_lens, 4, 1.0)
+    bad = torch.randn(4, 2, bs, nkv, 96).to(torch.bfloat16).to(dev)  # head_dim 96 not built
+    with pytest.raises(_C.MIError) as ei:
+        ops.paged_attn_decode(torch.empty(S, nq * 96, dtype=torch.bfloat16, device=dev),
+                              torch.empty(S, nq * 96, dtype=torch.bfloat16, device=dev), bad[:, 0], bad[:, 1],
+                              table.to(dev), seq_lens.to(dev), 4, 1.0)
+    assert ei.value.code == _C.MI_ERR_UNSUPPORTED
+    # workspace too small -> MI_ERR_WORKSPACE, nothing launched
+    qg, tg, lg = q.view(S, -1).to(dev), table.to(dev), seq_lens.to(dev)
+    code = ops.lib.mi_paged_attn_decode(out.data_ptr(), qg.data_ptr(), kvg[:, 0].data_ptr(), kvg[:, 1].data_ptr(),
+                                        tg.data_ptr(), lg.data_ptr(), S, nq, nkv, d, bs, tg.stride(0), 64, 1.0,
+                                        nq * d, nq * d, kvg.stride(0), kvg.stride(2), kvg.stride(3), 16, None, 0,
+                                        _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, None)
+    assert code == _C.MI_ERR_WORKSPACE
+    # misaligned stride -> MI_ERR_INVALID_ARG
+    code = ops.lib.mi_paged_attn_decode(out.data_ptr(), qg.data_ptr(), kvg[:, 0].data_ptr(), kvg[:, 1].data_ptr(),
+                                        tg.data_ptr(), lg.data_ptr(), S, nq, nkv, d, bs, tg.stride(0), 4, 1.0,
+                                        nq * d + 1, nq * d, kvg.stride(0), kvg.stride(2), kvg.stride(3), 16, None, 0,
+                                        _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, None)
+    assert code == _C.MI_ERR_INVALID_ARG

@@ -1,0 +1,113 @@
+// Shared device/host helpers for the gfx950 kernels.  gfx950 only: wave = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vllm_omni_amd.h"
+
+namespace mi {
+
+constexpr int kWave = 64;
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+// ---- element traits: T is the storage type tag -------------------------
+struct bf16_tag {};
+struct f16_tag {};
+
+template <typename Tag>
+struct Elem;
+
+template <>
+struct Elem<bf16_tag> {
+  // bf16 -> f32 is a 16-bit shift; lo/hi halves of a packed dword.
+  static __device__ __forceinline__ float lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+  static __device__ __forceinline__ float from_bits(uint16_t b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+  }
+  // round-to-nearest-even via the hardware convert (keeps NaN a NaN).
+  static __device__ __forceinline__ uint16_t to_bits(float f) {
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+  // acc += a.lo*b.lo + a.hi*b.hi, fp32 accumulate (v_dot2c_f32_bf16)
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a),
+                                           __builtin_bit_cast(bf16x2_t, b), acc, false);
+  }
+};
+
+template <>
+struct Elem<f16_tag> {
+  static __device__ __forceinline__ float lo(uint32_t w) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+  }
+  static __device__ __forceinline__ float hi(uint32_t w) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+  }
+  static __device__ __forceinline__ float from_bits(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static __device__ __forceinline__ uint16_t to_bits(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    f16x2_t v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b),
+                                  acc, false);
+  }
+};
+
+// ---- DPP helpers (a DPP row is 16 lanes) --------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kDppQuadXor1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;  // lane i <-> 7-i inside each 8
+constexpr int kDppRowMirror = 0x140;      // lane i <-> 15-i inside each 16
+
+// all-reduce (sum) over aligned groups of N consecutive lanes, N in {8,16}
+template <int N>
+__device__ __forceinline__ float group_allreduce_sum(float v) {
+  v += dpp_f32<kDppQuadXor1>(v);
+  v += dpp_f32<kDppQuadXor2>(v);
+  v += dpp_f32<kDppRowHalfMirror>(v);
+  if constexpr (N == 16) v += dpp_f32<kDppRowMirror>(v);
+  return v;
+}
+
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ---- host-side launch check ---------------------------------------------
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MI_OK : MI_ERR_LAUNCH;
+}
+
+inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace mi

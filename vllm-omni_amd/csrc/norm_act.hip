@@ -1,0 +1,312 @@
+// A8 RMSNorm / fused-add RMSNorm, A9 SiLU-gate, A11 talker logit mask + greedy argmax.
+// All three are launch-bound at decode (<= 20 MB per call); they are written as plain
+// vectorised (16 B/lane) streaming kernels, one workgroup per row.
+//
+// Replaces upstream RMSNorm / SiluAndMul reached from
+// vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:63,67,212-216,223,325 and
+// `bad_word_processor` (qwen2_5_omni_talker.py:150-169).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace mi {
+namespace {
+
+__device__ __forceinline__ float block_allreduce_sum(float v, float* smem) {
+  v = wave_allreduce_sum(v);
+  const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) smem[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += smem[i];
+  __syncthreads();
+  return r;
+}
+
+// rounding order: z = rnd(x + r); y = rnd(rnd(z * inv_rms) * w)
+template <typename Tag, bool ADD, int MAXC>
+__global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ out,
+                                                       const uint16_t* __restrict__ x,
+                                                       uint16_t* __restrict__ residual,
+                                                       const uint16_t* __restrict__ w, float eps,
+                                                       int hidden, int64_t x_stride,
+                                                       int64_t out_stride, int64_t r_stride) {
+  using E = Elem<Tag>;
+  __shared__ float smem[4];
+  const int row = blockIdx.x;
+  const int nchunk = hidden / 8;
+  const uint16_t* xr = x + row * x_stride;
+  uint16_t* rr = ADD ? residual + row * r_stride : nullptr;
+  uint16_t* orow = out + row * out_stride;
+  uint4 z[MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = threadIdx.x + k * 256;
+    if (ch < nchunk) {
+      uint4 a = *reinterpret_cast<const uint4*>(xr + ch * 8);
+      if constexpr (ADD) {
+        const uint4 b = *reinterpret_cast<const uint4*>(rr + ch * 8);
+        a.x = E::pack(E::lo(a.x) + E::lo(b.x), E::hi(a.x) + E::hi(b.x));
+        a.y = E::pack(E::lo(a.y) + E::lo(b.y), E::hi(a.y) + E::hi(b.y));
+        a.z = E::pack(E::lo(a.z) + E::lo(b.z), E::hi(a.z) + E::hi(b.z));
+        a.w = E::pack(E::lo(a.w) + E::lo(b.w), E::hi(a.w) + E::hi(b.w));
+        *reinterpret_cast<uint4*>(rr + ch * 8) = a;
+      }
+      z[k] = a;
+      const uint32_t ws[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lo = E::lo(ws[i]), hi = E::hi(ws[i]);
+        ss += lo * lo + hi * hi;
+      }
+    }
+  }
+  ss = block_allreduce_sum(ss, smem);
+  const float inv = __builtin_amdgcn_rsqf(ss / (float)hidden + eps);
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = threadIdx.x + k * 256;
+    if (ch < nchunk) {
+      const uint4 wv = *reinterpret_cast<const uint4*>(w + ch * 8);
+      const uint32_t zs[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
+      const uint32_t ws[4] = {wv.x, wv.y, wv.z, wv.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float nlo = E::from_bits(E::to_bits(E::lo(zs[i]) * inv));
+        const float nhi = E::from_bits(E::to_bits(E::hi(zs[i]) * inv));
+        o[i] = E::pack(nlo * E::lo(ws[i]), nhi * E::hi(ws[i]));
+      }
+      *reinterpret_cast<uint4*>(orow + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// Any hidden size / alignment: scalar, two passes over memory (row re-read hits L2).
+template <typename Tag, bool ADD>
+__global__ __launch_bounds__(256) void rms_norm_generic_kernel(uint16_t* out, const uint16_t* x,
+                                                               uint16_t* residual,
+                                                               const uint16_t* w, float eps,
+                                                               int hidden, int64_t x_stride,
+                                                               int64_t out_stride,
+                                                               int64_t r_stride) {
+  using E = Elem<Tag>;
+  __shared__ float smem[4];
+  const int row = blockIdx.x;
+  const uint16_t* xr = x + row * x_stride;
+  uint16_t* rr = ADD ? residual + row * r_stride : nullptr;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < hidden; i += 256) {
+    float v = E::from_bits(xr[i]);
+    if constexpr (ADD) {
+      const uint16_t zb = E::to_bits(v + E::from_bits(rr[i]));
+      rr[i] = zb;
+      v = E::from_bits(zb);
+    }
+    ss += v * v;
+  }
+  ss = block_allreduce_sum(ss, smem);  // barriers also order the rr[] writes above
+  const float inv = __builtin_amdgcn_rsqf(ss / (float)hidden + eps);
+  for (int i = threadIdx.x; i < hidden; i += 256) {
+    const float v = ADD ? E::from_bits(rr[i]) : E::from_bits(xr[i]);
+    const float n = E::from_bits(E::to_bits(v * inv));
+    out[row * out_stride + i] = E::to_bits(n * E::from_bits(w[i]));
+  }
+}
+
+// out = rnd(rnd(silu(g)) * u): silu in fp32, rounded, then the gate product rounded.
+template <typename Tag>
+__global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ out,
+                                                       const uint16_t* __restrict__ x, int inter,
+                                                       int64_t x_stride, int64_t out_stride) {
+  using E = Elem<Tag>;
+  const int row = blockIdx.y;
+  const uint16_t* g = x + row * x_stride;
+  const uint16_t* u = g + inter;
+  uint16_t* o = out + row * out_stride;
+  const int nchunk = inter / 8;
+  for (int ch = blockIdx.x * 256 + threadIdx.x; ch < nchunk; ch += gridDim.x * 256) {
+    const uint4 a = *reinterpret_cast<const uint4*>(g + ch * 8);
+    const uint4 b = *reinterpret_cast<const uint4*>(u + ch * 8);
+    const uint32_t as[4] = {a.x, a.y, a.z, a.w};
+    const uint32_t bs[4] = {b.x, b.y, b.z, b.w};
+    uint32_t r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g0 = E::lo(as[i]), g1 = E::hi(as[i]);
+      const float s0 = E::from_bits(E::to_bits(g0 / (1.f + __expf(-g0))));
+      const float s1 = E::from_bits(E::to_bits(g1 / (1.f + __expf(-g1))));
+      r[i] = E::pack(s0 * E::lo(bs[i]), s1 * E::hi(bs[i]));
+    }
+    *reinterpret_cast<uint4*>(o + ch * 8) = make_uint4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void silu_mul_scalar_kernel(uint16_t* out, const uint16_t* x,
+                                                              int inter, int64_t x_stride,
+                                                              int64_t out_stride) {
+  using E = Elem<Tag>;
+  const int row = blockIdx.y;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < inter; i += gridDim.x * 256) {
+    const float g = E::from_bits(x[row * x_stride + i]);
+    const float u = E::from_bits(x[row * x_stride + inter + i]);
+    const float s = E::from_bits(E::to_bits(g / (1.f + __expf(-g))));
+    out[row * out_stride + i] = E::to_bits(s * u);
+  }
+}
+
+// logits row: mask ranges to -1e9 in place, then first-index argmax.
+template <int DT>  // MI_DTYPE_*
+__global__ __launch_bounds__(256) void mask_argmax_kernel(void* logits, int64_t* ids, int vocab,
+                                                          int64_t row_stride, int lo0, int hi0,
+                                                          int lo1, int hi1, int col) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int row = blockIdx.x;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = threadIdx.x; i < vocab; i += 256) {
+    const bool masked = (i >= lo0 && i < hi0) || (i >= lo1 && i < hi1) || i == col;
+    float v;
+    if constexpr (DT == MI_DTYPE_F32) {
+      float* p = reinterpret_cast<float*>(logits) + row * row_stride + i;
+      if (masked) *p = -1e9f;
+      v = *p;
+    } else {
+      using E = Elem<typename std::conditional<DT == MI_DTYPE_BF16, bf16_tag, f16_tag>::type>;
+      uint16_t* p = reinterpret_cast<uint16_t*>(logits) + row * row_stride + i;
+      if (masked) *p = E::to_bits(-1e9f);  // f16 saturates to -inf, as torch does
+      v = E::from_bits(*p);
+    }
+    if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i)
+      if (sv[i] > best || (sv[i] == best && si[i] < besti)) { best = sv[i]; besti = si[i]; }
+    ids[row] = besti == 0x7fffffff ? 0 : besti;
+  }
+}
+
+template <typename Tag>
+int launch_rms(void* out, const void* x, void* residual, const void* w, float eps, int T, int H,
+               int64_t xs, int64_t os, int64_t rs, hipStream_t s) {
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto xx = reinterpret_cast<const uint16_t*>(x);
+  auto rr = reinterpret_cast<uint16_t*>(residual);
+  auto ww = reinterpret_cast<const uint16_t*>(w);
+  const bool add = residual != nullptr;
+  const bool vec = H % 8 == 0 && xs % 8 == 0 && os % 8 == 0 && rs % 8 == 0 && H <= 8 * 256 * 4 &&
+                   !(((uintptr_t)out | (uintptr_t)x | (uintptr_t)residual | (uintptr_t)w) & 15);
+  const dim3 grid(T), block(256);
+  if (vec) {
+    const int c = (H / 8 + 255) / 256;
+#define MI_RMS(ADD, C) \
+  hipLaunchKernelGGL((rms_norm_kernel<Tag, ADD, C>), grid, block, 0, s, o, xx, rr, ww, eps, H, xs, os, rs)
+    if (add) { if (c <= 1) MI_RMS(true, 1); else if (c <= 2) MI_RMS(true, 2); else MI_RMS(true, 4); }
+    else { if (c <= 1) MI_RMS(false, 1); else if (c <= 2) MI_RMS(false, 2); else MI_RMS(false, 4); }
+#undef MI_RMS
+  } else if (add) {
+    hipLaunchKernelGGL((rms_norm_generic_kernel<Tag, true>), grid, block, 0, s, o, xx, rr, ww, eps, H, xs, os, rs);
+  } else {
+    hipLaunchKernelGGL((rms_norm_generic_kernel<Tag, false>), grid, block, 0, s, o, xx, rr, ww, eps, H, xs, os, rs);
+  }
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace mi
+
+extern "C" int mi_rms_norm(void* out, const void* x, const void* weight, float eps,
+                           int32_t num_tokens, int32_t hidden, int64_t x_token_stride,
+                           int64_t out_token_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!out || !x || !weight || num_tokens < 0 || hidden <= 0) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MI_DTYPE_BF16)
+    return launch_rms<bf16_tag>(out, x, nullptr, weight, eps, num_tokens, hidden, x_token_stride,
+                                out_token_stride, 0, s);
+  if (dtype == MI_DTYPE_F16)
+    return launch_rms<f16_tag>(out, x, nullptr, weight, eps, num_tokens, hidden, x_token_stride,
+                               out_token_stride, 0, s);
+  return MI_ERR_UNSUPPORTED;
+}
+
+extern "C" int mi_fused_add_rms_norm(void* x, void* residual, const void* weight, float eps,
+                                     int32_t num_tokens, int32_t hidden, int64_t x_token_stride,
+                                     int64_t residual_token_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!x || !residual || !weight || num_tokens < 0 || hidden <= 0) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MI_DTYPE_BF16)
+    return launch_rms<bf16_tag>(x, x, residual, weight, eps, num_tokens, hidden, x_token_stride,
+                                x_token_stride, residual_token_stride, s);
+  if (dtype == MI_DTYPE_F16)
+    return launch_rms<f16_tag>(x, x, residual, weight, eps, num_tokens, hidden, x_token_stride,
+                               x_token_stride, residual_token_stride, s);
+  return MI_ERR_UNSUPPORTED;
+}
+
+extern "C" int mi_silu_and_mul(void* out, const void* x, int32_t num_tokens, int32_t inter,
+                               int64_t x_token_stride, int64_t out_token_stride, int dtype,
+                               void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!out || !x || num_tokens < 0 || inter <= 0) return MI_ERR_INVALID_ARG;
+  if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto xx = reinterpret_cast<const uint16_t*>(x);
+  const bool vec = inter % 8 == 0 && x_token_stride % 8 == 0 && out_token_stride % 8 == 0 &&
+                   !(((uintptr_t)out | (uintptr_t)x) & 15);
+  const int per_row = vec ? inter / 8 : inter;
+  int gx = (per_row + 255) / 256;
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, num_tokens), block(256);
+  if (dtype == MI_DTYPE_BF16) {
+    if (vec) hipLaunchKernelGGL((silu_mul_kernel<bf16_tag>), grid, block, 0, s, o, xx, inter, x_token_stride, out_token_stride);
+    else hipLaunchKernelGGL((silu_mul_scalar_kernel<bf16_tag>), grid, block, 0, s, o, xx, inter, x_token_stride, out_token_stride);
+  } else {
+    if (vec) hipLaunchKernelGGL((silu_mul_kernel<f16_tag>), grid, block, 0, s, o, xx, inter, x_token_stride, out_token_stride);
+    else hipLaunchKernelGGL((silu_mul_scalar_kernel<f16_tag>), grid, block, 0, s, o, xx, inter, x_token_stride, out_token_stride);
+  }
+  return launch_status();
+}
+
+extern "C" int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens,
+                                     int32_t vocab, int64_t row_stride, int32_t mask_lo0,
+                                     int32_t mask_hi0, int32_t mask_lo1, int32_t mask_hi1,
+                                     int32_t mask_col, int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!logits || !ids || num_tokens < 0 || vocab <= 0) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(num_tokens), block(256);
+  switch (dtype) {
+    case MI_DTYPE_F32:
+      hipLaunchKernelGGL((mask_argmax_kernel<MI_DTYPE_F32>), grid, block, 0, s, logits, ids, vocab, row_stride, mask_lo0, mask_hi0, mask_lo1, mask_hi1, mask_col);
+      break;
+    case MI_DTYPE_BF16:
+      hipLaunchKernelGGL((mask_argmax_kernel<MI_DTYPE_BF16>), grid, block, 0, s, logits, ids, vocab, row_stride, mask_lo0, mask_hi0, mask_lo1, mask_hi1, mask_col);
+      break;
+    case MI_DTYPE_F16:
+      hipLaunchKernelGGL((mask_argmax_kernel<MI_DTYPE_F16>), grid, block, 0, s, logits, ids, vocab, row_stride, mask_lo0, mask_hi0, mask_lo1, mask_hi1, mask_col);
+      break;
+    default:
+      return MI_ERR_UNSUPPORTED;
+  }
+  return launch_status();
+}

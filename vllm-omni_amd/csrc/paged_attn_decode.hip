@@ -1,0 +1,496 @@
+// A5 — paged-attention decode for gfx950 (MI355X).
+//
+// Replaces the decode half of upstream `Attention.forward` reached from
+// vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:154.
+//
+// Shape of the problem: per generated token and KV head, G = n_q/n_kv (7 for the
+// Qwen2.5-Omni talker) query rows against `ctx` cached keys/values: 3.5 FLOP per KV
+// byte, i.e. an HBM-bound stream.  Design:
+//   * unit of work = one WAVE: (sequence, G query heads sharing one KV head, one
+//     context partition).  No LDS, no barriers: K and V go HBM -> VGPR with 16 B per
+//     lane (`global_load_dwordx4`), one wave-instruction = 1 KiB = 64/LPT whole
+//     token rows of one head, so every fetched 128-B line is used in full.
+//   * lane (g, c): token g of the load, dims [8c, 8c+8).  QK^T = packed bf16/f16
+//     `v_dot2c` on the raw cache words (no up-conversion), partial sums all-reduced
+//     over the LPT lanes of a token with 3-4 `v_add_f32_dpp` (DPP row ops).
+//   * online softmax in fp32 in the exp2 domain; rescale of the accumulators only
+//     when some running max moved (wave vote), which after the first tiles is rare.
+//   * PV either with P kept fp32 (v_fma, exact) or, default, P rounded to the cache
+//     dtype and contracted two tokens at a time with `v_dot2c` (what the reference's
+//     Triton kernel does: `tl.dot(P.to(V.dtype), V)`).
+//   * tiles of 16 tokens, register double-buffered: the loads of tile t+1 are in
+//     flight while tile t is computed (8 KiB per wave in flight).
+//   * partitions of the context are merged by `decode_reduce_kernel`.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace mi {
+namespace {
+
+struct DecodeParams {
+  void* out;
+  const void* q;
+  const void* k_cache;
+  const void* v_cache;
+  const int32_t* block_table;
+  const int32_t* seq_lens;
+  float* part_o;   // [num_seqs, n_q, num_parts, HD]
+  float* part_ml;  // [num_seqs, n_q, num_parts, 2]
+  int32_t num_seqs, num_q_heads, kv_group;  // kv_group = n_q / n_kv
+  int32_t bs_log2, block_table_stride;
+  int32_t num_parts, part_tiles;  // tiles (16 tokens) per partition
+  int32_t total_waves;
+  int32_t out_f32;
+  float scale_log2e;
+  int64_t q_stride, out_stride, blk_stride, tok_stride, head_stride;
+};
+
+constexpr int kTile = 16;
+constexpr float kNegBig = -3.0e38f;
+
+template <typename Tag, int HD, int G, bool PACKED_PV>
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+  using E = Elem<Tag>;
+  constexpr int LPT = HD / 8;      // lanes per token row
+  constexpr int TPL = 64 / LPT;    // token rows per wave-load
+  constexpr int NL = kTile / TPL;  // loads per tile (per K and per V)
+  constexpr int NG = TPL;          // lane groups per wave
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (wave >= p.total_waves) return;
+  const int part = wave % p.num_parts;
+  const int hw = (wave / p.num_parts) % (p.num_q_heads / G);  // q-head chunk
+  const int seq = wave / (p.num_parts * (p.num_q_heads / G));
+  const int qh0 = hw * G;
+  const int kvh = qh0 / p.kv_group;
+
+  const int g = lane / LPT;
+  const int c = lane % LPT;
+
+  const int seq_len = p.seq_lens[seq];
+  const int num_tiles = (seq_len + kTile - 1) / kTile;
+  const int t_begin = part * p.part_tiles;
+  const int t_end = min(t_begin + p.part_tiles, num_tiles);
+  const bool direct = p.num_parts == 1;
+
+  uint16_t* const out16 = reinterpret_cast<uint16_t*>(p.out);
+  float* const out32 = reinterpret_cast<float*>(p.out);
+
+  if (t_begin >= t_end) {
+    // Empty partition.  Only the direct path has to produce output here
+    // (seq_len == 0 -> zeros); otherwise the reduce kernel skips this slot.
+    if (direct) {
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        if (g == h % NG) {
+          const int64_t o = (int64_t)seq * p.out_stride + (int64_t)(qh0 + h) * HD + c * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (p.out_f32) out32[o + e] = 0.f; else out16[o + e] = 0;
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  const uint16_t* const kbase = reinterpret_cast<const uint16_t*>(p.k_cache);
+  const uint16_t* const vbase = reinterpret_cast<const uint16_t*>(p.v_cache);
+  const int32_t* const bt_row = p.block_table + (int64_t)seq * p.block_table_stride;
+  const int bs_mask = (1 << p.bs_log2) - 1;
+  const int last_blk = (seq_len - 1) >> p.bs_log2;
+  const int64_t lane_off = (int64_t)g * p.tok_stride + (int64_t)kvh * p.head_stride + c * 8;
+
+  // ---- q: G heads, this lane's 8 dims, kept packed for dot2 -------------
+  uint4 qv[G];
+  {
+    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)seq * p.q_stride +
+                         (int64_t)qh0 * HD + c * 8;
+#pragma unroll
+    for (int h = 0; h < G; ++h) qv[h] = *reinterpret_cast<const uint4*>(qb + h * HD);
+  }
+
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int h = 0; h < G; ++h) {
+    m[h] = kNegBig;
+    l[h] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+  }
+
+  auto load_tile = [&](int t, uint4(&kr)[NL], uint4(&vr)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int tok0 = t * kTile + i * TPL;  // wave-uniform
+      // clamp: rows past seq_len must not walk into unallocated table entries
+      const int blk = min(tok0 >> p.bs_log2, last_blk);
+      const int phys = bt_row[blk];
+      const int64_t e = (int64_t)phys * p.blk_stride + (int64_t)(tok0 & bs_mask) * p.tok_stride +
+                        lane_off;
+      kr[i] = *reinterpret_cast<const uint4*>(kbase + e);
+      vr[i] = *reinterpret_cast<const uint4*>(vbase + e);
+    }
+  };
+
+  auto compute = [&](int t, const uint4(&kr)[NL], const uint4(&vr_in)[NL]) {
+    // ---- scores: s[h][i] = q_h . k_(token i*TPL+g) -----------------------
+    float s[G][NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        float a = E::dot2(qv[h].x, kr[i].x, 0.f);
+        a = E::dot2(qv[h].y, kr[i].y, a);
+        a = E::dot2(qv[h].z, kr[i].z, a);
+        a = E::dot2(qv[h].w, kr[i].w, a);
+        s[h][i] = group_allreduce_sum<LPT>(a) * p.scale_log2e;
+      }
+    }
+    uint4 vr[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) vr[i] = vr_in[i];
+    const bool tail = (t + 1) * kTile > seq_len;  // wave-uniform
+    if (tail) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const bool valid = t * kTile + i * TPL + g < seq_len;
+        if (!valid) {
+          vr[i] = make_uint4(0, 0, 0, 0);  // 0 * garbage must not make NaN
+#pragma unroll
+          for (int h = 0; h < G; ++h) s[h][i] = -INFINITY;
+        }
+      }
+    }
+    // ---- online softmax (per lane group; groups merged after the loop) ----
+    bool moved = false;
+    float m_new[G];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      float tm = s[h][0];
+#pragma unroll
+      for (int i = 1; i < NL; ++i) tm = fmaxf(tm, s[h][i]);
+      m_new[h] = fmaxf(m[h], tm);
+      moved |= (m_new[h] != m[h]);
+    }
+    if (__any(moved)) {
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        const float alpha = fast_exp2(m[h] - m_new[h]);
+        m[h] = m_new[h];
+        l[h] *= alpha;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[h][e] *= alpha;
+      }
+    }
+    float pr[G][NL];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      float ls = 0.f;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        pr[h][i] = fast_exp2(s[h][i] - m[h]);
+        ls += pr[h][i];
+      }
+      l[h] += ls;
+    }
+    // ---- PV ---------------------------------------------------------------
+    if constexpr (PACKED_PV) {
+#pragma unroll
+      for (int i = 0; i < NL; i += 2) {
+        uint32_t pp[G];
+#pragma unroll
+        for (int h = 0; h < G; ++h) pp[h] = E::pack(pr[h][i], pr[h][i + 1]);
+        const uint32_t a[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+        const uint32_t b[4] = {vr[i + 1].x, vr[i + 1].y, vr[i + 1].z, vr[i + 1].w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          // (tok i, tok i+1) pairs for dims 2w and 2w+1
+          const uint32_t lo = __builtin_amdgcn_perm(b[w], a[w], 0x05040100u);
+          const uint32_t hi = __builtin_amdgcn_perm(b[w], a[w], 0x07060302u);
+#pragma unroll
+          for (int h = 0; h < G; ++h) {
+            acc[h][2 * w] = E::dot2(pp[h], lo, acc[h][2 * w]);
+            acc[h][2 * w + 1] = E::dot2(pp[h], hi, acc[h][2 * w + 1]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const uint32_t a[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float v0 = E::lo(a[w]), v1 = E::hi(a[w]);
+#pragma unroll
+          for (int h = 0; h < G; ++h) {
+            acc[h][2 * w] = __builtin_fmaf(pr[h][i], v0, acc[h][2 * w]);
+            acc[h][2 * w + 1] = __builtin_fmaf(pr[h][i], v1, acc[h][2 * w + 1]);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- main loop: register double buffer, static indexing ----------------
+  uint4 kA[NL], vA[NL], kB[NL], vB[NL];
+  load_tile(t_begin, kA, vA);
+  for (int t = t_begin; t < t_end; t += 2) {
+    const bool has_b = t + 1 < t_end;
+    if (has_b) load_tile(t + 1, kB, vB);
+    compute(t, kA, vA);
+    if (has_b) {
+      if (t + 2 < t_end) load_tile(t + 2, kA, vA);
+      compute(t + 1, kB, vB);
+    }
+  }
+
+  // ---- merge the NG lane groups of the wave -------------------------------
+#pragma unroll
+  for (int h = 0; h < G; ++h) {
+    float mm = m[h];
+#pragma unroll
+    for (int o = LPT; o < 64; o <<= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+    const float f = fast_exp2(m[h] - mm);
+    m[h] = mm;
+    float ll = l[h] * f;
+#pragma unroll
+    for (int o = LPT; o < 64; o <<= 1) ll += __shfl_xor(ll, o, 64);
+    l[h] = ll;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[h][e] * f;
+#pragma unroll
+      for (int o = LPT; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+      acc[h][e] = a;
+    }
+  }
+
+  if (direct) {
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      if (g == h % NG) {
+        const float inv = 1.f / l[h];
+        const int64_t o = (int64_t)seq * p.out_stride + (int64_t)(qh0 + h) * HD + c * 8;
+        if (p.out_f32) {
+          float4 a = {acc[h][0] * inv, acc[h][1] * inv, acc[h][2] * inv, acc[h][3] * inv};
+          float4 b = {acc[h][4] * inv, acc[h][5] * inv, acc[h][6] * inv, acc[h][7] * inv};
+          *reinterpret_cast<float4*>(out32 + o) = a;
+          *reinterpret_cast<float4*>(out32 + o + 4) = b;
+        } else {
+          uint4 r;
+          r.x = E::pack(acc[h][0] * inv, acc[h][1] * inv);
+          r.y = E::pack(acc[h][2] * inv, acc[h][3] * inv);
+          r.z = E::pack(acc[h][4] * inv, acc[h][5] * inv);
+          r.w = E::pack(acc[h][6] * inv, acc[h][7] * inv);
+          *reinterpret_cast<uint4*>(out16 + o) = r;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      if (g == h % NG) {
+        const int64_t slot = ((int64_t)seq * p.num_q_heads + (qh0 + h)) * p.num_parts + part;
+        float* po = p.part_o + slot * HD + c * 8;
+        *reinterpret_cast<float4*>(po) = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+        *reinterpret_cast<float4*>(po + 4) = make_float4(acc[h][4], acc[h][5], acc[h][6], acc[h][7]);
+        if (c == 0) *reinterpret_cast<float2*>(p.part_ml + slot * 2) = make_float2(m[h], l[h]);
+      }
+    }
+  }
+}
+
+// Merge the partitions of one (sequence, q head): one wave per pair.
+template <typename Tag, int HD>
+__global__ __launch_bounds__(64) void decode_reduce_kernel(const DecodeParams p) {
+  using E = Elem<Tag>;
+  constexpr int DPL = HD / 64;  // dims per lane
+  const int qh = blockIdx.x;
+  const int seq = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int seq_len = p.seq_lens[seq];
+  const int num_tiles = (seq_len + kTile - 1) / kTile;
+  const int np = min(p.num_parts, (num_tiles + p.part_tiles - 1) / p.part_tiles);
+  const int64_t slot0 = ((int64_t)seq * p.num_q_heads + qh) * p.num_parts;
+  const float2* ml = reinterpret_cast<const float2*>(p.part_ml) + slot0;
+  float mm = kNegBig;
+  for (int i = 0; i < np; ++i) mm = fmaxf(mm, ml[i].x);
+  float L = 0.f, a[DPL];
+#pragma unroll
+  for (int d = 0; d < DPL; ++d) a[d] = 0.f;
+  for (int i = 0; i < np; ++i) {
+    const float2 x = ml[i];
+    const float w = fast_exp2(x.x - mm);
+    L += w * x.y;
+    const float* po = p.part_o + (slot0 + i) * HD + lane * DPL;
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) a[d] += w * po[d];
+  }
+  const float inv = np > 0 ? 1.f / L : 0.f;
+  const int64_t o = (int64_t)seq * p.out_stride + (int64_t)qh * HD + lane * DPL;
+#pragma unroll
+  for (int d = 0; d < DPL; ++d) {
+    const float r = a[d] * inv;
+    if (p.out_f32) reinterpret_cast<float*>(p.out)[o + d] = r;
+    else reinterpret_cast<uint16_t*>(p.out)[o + d] = E::to_bits(r);
+  }
+}
+
+template <typename Tag, int HD, int G>
+int launch_decode(const DecodeParams& p, bool packed, hipStream_t stream) {
+  const int grid = (p.total_waves + 3) / 4;
+  if (packed)
+    hipLaunchKernelGGL((decode_kernel<Tag, HD, G, true>), dim3(grid), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((decode_kernel<Tag, HD, G, false>), dim3(grid), dim3(256), 0, stream, p);
+  if (p.num_parts > 1)
+    hipLaunchKernelGGL((decode_reduce_kernel<Tag, HD>), dim3(p.num_q_heads, p.num_seqs), dim3(64),
+                       0, stream, p);
+  return launch_status();
+}
+
+template <typename Tag, int HD>
+int dispatch_group(const DecodeParams& p, int G, bool packed, hipStream_t stream) {
+  switch (G) {
+    case 1: return launch_decode<Tag, HD, 1>(p, packed, stream);
+    case 2: return launch_decode<Tag, HD, 2>(p, packed, stream);
+    case 3: return launch_decode<Tag, HD, 3>(p, packed, stream);
+    case 4: return launch_decode<Tag, HD, 4>(p, packed, stream);
+    case 5: return launch_decode<Tag, HD, 5>(p, packed, stream);
+    case 6: return launch_decode<Tag, HD, 6>(p, packed, stream);
+    case 7: return launch_decode<Tag, HD, 7>(p, packed, stream);
+    case 8: return launch_decode<Tag, HD, 8>(p, packed, stream);
+  }
+  return MI_ERR_UNSUPPORTED;
+}
+
+// q heads handled per wave: the largest divisor of the GQA group that is <= 8
+int heads_per_wave(int kv_group) {
+  for (int g = 8; g >= 1; --g)
+    if (kv_group % g == 0) return g;
+  return 1;
+}
+
+int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// PV contraction mode: 1 = P rounded to the cache dtype + dot2 (default), 0 = fp32 P.
+int packed_pv_default() {
+  static int v = [] {
+    const char* e = getenv("MI_DECODE_FP32_PV");
+    return (e && e[0] == '1') ? 0 : 1;
+  }();
+  return v;
+}
+
+}  // namespace
+}  // namespace mi
+
+extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
+                                                       int32_t max_seq_len) {
+  // Want enough waves to fill 256 CUs x 8-12 resident waves a few times over, but
+  // partitions long enough (>= 128 tokens) that the per-wave prologue/merge is noise.
+  if (num_seqs <= 0 || num_kv_heads <= 0 || max_seq_len <= 0) return 128;
+  const int64_t target_waves = 8192;
+  const int64_t pairs = (int64_t)num_seqs * num_kv_heads;
+  int32_t best = 128;
+  for (int32_t ps = 128; ps <= 16384; ps *= 2) {
+    const int64_t parts = (max_seq_len + ps - 1) / ps;
+    if (pairs * parts >= target_waves || ps == 128) best = ps;
+    else break;
+  }
+  if (best > mi::round_up(max_seq_len, mi::kTile)) best = mi::round_up(max_seq_len, mi::kTile);
+  return best;
+}
+
+extern "C" int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
+                                                        int32_t head_dim, int32_t max_seq_len,
+                                                        int32_t partition_size) {
+  if (num_seqs <= 0 || num_q_heads <= 0 || head_dim <= 0 || max_seq_len <= 0 ||
+      partition_size <= 0)
+    return 0;
+  const int64_t parts = (max_seq_len + partition_size - 1) / partition_size;
+  if (parts <= 1) return 0;
+  return (int64_t)num_seqs * num_q_heads * parts * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cache,
+                                    const void* v_cache, const int32_t* block_table,
+                                    const int32_t* seq_lens, int32_t num_seqs,
+                                    int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                    int32_t block_size, int32_t block_table_stride,
+                                    int32_t max_seq_len, float scale, int64_t q_token_stride,
+                                    int64_t out_token_stride, int64_t cache_block_stride,
+                                    int64_t cache_token_stride, int64_t cache_head_stride,
+                                    int32_t partition_size, void* workspace,
+                                    int64_t workspace_bytes, int dtype, int out_dtype,
+                                    void* stream) {
+  using namespace mi;
+  if (num_seqs == 0) return MI_OK;
+  if (!out || !q || !k_cache || !v_cache || !block_table || !seq_lens) return MI_ERR_INVALID_ARG;
+  if (num_seqs < 0 || num_q_heads <= 0 || num_kv_heads <= 0 || max_seq_len <= 0 ||
+      block_table_stride <= 0)
+    return MI_ERR_INVALID_ARG;
+  if (num_q_heads % num_kv_heads != 0) return MI_ERR_INVALID_ARG;
+  if (head_dim != 64 && head_dim != 128) return MI_ERR_UNSUPPORTED;
+  if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
+  if (out_dtype != dtype && out_dtype != MI_DTYPE_F32) return MI_ERR_UNSUPPORTED;
+  const int tpl = 64 / (head_dim / 8);
+  if (!is_pow2(block_size) || block_size < tpl) return MI_ERR_UNSUPPORTED;
+  // 16-byte vector access: every stride must keep 8-element alignment
+  if (q_token_stride % 8 || out_token_stride % 8 || cache_block_stride % 8 ||
+      cache_token_stride % 8 || cache_head_stride % 8)
+    return MI_ERR_INVALID_ARG;
+  if (((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) & 15)
+    return MI_ERR_INVALID_ARG;
+
+  if (partition_size <= 0)
+    partition_size = mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len);
+  if (partition_size % kTile) return MI_ERR_INVALID_ARG;
+  const int num_parts = (max_seq_len + partition_size - 1) / partition_size;
+  const int64_t need = mi_paged_attn_decode_workspace_bytes(num_seqs, num_q_heads, head_dim,
+                                                            max_seq_len, partition_size);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MI_ERR_WORKSPACE;
+
+  const int kv_group = num_q_heads / num_kv_heads;
+  const int G = heads_per_wave(kv_group);
+
+  DecodeParams p;
+  p.out = out;
+  p.q = q;
+  p.k_cache = k_cache;
+  p.v_cache = v_cache;
+  p.block_table = block_table;
+  p.seq_lens = seq_lens;
+  p.part_o = reinterpret_cast<float*>(workspace);
+  p.part_ml = p.part_o ? p.part_o + (int64_t)num_seqs * num_q_heads * num_parts * head_dim : nullptr;
+  p.num_seqs = num_seqs;
+  p.num_q_heads = num_q_heads;
+  p.kv_group = kv_group;
+  p.bs_log2 = __builtin_ctz((unsigned)block_size);
+  p.block_table_stride = block_table_stride;
+  p.num_parts = num_parts;
+  p.part_tiles = partition_size / kTile;
+  const int64_t total = (int64_t)num_seqs * (num_q_heads / G) * num_parts;
+  if (total > INT32_MAX) return MI_ERR_UNSUPPORTED;
+  p.total_waves = (int32_t)total;
+  p.out_f32 = out_dtype == MI_DTYPE_F32;
+  p.scale_log2e = scale * kLog2e;
+  p.q_stride = q_token_stride;
+  p.out_stride = out_token_stride;
+  p.blk_stride = cache_block_stride;
+  p.tok_stride = cache_token_stride;
+  p.head_stride = cache_head_stride;
+
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool packed = packed_pv_default() != 0;
+  if (dtype == MI_DTYPE_BF16) {
+    return head_dim == 128 ? dispatch_group<bf16_tag, 128>(p, G, packed, s)
+                           : dispatch_group<bf16_tag, 64>(p, G, packed, s);
+  }
+  return head_dim == 128 ? dispatch_group<f16_tag, 128>(p, G, packed, s)
+                         : dispatch_group<f16_tag, 64>(p, G, packed, s);
+}

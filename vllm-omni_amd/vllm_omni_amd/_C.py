@@ -1,0 +1,91 @@
+"""ctypes binding of the C ABI (include/vllm_omni_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``.  If it is
+missing this module raises ImportError: the product path never falls back to torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvllm_omni_amd.so")
+
+MI_DTYPE_F16, MI_DTYPE_BF16, MI_DTYPE_F32 = 0, 1, 2
+MI_OK = 0
+MI_ERR_INVALID_ARG, MI_ERR_UNSUPPORTED, MI_ERR_WORKSPACE = -1, -2, -3
+MI_ERR_LAUNCH, MI_ERR_EXHAUSTED, MI_ERR_STATE = -4, -5, -6
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); mirrors include/vllm_omni_amd.h declaration by declaration
+_P = c_void_p
+SIGNATURES = {
+    "mi_abi_version": (c_int, []),
+    "mi_error_string": (c_char_p, [c_int]),
+    "mi_reshape_and_cache": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                      c_int64, c_int64, c_int64, c_int64, c_int64, c_int, _P]),
+    "mi_rope_neox_and_cache": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int32, c_int32, _P, _P,
+                                        c_float, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                        c_int32, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                        c_int64, c_int, _P]),
+    "mi_paged_attn_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mi_paged_attn_decode_auto_partition": (c_int32, [c_int32, c_int32, c_int32]),
+    "mi_paged_attn_decode": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                      c_int32, c_int32, c_int32, c_float, c_int64, c_int64,
+                                      c_int64, c_int64, c_int64, c_int32, _P, c_int64, c_int,
+                                      c_int, _P]),
+    "mi_paged_attn_prefill": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32,
+                                       c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_int, _P]),
+    "mi_rms_norm": (c_int, [_P, _P, _P, c_float, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
+    "mi_fused_add_rms_norm": (c_int, [_P, _P, _P, c_float, c_int32, c_int32, c_int64, c_int64,
+                                       c_int, _P]),
+    "mi_silu_and_mul": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
+    "mi_mask_logits_argmax": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
+                                       c_int32, c_int32, c_int32, c_int, _P]),
+    "mi_dynamic_int8_quant": (c_int, [_P, _P, _P, c_int32, c_int32, c_int64, c_int, _P]),
+    "mi_int8_gemm_dequant": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64,
+                                      c_int, _P]),
+    "mi_blockpool_create": (_P, [c_int32]),
+    "mi_blockpool_destroy": (None, [_P]),
+    "mi_blockpool_num_free": (c_int32, [_P]),
+    "mi_blockpool_num_blocks": (c_int32, [_P]),
+    "mi_blockpool_alloc": (c_int, [_P, c_int32, POINTER(c_int32)]),
+    "mi_blockpool_ref": (c_int, [_P, POINTER(c_int32), c_int32]),
+    "mi_blockpool_free": (c_int, [_P, POINTER(c_int32), c_int32]),
+    "mi_blockpool_refcount": (c_int32, [_P, c_int32]),
+    "mi_compute_slot_mapping": (c_int, [_P, _P, c_int32, _P, _P, c_int32, c_int32]),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.mi_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libvllm_omni_amd.so ABI version {got} != expected {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+LIB_PATH = _LIB_PATH
+
+
+class MIError(RuntimeError):
+    def __init__(self, fn: str, code: int):
+        self.code = code
+        msg = lib.mi_error_string(code)
+        super().__init__(f"{fn} failed: {code} ({msg.decode() if msg else '?'})")
+
+
+def check(fn: str, code: int) -> None:
+    if code != MI_OK:
+        raise MIError(fn, code)

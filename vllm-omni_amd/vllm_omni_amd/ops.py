@@ -1,0 +1,249 @@
+"""Torch-tensor wrappers over the C ABI.  Plumbing only: no arithmetic happens here.
+
+Every function launches on torch's *current* stream (so it is hipGraph-capturable under
+``torch.cuda.graph``) and raises on non-GPU tensors — there is no CPU path in the product.
+Reference call sites these stand in for are cited in include/vllm_omni_amd.h.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _C
+from ._C import check, lib
+
+_DT = {torch.float16: _C.MI_DTYPE_F16, torch.bfloat16: _C.MI_DTYPE_BF16, torch.float32: _C.MI_DTYPE_F32}
+
+
+def _dt(t: torch.dtype) -> int:
+    try:
+        return _DT[t]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t}") from None
+
+
+def _gpu(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "vllm_omni_amd ops run only on the GPU (HIP kernels); got a CPU tensor. "
+                "There is no CPU fallback by design."
+            )
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _cache_strides(kc: torch.Tensor, vc: torch.Tensor):
+    """k_cache / v_cache are views shaped [num_blocks, block_size, kv_heads, head_dim]."""
+    if kc.dim() != 4 or vc.shape != kc.shape or kc.stride() != vc.stride() or kc.stride(3) != 1:
+        raise ValueError("k_cache/v_cache must be [num_blocks, block_size, kv_heads, head_dim] views "
+                         "with identical strides and contiguous head_dim")
+    return kc.stride(0), kc.stride(1), kc.stride(2)
+
+
+# --------------------------------------------------------------------------- A4
+def reshape_and_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                      slot_mapping: torch.Tensor) -> None:
+    """cache[slot] = (k, v)[token] for slot >= 0.  k, v: [T, kv_heads, head_dim] (or flattened)."""
+    _gpu(k, v, k_cache, v_cache, slot_mapping)
+    nb, bs, h, d = k_cache.shape
+    t = k.shape[0]
+    if slot_mapping.dtype != torch.int64 or slot_mapping.numel() < t:
+        raise ValueError("slot_mapping must be int64 with >= num_tokens entries")
+    cb, ct, ch = _cache_strides(k_cache, v_cache)
+    check("mi_reshape_and_cache", lib.mi_reshape_and_cache(
+        _p(k), _p(v), _p(k_cache), _p(v_cache), _p(slot_mapping), t, h, d, bs,
+        k.stride(0), v.stride(0), cb, ct, ch, _dt(k.dtype), _stream()))
+
+
+# --------------------------------------------------------------------- A7/A7b/A4
+def rope_neox_and_cache(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor],
+                        positions: torch.Tensor, cos_sin_cache: torch.Tensor, head_dim: int,
+                        k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None,
+                        slot_mapping: Optional[torch.Tensor] = None,
+                        mrope_section: Optional[torch.Tensor] = None,
+                        q_norm_weight: Optional[torch.Tensor] = None,
+                        k_norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 1e-6) -> None:
+    """In-place (q/k-norm ->) neox RoPE on q [T, nq*d], k [T, nkv*d]; optional KV-cache write.
+
+    positions int64 [T] or [3, T] (then ``mrope_section`` is an int32 *host* tensor of 3 entries);
+    cos_sin_cache fp32 [max_position, rot_dim].
+    """
+    _gpu(q, k, v, positions, cos_sin_cache, k_cache, v_cache, slot_mapping, q_norm_weight, k_norm_weight)
+    t = q.shape[0]
+    nq = q.shape[-1] // head_dim if q.dim() == 2 else q.shape[1]
+    nkv = k.shape[-1] // head_dim if k.dim() == 2 else k.shape[1]
+    if positions.dtype != torch.int64 or cos_sin_cache.dtype != torch.float32:
+        raise TypeError("positions must be int64 and cos_sin_cache float32")
+    max_pos, rot_dim = cos_sin_cache.shape
+    sec = None
+    row_stride = 0
+    if positions.dim() == 2:
+        if mrope_section is None:
+            raise ValueError("positions is [3, T]: mrope_section required")
+        sec = (ctypes.c_int32 * 3)(*[int(x) for x in mrope_section])
+        row_stride = positions.stride(0)
+        if positions.stride(1) != 1:
+            raise ValueError("positions rows must be contiguous")
+    bs = cb = ct = ch = 0
+    if k_cache is not None:
+        cb, ct, ch = _cache_strides(k_cache, v_cache)
+        bs = k_cache.shape[1]
+        if slot_mapping is None or slot_mapping.dtype != torch.int64:
+            raise ValueError("slot_mapping (int64) required with k_cache")
+    check("mi_rope_neox_and_cache", lib.mi_rope_neox_and_cache(
+        _p(q), _p(k), _p(v), _p(positions), row_stride,
+        ctypes.cast(sec, ctypes.c_void_p) if sec is not None else None,
+        _p(cos_sin_cache), max_pos, rot_dim, _p(q_norm_weight), _p(k_norm_weight), float(norm_eps),
+        _p(k_cache), _p(v_cache), _p(slot_mapping), t, nq, nkv, head_dim, bs,
+        q.stride(0), k.stride(0), v.stride(0) if v is not None else 0, cb, ct, ch,
+        _dt(q.dtype), _stream()))
+
+
+# --------------------------------------------------------------------------- A5
+def decode_auto_partition(num_seqs: int, num_kv_heads: int, max_seq_len: int) -> int:
+    return int(lib.mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len))
+
+
+def decode_workspace_bytes(num_seqs: int, num_q_heads: int, head_dim: int, max_seq_len: int,
+                           partition_size: int) -> int:
+    return int(lib.mi_paged_attn_decode_workspace_bytes(num_seqs, num_q_heads, head_dim, max_seq_len,
+                                                        partition_size))
+
+
+def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                      block_table: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, scale: float,
+                      num_kv_heads: Optional[int] = None, partition_size: int = 0,
+                      workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[s, h] = softmax(q[s,h] . K^T * scale) . V over the paged cache (one query per sequence).
+
+    q, out: [S, nq*d] (or [S, nq, d]); block_table int32 [S, max_blocks]; seq_lens int32 [S].
+    ``max_seq_len`` is a host-side upper bound of seq_lens (sizes the launch).
+    ``out`` may be fp32 for parity measurement.  Returns ``out``.
+    """
+    _gpu(out, q, k_cache, v_cache, block_table, seq_lens, workspace)
+    nb, bs, hkv, d = k_cache.shape
+    s = q.shape[0]
+    nq = q.numel() // (s * d) if s else 0
+    if block_table.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise TypeError("block_table and seq_lens must be int32")
+    if block_table.stride(1) != 1:
+        raise ValueError("block_table rows must be contiguous")
+    cb, ct, ch = _cache_strides(k_cache, v_cache)
+    if s == 0:
+        return out
+    if partition_size <= 0:
+        partition_size = decode_auto_partition(s, hkv, max_seq_len)
+    need = decode_workspace_bytes(s, nq, d, max_seq_len, partition_size)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    check("mi_paged_attn_decode", lib.mi_paged_attn_decode(
+        _p(out), _p(q), _p(k_cache), _p(v_cache), _p(block_table), _p(seq_lens), s, nq, hkv, d, bs,
+        block_table.stride(0), int(max_seq_len), float(scale), q.stride(0), out.stride(0), cb, ct, ch,
+        int(partition_size), _p(workspace),
+        workspace.numel() * workspace.element_size() if workspace is not None else 0,
+        _dt(q.dtype), _dt(out.dtype), _stream()))
+    return out
+
+
+# --------------------------------------------------------------------------- A6
+def paged_attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                       block_table: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
+                       max_query_len: int, scale: float) -> torch.Tensor:
+    """Varlen causal attention of query chunks against the paged cache (chunked prefill)."""
+    _gpu(out, q, k_cache, v_cache, block_table, seq_lens, query_start_loc)
+    nb, bs, hkv, d = k_cache.shape
+    t = q.shape[0]
+    nq = q.numel() // (t * d) if t else 0
+    s = seq_lens.shape[0]
+    cb, ct, ch = _cache_strides(k_cache, v_cache)
+    if t == 0 or s == 0:
+        return out
+    check("mi_paged_attn_prefill", lib.mi_paged_attn_prefill(
+        _p(out), _p(q), _p(k_cache), _p(v_cache), _p(block_table), _p(seq_lens), _p(query_start_loc),
+        s, t, int(max_query_len), nq, hkv, d, bs, block_table.stride(0), float(scale),
+        q.stride(0), out.stride(0), cb, ct, ch, _dt(q.dtype), _stream()))
+    return out
+
+
+# --------------------------------------------------------------------------- A8
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _gpu(x, weight, out)
+    x2 = x.view(-1, x.shape[-1])
+    if out is None:
+        out = torch.empty_like(x)
+    o2 = out.view(-1, x.shape[-1])
+    check("mi_rms_norm", lib.mi_rms_norm(_p(o2), _p(x2), _p(weight), float(eps), x2.shape[0], x2.shape[1],
+                                          x2.stride(0), o2.stride(0), _dt(x.dtype), _stream()))
+    return out
+
+
+def fused_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+    """In place: residual <- x + residual; x <- rmsnorm(residual) * weight."""
+    _gpu(x, residual, weight)
+    x2 = x.view(-1, x.shape[-1])
+    r2 = residual.view(-1, x.shape[-1])
+    check("mi_fused_add_rms_norm", lib.mi_fused_add_rms_norm(
+        _p(x2), _p(r2), _p(weight), float(eps), x2.shape[0], x2.shape[1], x2.stride(0), r2.stride(0),
+        _dt(x.dtype), _stream()))
+
+
+# --------------------------------------------------------------------------- A9
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _gpu(x, out)
+    inter = x.shape[-1] // 2
+    x2 = x.view(-1, x.shape[-1])
+    if out is None:
+        out = torch.empty(*x.shape[:-1], inter, dtype=x.dtype, device=x.device)
+    o2 = out.view(-1, inter)
+    check("mi_silu_and_mul", lib.mi_silu_and_mul(_p(o2), _p(x2), x2.shape[0], inter, x2.stride(0),
+                                                  o2.stride(0), _dt(x.dtype), _stream()))
+    return out
+
+
+# -------------------------------------------------------------------------- A11
+def mask_logits_argmax(logits: torch.Tensor, ranges: Sequence[tuple[int, int]] = (), col: int = -1,
+                       ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Set up to two [lo, hi) column ranges and one column to -1e9 in place; greedy argmax."""
+    _gpu(logits, ids)
+    if len(ranges) > 2:
+        raise ValueError("at most two masked ranges")
+    r = list(ranges) + [(0, 0)] * (2 - len(ranges))
+    t, v = logits.shape
+    if ids is None:
+        ids = torch.empty(t, dtype=torch.int64, device=logits.device)
+    check("mi_mask_logits_argmax", lib.mi_mask_logits_argmax(
+        _p(logits), _p(ids), t, v, logits.stride(0), r[0][0], r[0][1], r[1][0], r[1][1], int(col),
+        _dt(logits.dtype), _stream()))
+    return ids
+
+
+# -------------------------------------------------------------------------- A13
+def dynamic_int8_quant(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    _gpu(x)
+    x2 = x.view(-1, x.shape[-1])
+    xq = torch.empty(x2.shape, dtype=torch.int8, device=x.device)
+    xs = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    check("mi_dynamic_int8_quant", lib.mi_dynamic_int8_quant(_p(xq), _p(xs), _p(x2), x2.shape[0], x2.shape[1],
+                                                              x2.stride(0), _dt(x.dtype), _stream()))
+    return xq, xs
+
+
+def int8_gemm_dequant(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+                      bias: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+    _gpu(xq, x_scale, wq, w_scale, bias)
+    m, k = xq.shape
+    n = wq.shape[0]
+    out = torch.empty(m, n, dtype=out_dtype, device=xq.device)
+    check("mi_int8_gemm_dequant", lib.mi_int8_gemm_dequant(
+        _p(out), _p(xq), _p(x_scale), _p(wq), _p(w_scale), _p(bias), m, n, k, out.stride(0),
+        _dt(out_dtype), _stream()))
+    return out
