@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""Headline benchmark: talker decode tokens/s (+ achieved HBM GB/s of the paged-attention decode
+kernel) at BASELINE.json's shape — Qwen2.5-Omni-7B talker, global batch 256, ctx 4096, bf16.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one engine step of the decode hot path over the whole batch: scheduler output ->
+``GPUARModelRunner.execute_model`` (persistent-batch update, input prep, 28 decoder layers with the
+HIP kernels, logits, mask, argmax) -> ``sample_tokens`` (ids + hidden states back on the host).
+Synthetic data: random-init weights of the named architecture, KV cache pre-filled N(0,1),
+non-contiguous block tables, every sequence at exactly ``ctx`` tokens and NOT growing during the
+timed region, so bytes/step are constant.  Inputs are resident in HBM when the
+timed region starts.
+
+Parallelism by N: 1 -> tp1, 2 -> tp2, 4 -> tp4, 8 -> dp2 x tp4 (28 query heads do not divide by 8:
+vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:91); the global batch is fixed (strong
+scaling).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vllm-omni_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="GLOBAL batch (sequences decoded per step)")
+    ap.add_argument("--ctx", type=int, default=4096)
+    ap.add_argument("--config", default="qwen2_5_omni_talker")
+    ap.add_argument("--block-size", type=int, default=16)
+    ap.add_argument("--kv-layout", default="NB2")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps for per-launch timing")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-layers", type=int, default=2)
+    ap.add_argument("--cpu-baseline-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+def parallel_plan(n_gpus: int, cfg) -> tuple[int, int, str]:
+    """(tp, dp, label).  TP must divide the query heads; what is left becomes data parallel."""
+    tp = n_gpus
+    while tp > 1 and (cfg.num_attention_heads % tp or (cfg.num_key_value_heads < tp and tp % cfg.num_key_value_heads)
+                      or (cfg.num_key_value_heads >= tp and cfg.num_key_value_heads % tp)):
+        tp //= 2
+    dp = n_gpus // tp
+    return tp, dp, (f"tp{tp}" if dp == 1 else f"dp{dp}xtp{tp}")
+
+
+class SyntheticScheduler:
+    """Feeds the runner what ``OmniARScheduler.schedule()`` would for a steady decode batch, using the
+    real block manager for the block ids.  Sequences sit at ``ctx`` tokens and do not grow."""
+
+    def __init__(self, batch: int, ctx: int, block_size: int, vocab: int, rank_seed: int):
+        from vllm_omni_amd.kv_cache import KVCacheManager
+        from vllm_omni_amd.sched_output import Request, SamplingParams
+
+        self.batch, self.ctx = batch, ctx
+        blocks_per_seq = -(-ctx // block_size)
+        self.num_blocks = batch * blocks_per_seq + 1
+        self.kv = KVCacheManager(self.num_blocks, block_size)
+        # fragment the pool so block tables are NON-contiguous: take every block, free in random order
+        all_ids = self.kv.block_pool.get_new_blocks(self.num_blocks - 1)
+        rng = np.random.default_rng(2 + rank_seed)
+        self.kv.block_pool.free_blocks(rng.permutation(all_ids).tolist())
+        self.requests = []
+        for i in range(batch):
+            r = Request(f"req-{i}", rng.integers(0, vocab, size=ctx).tolist(), SamplingParams(temperature=0.0))
+            blocks = self.kv.allocate_slots(r, ctx)
+            assert blocks is not None
+            r.num_computed_tokens = ctx - 1  # everything but the token decoded this step is cached
+            self.requests.append(r)
+        self._first = True
+
+    def schedule(self):
+        from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SchedulerOutput
+
+        self.kv.new_step_starts()
+        n = self.batch
+        sched = {r.request_id: 1 for r in self.requests}
+        if self._first:
+            self._first = False
+            new = [NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params,
+                                  self.kv.get_block_ids(r.request_id), r.num_computed_tokens) for r in self.requests]
+            return SchedulerOutput(scheduled_new_reqs=new, num_scheduled_tokens=sched, total_num_scheduled_tokens=n)
+        cached = CachedRequestData(req_ids=[r.request_id for r in self.requests], new_token_ids=[],
+                                   new_block_ids=[None] * n,
+                                   num_computed_tokens=[self.ctx - 1] * n, num_output_tokens=[1] * n)
+        return SchedulerOutput(scheduled_cached_reqs=cached, num_scheduled_tokens=sched, total_num_scheduled_tokens=n)
+
+
+def fill_kv_cache(runner, seed: int) -> None:
+    from vllm_omni_amd.kv_cache import normalize_layer_kv
+
+    g = torch.Generator(device=runner.device).manual_seed(seed)
+    for kv in runner.kv_caches:
+        kb, vb = normalize_layer_kv(kv)
+        base = kv if isinstance(kv, torch.Tensor) else kb._base
+        base.normal_(0.0, 1.0, generator=g)
+
+
+def time_decode_launches(runner, steps: int):
+    """Instrumented pass: HIP events around every paged-attention decode launch (on the stream the
+    kernel is launched on), eager mode, same inputs as the timed region.  Returns (avg ms, launches)."""
+    from vllm_omni_amd import ops
+
+    events: list[tuple[torch.cuda.Event, torch.cuda.Event]] = []
+    orig = ops.paged_attn_decode
+
+    def timed(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(*a, **k)
+        e1.record()
+        events.append((e0, e1))
+        return r
+
+    ops.paged_attn_decode = timed
+    was = runner.enforce_eager
+    runner.enforce_eager = True
+    try:
+        sched = runner._bench_sched
+        for _ in range(steps):
+            runner.execute_model(sched.schedule())
+            runner.sample_tokens()
+        torch.cuda.synchronize()
+    finally:
+        ops.paged_attn_decode = orig
+        runner.enforce_eager = was
+    ms = [a.elapsed_time(b) for a, b in events]
+    return (float(np.mean(ms)) if ms else float("nan")), len(ms)
+
+
+def cpu_baseline(cfg, batch: int, ctx: int, layers: int, block_size: int):
+    """The oracle (CPU restatement of the reference's decode-step semantics — the reference has no
+    CPU execution path) timed on this box's host cores on a bounded sample."""
+    from oracle import ref_ops, ref_talker
+
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    torch.set_num_threads(threads)
+    w = ref_talker.random_weights(cfg, seed=0, dtype=torch.bfloat16, num_layers=layers)
+    w = {k: v.float() for k, v in w.items()}
+    bps = -(-ctx // block_size)
+    nb = batch * bps + 1
+    d, nkv = cfg.head_dim, cfg.num_key_value_heads
+    kvs = [(torch.randn(nb, block_size, nkv, d), torch.randn(nb, block_size, nkv, d)) for _ in range(layers)]
+    table = (torch.randperm(nb - 1)[: batch * bps] + 1).view(batch, bps).to(torch.int32)
+    seq_lens = torch.full((batch,), ctx, dtype=torch.int32)
+    qsl = torch.arange(batch + 1, dtype=torch.int32)
+    pos = torch.full((batch,), ctx - 1, dtype=torch.int64)
+    slots = ref_ops.slot_mapping(table, torch.arange(batch), pos, block_size)
+    csc = ref_ops.build_cos_sin_cache(d, ctx + 1, cfg.rope_theta)
+    emb = torch.randn(batch, cfg.embedding_size)
+
+    def run():
+        h = ref_talker.talker_step(cfg, w, emb, pos, kvs, table, seq_lens, qsl, slots, csc, None, num_layers=layers)
+        return ref_talker.logits_and_greedy(cfg, w, h, None)
+
+    run()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or time.perf_counter() - t0 < 8.0:
+        run()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    # the sample ran `layers` of L layers: scale the per-layer part to the full depth
+    t_head0 = time.perf_counter()
+    ref_talker.logits_and_greedy(cfg, w, torch.randn(batch, cfg.hidden_size), None)
+    t_head = time.perf_counter() - t_head0
+    full = (dt - t_head) * cfg.num_hidden_layers / layers + t_head
+    return {"value": batch / full, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"torch-fp32 oracle of the decode step, {batch} sequences x ctx {ctx}, {layers} of "
+                      f"{cfg.num_hidden_layers} layers + lm_head timed ({dt * 1e3:.0f} ms/step), layer time scaled "
+                      f"to {cfg.num_hidden_layers} layers; CPU restatement of reference semantics, not a reference CPU backend"}
+
+
+def main():
+    a = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.distributed import init_distributed_environment
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json(a.config)
+    tp, dp, plabel = parallel_plan(world, cfg)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        init_distributed_environment(world, rank, tp, backend="nccl", device=dev)
+    if a.batch % dp:
+        raise SystemExit("global batch must divide by the data-parallel degree")
+    local_batch = a.batch // dp
+
+    max_model_len = a.ctx + a.block_size
+    runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=local_batch, max_model_len=max_model_len,
+                              max_num_batched_tokens=max(local_batch, 256), block_size=a.block_size,
+                              kv_layout=a.kv_layout, enforce_eager=a.eager, seed=0)
+    runner.load_model()
+    # every rank of a TP group must see the same schedule: seed by data-parallel replica only
+    sched = SyntheticScheduler(local_batch, a.ctx, a.block_size, cfg.vocab_size, rank_seed=rank // tp)
+    runner.initialize_kv_cache(sched.num_blocks)
+    fill_kv_cache(runner, seed=1)
+    runner._bench_sched = sched
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        runner.execute_model(sched.schedule())
+        return runner.sample_tokens()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    tokens_per_s = a.batch * a.steps / elapsed
+
+    # ---- roofline of the dominant kernel (paged-attention decode), this rank ----
+    attn = runner.model.language_model.model.layers[0].self_attn
+    # unique KV bytes one launch must read: K+V, local kv heads, head_dim, 2 B, ctx tokens, local batch
+    algo_bytes = 2 * attn.num_kv_heads * attn.head_dim * 2 * a.ctx * local_batch
+    kern_ms, launches = time_decode_launches(runner, a.roofline_steps)
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_decode_bytes_per_launch.json")
+    if os.path.exists(prof):
+        try:
+            with open(prof) as f:
+                pj = json.load(f)
+            if pj.get("batch") == local_batch and pj.get("ctx") == a.ctx and pj.get("tp") == tp:
+                traffic = pj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "mi::decode_kernel (paged-attention decode)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 4),
+                "launches_timed": launches,
+                "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
+
+    out = {
+        "metric": "decode tokens/s, Qwen-Omni-7B talker, bs=256 ctx=4k", "value": round(tokens_per_s, 1),
+        "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random-init weights, N(0,1) KV cache, random non-contiguous block tables, fixed ctx)",
+        "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
+                   "global_batch": a.batch, "seq_len": a.ctx, "parallelism": plabel,
+                   "hipgraph": bool(not a.eager and tp == 1), "kv_layout": a.kv_layout,
+                   "decode_partition": runner._decode_part},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_batch, a.ctx, a.cpu_baseline_layers, a.block_size)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,7 +106,11 @@ int mi_rope_neox_and_cache(void* q, void* k, const void* v, const int64_t* posit
  * on seq_lens[] that sizes the grid, so the launch is graph-replayable while
  * sequences grow.  seq_lens[s] == 0 writes zeros.
  * out_dtype: MI_DTYPE_F32 is accepted for parity measurement.
+ * flags: MI_DECODE_PACKED_PV rounds the (unnormalised) probabilities to the cache
+ * dtype and contracts P.V two tokens at a time with v_dot2c (what flash-style
+ * kernels, incl. the reference's TRITON_ATTN backend, do); without it P stays fp32.
  * ---------------------------------------------------------------------- */
+#define MI_DECODE_PACKED_PV 1
 int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
                                              int32_t head_dim, int32_t max_seq_len,
                                              int32_t partition_size);
@@ -118,7 +122,7 @@ int mi_paged_attn_decode(void* out, const void* q, const void* k_cache, const vo
                          int64_t out_token_stride, int64_t cache_block_stride,
                          int64_t cache_token_stride, int64_t cache_head_stride,
                          int32_t partition_size, void* workspace, int64_t workspace_bytes,
-                         int dtype, int out_dtype, void* stream);
+                         int dtype, int out_dtype, int32_t flags, void* stream);
 /* Partition size the auto heuristic would pick (exposed for bench/DESIGN). */
 int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
                                             int32_t max_seq_len);
@@ -179,6 +183,21 @@ int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_
                           int64_t row_stride, int32_t mask_lo0, int32_t mask_hi0,
                           int32_t mask_lo1, int32_t mask_hi1, int32_t mask_col, int dtype,
                           void* stream);
+
+/* ------------------------------------------------------------------------
+ * A11 — talker per-step input embedding, batched:
+ *   out[t] = embed_table[token_ids[t]] (+ reply_rows[reply_idx[t]] when reply_idx[t] >= 0)
+ * i.e. `thinker_reply_part[0:1] + embed_input_ids(last token)` of
+ * `_thinker_to_talker_decode_one_step` (vllm_omni/model_executor/models/qwen2_5_omni/
+ * qwen2_5_omni.py:796-804) for every decode request at once.  fp32 add, one rounding.
+ * reply_rows / reply_idx may be NULL (plain embedding gather).  Token ids outside
+ * [0, vocab) yield a zero row (never an out-of-bounds read).
+ * ---------------------------------------------------------------------- */
+int mi_talker_decode_embeds(void* out, const void* embed_table, const int64_t* token_ids,
+                            const void* reply_rows, const int64_t* reply_idx,
+                            int32_t num_tokens, int32_t embed_dim, int32_t vocab,
+                            int64_t num_reply_rows, int64_t out_token_stride, int dtype,
+                            void* stream);
 
 /* ------------------------------------------------------------------------
  * A13 — W8A8 int8 linear (scheme of vllm_omni/quantization/int8_config.py:

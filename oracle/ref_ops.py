@@ -106,9 +106,12 @@ def scatter_rows_by_slot(cache: torch.Tensor, slot_map: torch.Tensor, rows: torc
 
     core/prefix_cache.py:124-133 (``flat_cache[unpadded_slot_mapping] = hidden_states``).
     """
-    flat = cache.view(cache.shape[0] * cache.shape[1], -1)
+    b = cache.shape[1]
     keep = slot_map >= 0
-    flat[slot_map[keep]] = rows.reshape(rows.shape[0], -1)[keep].to(cache.dtype)
+    s = slot_map[keep].to(torch.int64)
+    # row `slot` of the flattened (nb*b, F) view == cache[slot // b, slot % b]; indexing the
+    # 2-D way also works on strided K / V views of a stacked cache tensor
+    cache[s // b, s % b] = rows[keep].reshape(-1, *cache.shape[2:]).to(cache.dtype)
 
 
 def reshape_and_cache(k: torch.Tensor, v: torch.Tensor, key_blocks: torch.Tensor, value_blocks: torch.Tensor,

@@ -1,0 +1,113 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+CPU restatement of one talker engine step: projection -> 28x
+{RMSNorm, QKV, RoPE, KV write, paged attention, o_proj, RMSNorm, gate_up, SiLU-mul, down} ->
+final norm -> logits -> bad_word mask -> greedy argmax.
+
+Layer order / residual flow: vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:146-156
+(attention), :205-225 (layer), :300-326 (stack); talker wrapper: qwen2_5_omni_talker.py:123-174;
+per-step input: qwen2_5_omni.py:796-804.  Arithmetic in fp32 with the model-dtype rounding points of
+a 16-bit checkpoint at every op boundary (``round_to``).  Weight names are the fused names the
+product exposes (``named_weights``).  Parity status: see oracle/ref_ops.py header.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import ref_ops as R
+
+F32 = torch.float32
+
+
+def _lin(x, w, b=None, rt=None):
+    y = x @ w.to(F32).t()
+    if b is not None:
+        y = y + b.to(F32)
+    return R._rt(y, rt)
+
+
+def decode_embeds(weights: dict, last_token_ids: torch.Tensor, step_vec: Optional[torch.Tensor], rt=None):
+    e = weights["language_model.model.embed_tokens.weight"].to(F32)[last_token_ids]
+    return e if step_vec is None else R._rt(step_vec.to(F32) + e, rt)
+
+
+def talker_step(cfg, weights: dict, inputs_embeds: torch.Tensor, positions: torch.Tensor, kv_caches: Sequence,
+                block_table: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
+                slot_map: torch.Tensor, cos_sin_cache: torch.Tensor, round_to: Optional[torch.dtype] = None,
+                num_layers: Optional[int] = None):
+    """Run the stack on ``inputs_embeds`` [T, E] (all requests' scheduled tokens, varlen).
+
+    kv_caches: per layer (key_blocks, value_blocks) CPU views, UPDATED IN PLACE at ``slot_map``.
+    Returns (hidden [T, H] after the final norm, as fp32 values on the ``round_to`` grid).
+    """
+    rt = round_to
+    d, nq, nkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+    t = inputs_embeds.shape[0]
+    h = _lin(inputs_embeds.to(F32), weights["thinker_to_talker_proj.weight"], weights["thinker_to_talker_proj.bias"], rt)
+    residual = None
+    nl = cfg.num_hidden_layers if num_layers is None else num_layers
+    pos1d = positions if positions.dim() == 1 else positions
+    for i in range(nl):
+        p = f"language_model.model.layers.{i}."
+        if residual is None:
+            residual = h
+            x = R.rms_norm(h, weights[p + "input_layernorm.weight"], cfg.rms_norm_eps, rt)
+        else:
+            x, residual = R.fused_add_rms_norm(h, residual, weights[p + "input_layernorm.weight"], cfg.rms_norm_eps, rt)
+        qkv = _lin(x, weights[p + "self_attn.qkv_proj.weight"], weights.get(p + "self_attn.qkv_proj.bias"), rt)
+        q, k, v = qkv.split([nq * d, nkv * d, nkv * d], dim=-1)
+        if cfg.qk_norm:
+            q = R.head_rms_norm(q, weights[p + "self_attn.q_norm.weight"], d, cfg.rms_norm_eps, rt)
+            k = R.head_rms_norm(k, weights[p + "self_attn.k_norm.weight"], d, cfg.rms_norm_eps, rt)
+        q = R.rope_neox(pos1d, q, d, cos_sin_cache, cfg.mrope_section if positions.dim() == 2 else None, rt)
+        k = R.rope_neox(pos1d, k, d, cos_sin_cache, cfg.mrope_section if positions.dim() == 2 else None, rt)
+        kb, vb = kv_caches[i]
+        R.reshape_and_cache(k.view(t, nkv, d), v.view(t, nkv, d), kb, vb, slot_map)
+        a = R.paged_attention_prefill(q.view(t, nq, d), kb, vb, block_table, seq_lens, query_start_loc, d ** -0.5)
+        a = R._rt(a.reshape(t, nq * d), rt)
+        o = _lin(a, weights[p + "self_attn.o_proj.weight"], None, rt)
+        x, residual = R.fused_add_rms_norm(o, residual, weights[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, rt)
+        gu = _lin(x, weights[p + "mlp.gate_up_proj.weight"], None, rt)
+        h = _lin(R.silu_and_mul(gu, rt), weights[p + "mlp.down_proj.weight"], None, rt)
+    hidden, _ = R.fused_add_rms_norm(h, residual, weights["language_model.model.norm.weight"], cfg.rms_norm_eps, rt)
+    return hidden
+
+
+def logits_and_greedy(cfg, weights: dict, hidden: torch.Tensor, suppress_start_id: Optional[int], round_to=None):
+    logits = _lin(hidden, weights["language_model.lm_head.weight"], None, round_to)
+    logits = R.bad_word_processor(logits, suppress_start_id, cfg.tts_codec_end_token_id, cfg.tts_codec_start_token_id)
+    return logits, logits.argmax(-1)
+
+
+def random_weights(cfg, seed: int = 0, dtype=torch.bfloat16, num_layers: Optional[int] = None) -> dict:
+    """N(0, 0.02^2) linears, RMSNorm weight 1 + N(0, 0.01^2), small biases."""
+    g = torch.Generator().manual_seed(seed)
+    nl = cfg.num_hidden_layers if num_layers is None else num_layers
+
+    def w(*shape, std=0.02, mean=0.0):
+        return (torch.randn(*shape, generator=g) * std + mean).to(dtype)
+
+    d, nq, nkv, h, i = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.hidden_size, cfg.intermediate_size
+    out = {
+        "thinker_to_talker_proj.weight": w(h, cfg.embedding_size),
+        "thinker_to_talker_proj.bias": w(h),
+        "language_model.lm_head.weight": w(cfg.vocab_size, h),
+        "language_model.model.embed_tokens.weight": w(cfg.vocab_size, cfg.embedding_size),
+        "language_model.model.norm.weight": w(h, std=0.01, mean=1.0),
+    }
+    for li in range(nl):
+        p = f"language_model.model.layers.{li}."
+        out[p + "self_attn.qkv_proj.weight"] = w((nq + 2 * nkv) * d, h)
+        if cfg.attention_bias:
+            out[p + "self_attn.qkv_proj.bias"] = w((nq + 2 * nkv) * d)
+        out[p + "self_attn.o_proj.weight"] = w(h, nq * d)
+        if cfg.qk_norm:
+            out[p + "self_attn.q_norm.weight"] = w(d, std=0.01, mean=1.0)
+            out[p + "self_attn.k_norm.weight"] = w(d, std=0.01, mean=1.0)
+        out[p + "mlp.gate_up_proj.weight"] = w(2 * i, h)
+        out[p + "mlp.down_proj.weight"] = w(h, i)
+        out[p + "input_layernorm.weight"] = w(h, std=0.01, mean=1.0)
+        out[p + "post_attention_layernorm.weight"] = w(h, std=0.01, mean=1.0)
+    return out

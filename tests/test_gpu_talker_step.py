@@ -1,0 +1,152 @@
+"""GPU parity of the whole decode step through the runner's two-phase API:
+execute_model -> sample_tokens, eager and hipGraph replay, vs the CPU oracle step.
+
+Tolerance: hidden states after 2 layers are compared with rtol 2e-2 / atol 2e-2 (bf16 activations:
+every op boundary rounds to 2^-8 relative and GEMM accumulation order differs between hipBLASLt
+and the oracle); greedy token ids must agree wherever the oracle's top-2 logit margin exceeds the
+logit tolerance (multi-step greedy agreement is the telling test).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops, ref_talker
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, cfg_name, ctxs, enforce_eager, mrope):
+    from vllm_omni_amd.kv_cache import KVCacheManager, normalize_layer_kv
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import Request, SamplingParams
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json(cfg_name)
+    if not mrope:
+        cfg.mrope_section = None
+    B, bs = len(ctxs), 16
+    runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=8, max_model_len=256, max_num_batched_tokens=64,
+                              block_size=bs, enforce_eager=enforce_eager, max_reply_rows=64, seed=0)
+    runner.load_model()
+    w = ref_talker.random_weights(cfg, seed=3)
+    loaded = runner.model.load_weights({k: v.to(dev) for k, v in w.items()})
+    assert loaded == set(w.keys())
+    nb = 64
+    runner.initialize_kv_cache(nb)
+    g = torch.Generator().manual_seed(5)
+    cpu_caches = []
+    for kv in runner.kv_caches:
+        init = torch.randn(nb, 2, bs, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
+        kv.copy_(init.to(dev))
+        cpu_caches.append((init[:, 0].clone(), init[:, 1].clone()))
+    mgr = KVCacheManager(nb, bs)
+    scramble = mgr.block_pool.get_new_blocks(nb - 1)
+    mgr.block_pool.free_blocks(np.random.default_rng(0).permutation(scramble).tolist())
+    reqs = []
+    for i, c in enumerate(ctxs):
+        r = Request(f"r{i}", list(range(c + 1)), SamplingParams(temperature=0.0))
+        r.additional_information = {"thinker_reply_part": torch.randn(3, cfg.embedding_size, generator=g).to(torch.bfloat16)}
+        assert mgr.allocate_slots(r, c + 1) is not None
+        r.num_computed_tokens = c
+        reqs.append(r)
+    return cfg, runner, w, cpu_caches, mgr, reqs
+
+
+@pytest.mark.parametrize("enforce_eager", [True, False])
+def test_decode_steps_match_oracle(dev, enforce_eager):
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SchedulerOutput
+
+    ctxs = [5, 16, 40, 1]
+    # decode positions are 1-D (all three M-RoPE rows equal at decode => plain RoPE)
+    cfg, runner, w, cpu_caches, mgr, reqs = _setup(dev, "mini_talker", ctxs, enforce_eager, False)
+    runner.model.set_suppress_start_id(cfg.tts_codec_mask_token_id)
+    B, bs = len(reqs), 16
+    csc = ref_ops.build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
+    last_ids = torch.tensor([r.prompt_token_ids[-1] for r in reqs], dtype=torch.int64)
+    table = torch.zeros(B, 16, dtype=torch.int32)
+    for i, r in enumerate(reqs):
+        ids = mgr.get_block_ids(r.request_id)[0]
+        table[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    agree = total = 0
+    for step in range(3):
+        sched = {r.request_id: 1 for r in reqs}
+        if step == 0:
+            so = SchedulerOutput(scheduled_new_reqs=[
+                NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id),
+                               r.num_computed_tokens, additional_information=r.additional_information) for r in reqs],
+                num_scheduled_tokens=sched, total_num_scheduled_tokens=B)
+        else:
+            new_blocks = []
+            for r in reqs:
+                nb_ = mgr.allocate_slots(r, 1)
+                assert nb_ is not None
+                new_blocks.append(nb_.get_block_ids() if nb_.blocks[0] else None)
+            for i, r in enumerate(reqs):
+                ids = mgr.get_block_ids(r.request_id)[0]
+                table[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+            so = SchedulerOutput(scheduled_cached_reqs=CachedRequestData(
+                req_ids=[r.request_id for r in reqs], new_block_ids=new_blocks,
+                num_computed_tokens=[r.num_computed_tokens for r in reqs], num_output_tokens=[step] * B),
+                num_scheduled_tokens=sched, total_num_scheduled_tokens=B)
+        assert runner.execute_model(so) is None
+        with pytest.raises(RuntimeError, match="State error"):
+            runner.execute_model(so)
+        out = runner.sample_tokens()
+        with pytest.raises(RuntimeError, match="State error"):
+            runner.sample_tokens()
+        order = [out.req_id_to_index[r.request_id] for r in reqs]
+        # ---- oracle for the same step ----
+        pos = torch.tensor([r.num_computed_tokens for r in reqs], dtype=torch.int64)
+        step_vec = torch.stack([r.additional_information["thinker_reply_part"][step] for r in reqs])
+        emb = ref_talker.decode_embeds(w, last_ids, step_vec, torch.bfloat16)
+        seq_lens = (pos + 1).to(torch.int32)
+        slots = ref_ops.slot_mapping(table, torch.arange(B), pos, bs)
+        hidden = ref_talker.talker_step(cfg, w, emb, pos, cpu_caches, table, seq_lens,
+                                        torch.arange(B + 1, dtype=torch.int32), slots, csc, torch.bfloat16)
+        logits, ids = ref_talker.logits_and_greedy(cfg, w, hidden, cfg.tts_codec_mask_token_id, torch.bfloat16)
+        got_hidden = torch.stack([out.pooler_output[j]["hidden"][0] for j in order]).float()
+        torch.testing.assert_close(got_hidden, hidden, rtol=2e-2, atol=2e-2)
+        got_ids = torch.tensor([out.sampled_token_ids[j][0] for j in order])
+        top2 = logits.topk(2, dim=-1).values
+        confident = (top2[:, 0] - top2[:, 1]) > 0.05
+        total += int(confident.sum())
+        agree += int((got_ids[confident] == ids[confident]).sum())
+        # masked columns ([mask_id, V) and the codec BOS column) can never be sampled
+        assert not ((got_ids >= cfg.tts_codec_mask_token_id) | (got_ids == cfg.tts_codec_start_token_id)).any()
+        # the KV rows written this step match the oracle's cache bit-for-bit in placement
+        from vllm_omni_amd.kv_cache import normalize_layer_kv
+        for li, kv in enumerate(runner.kv_caches):
+            kb, vb = normalize_layer_kv(kv)
+            b_idx, off = (slots // bs), (slots % bs)
+            torch.testing.assert_close(kb.cpu()[b_idx, off].float(), cpu_caches[li][0][b_idx, off].float(),
+                                       rtol=3e-2, atol=3e-2)
+        # feed the GPU's tokens to both sides so later steps stay comparable
+        last_ids = got_ids.clone()
+        for r, t in zip(reqs, got_ids.tolist()):
+            r.num_computed_tokens += 1
+            r.output_token_ids.append(t)
+    assert total == 0 or agree == total, f"greedy ids disagree on {total - agree} of {total} confident rows"
+
+
+def test_finished_requests_are_removed_and_kv_extracted(dev):
+    from vllm_omni_amd.sched_output import NewRequestData, SchedulerOutput
+
+    cfg, runner, w, cpu_caches, mgr, reqs = _setup(dev, "mini_talker", [20, 9], True, False)
+    so = SchedulerOutput(scheduled_new_reqs=[
+        NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id),
+                       r.num_computed_tokens) for r in reqs],
+        num_scheduled_tokens={r.request_id: 1 for r in reqs}, total_num_scheduled_tokens=2)
+    runner.execute_model(so)
+    runner.sample_tokens()
+    blocks = mgr.get_block_ids("r0")[0]
+    so2 = SchedulerOutput(finished_req_ids={"r0"},
+                          finished_requests_needing_kv_transfer={"r0": {"block_ids": blocks, "seq_len": 21}})
+    out = runner.execute_model(so2)
+    assert out.kv_extracted_req_ids == ["r0"] and "r0" not in runner.input_batch.req_id_to_index
+    got = runner.kv_extracted["r0"]
+    assert len(got["key_cache"]) == cfg.num_hidden_layers
+    assert got["key_cache"][0].shape == (21, cfg.num_key_value_heads, cfg.head_dim)
+    exp = ref_ops.extract_kv(cpu_caches[0][0], cpu_caches[0][1], blocks, 21)
+    # rows 0..19 were pre-filled identically on both sides (row 20 was written by the step on the GPU only)
+    assert torch.equal(got["key_cache"][0][:20].cpu(), exp[0][:20])
+    assert runner.input_batch.req_ids == ["r1"]

@@ -1,0 +1,71 @@
+"""Micro-benchmark of the paged-attention decode kernel alone (one layer of the workload).
+
+    python tools/bench_decode_kernel.py [--batch 256 --ctx 4096 --nq 28 --nkv 4 --d 128]
+
+Reports achieved algorithmic GB/s = (2 * nkv * d * 2 B * ctx * batch) / kernel time, for
+both P.V modes and a sweep of partition sizes.  Timing with HIP events on the launch stream.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vllm-omni_amd"))
+
+import torch  # noqa: E402
+
+from vllm_omni_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--ctx", type=int, default=4096)
+    ap.add_argument("--nq", type=int, default=28)
+    ap.add_argument("--nkv", type=int, default=4)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--layout", default="NB2")
+    ap.add_argument("--parts", default="0,256,512,1024,2048,4096")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    blocks_per_seq = (a.ctx + a.bs - 1) // a.bs
+    nb = a.batch * blocks_per_seq + 1
+    if a.layout == "NB2":
+        kv = torch.empty(nb, 2, a.bs, a.nkv, a.d, dtype=torch.bfloat16, device=dev).normal_()
+        kb, vb = kv[:, 0], kv[:, 1]
+    else:
+        kv = torch.empty(nb, 2, a.nkv, a.bs, a.d, dtype=torch.bfloat16, device=dev).normal_()
+        kb, vb = kv[:, 0].permute(0, 2, 1, 3), kv[:, 1].permute(0, 2, 1, 3)
+    table = (torch.randperm(nb - 1, device=dev)[: a.batch * blocks_per_seq] + 1).view(a.batch, -1).to(torch.int32)
+    seq_lens = torch.full((a.batch,), a.ctx, dtype=torch.int32, device=dev)
+    q = torch.randn(a.batch, a.nq * a.d, dtype=torch.bfloat16, device=dev)
+    out = torch.empty_like(q)
+    algo_bytes = 2 * a.nkv * a.d * 2 * a.ctx * a.batch
+    print(f"layout={a.layout} batch={a.batch} ctx={a.ctx} nq={a.nq} nkv={a.nkv} d={a.d} "
+          f"algorithmic bytes/launch={algo_bytes / 1e9:.3f} GB")
+    for packed in (False, True):
+        for ps in [int(x) for x in a.parts.split(",")]:
+            eff = ps or ops.decode_auto_partition(a.batch, a.nkv, a.ctx)
+            ws = torch.empty(max(1, ops.decode_workspace_bytes(a.batch, a.nq, a.d, a.ctx, eff)), dtype=torch.uint8,
+                             device=dev)
+            for _ in range(3):
+                ops.paged_attn_decode(out, q, kb, vb, table, seq_lens, a.ctx, a.d ** -0.5, partition_size=eff,
+                                      workspace=ws, packed_pv=packed)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                ops.paged_attn_decode(out, q, kb, vb, table, seq_lens, a.ctx, a.d ** -0.5, partition_size=eff,
+                                      workspace=ws, packed_pv=packed)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print(f"packed_pv={int(packed)} partition={eff:5d}{'(auto)' if ps == 0 else '      '} "
+                  f"{ms * 1e3:9.1f} us  {algo_bytes / ms / 1e6:8.1f} GB/s  ({algo_bytes / ms / 1e6 / 8000:.1%} of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -198,6 +198,35 @@ __global__ __launch_bounds__(256) void mask_argmax_kernel(void* logits, int64_t*
   }
 }
 
+// out[t] = embed[ids[t]] (+ reply[idx[t]]): one workgroup per token, 16 B per lane.
+template <typename Tag>
+__global__ __launch_bounds__(256) void talker_embeds_kernel(uint16_t* __restrict__ out,
+                                                            const uint16_t* __restrict__ table,
+                                                            const int64_t* __restrict__ ids,
+                                                            const uint16_t* __restrict__ reply,
+                                                            const int64_t* __restrict__ ridx, int dim,
+                                                            int vocab, int64_t nreply,
+                                                            int64_t out_stride) {
+  using E = Elem<Tag>;
+  const int t = blockIdx.x;
+  const int64_t id = ids[t];
+  const bool ok = id >= 0 && id < vocab;
+  int64_t r = (reply && ridx) ? ridx[t] : -1;
+  if (r >= nreply) r = -1;
+  const uint16_t* src = table + (ok ? id : 0) * (int64_t)dim;
+  for (int ch = threadIdx.x; ch < dim / 8; ch += 256) {
+    uint4 a = ok ? *reinterpret_cast<const uint4*>(src + ch * 8) : make_uint4(0, 0, 0, 0);
+    if (r >= 0) {
+      const uint4 b = *reinterpret_cast<const uint4*>(reply + r * (int64_t)dim + ch * 8);
+      a.x = E::pack(E::lo(a.x) + E::lo(b.x), E::hi(a.x) + E::hi(b.x));
+      a.y = E::pack(E::lo(a.y) + E::lo(b.y), E::hi(a.y) + E::hi(b.y));
+      a.z = E::pack(E::lo(a.z) + E::lo(b.z), E::hi(a.z) + E::hi(b.z));
+      a.w = E::pack(E::lo(a.w) + E::lo(b.w), E::hi(a.w) + E::hi(b.w));
+    }
+    *reinterpret_cast<uint4*>(out + t * out_stride + ch * 8) = a;
+  }
+}
+
 template <typename Tag>
 int launch_rms(void* out, const void* x, void* residual, const void* w, float eps, int T, int H,
                int64_t xs, int64_t os, int64_t rs, hipStream_t s) {
@@ -308,5 +337,29 @@ extern "C" int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tok
     default:
       return MI_ERR_UNSUPPORTED;
   }
+  return launch_status();
+}
+
+extern "C" int mi_talker_decode_embeds(void* out, const void* embed_table, const int64_t* token_ids,
+                                       const void* reply_rows, const int64_t* reply_idx,
+                                       int32_t num_tokens, int32_t embed_dim, int32_t vocab,
+                                       int64_t num_reply_rows, int64_t out_token_stride, int dtype,
+                                       void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!out || !embed_table || !token_ids || num_tokens < 0 || embed_dim <= 0 || vocab <= 0)
+    return MI_ERR_INVALID_ARG;
+  if (embed_dim % 8 || out_token_stride % 8) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)out | (uintptr_t)embed_table | (uintptr_t)reply_rows) & 15) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto tb = reinterpret_cast<const uint16_t*>(embed_table);
+  auto rp = reinterpret_cast<const uint16_t*>(reply_rows);
+  if (dtype == MI_DTYPE_BF16)
+    hipLaunchKernelGGL((talker_embeds_kernel<bf16_tag>), dim3(num_tokens), dim3(256), 0, s, o, tb, token_ids, rp, reply_idx, embed_dim, vocab, num_reply_rows, out_token_stride);
+  else if (dtype == MI_DTYPE_F16)
+    hipLaunchKernelGGL((talker_embeds_kernel<f16_tag>), dim3(num_tokens), dim3(256), 0, s, o, tb, token_ids, rp, reply_idx, embed_dim, vocab, num_reply_rows, out_token_stride);
+  else
+    return MI_ERR_UNSUPPORTED;
   return launch_status();
 }

@@ -377,15 +377,6 @@ int heads_per_wave(int kv_group) {
 
 int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-// PV contraction mode: 1 = P rounded to the cache dtype + dot2 (default), 0 = fp32 P.
-int packed_pv_default() {
-  static int v = [] {
-    const char* e = getenv("MI_DECODE_FP32_PV");
-    return (e && e[0] == '1') ? 0 : 1;
-  }();
-  return v;
-}
-
 }  // namespace
 }  // namespace mi
 
@@ -427,7 +418,7 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
                                     int64_t cache_token_stride, int64_t cache_head_stride,
                                     int32_t partition_size, void* workspace,
                                     int64_t workspace_bytes, int dtype, int out_dtype,
-                                    void* stream) {
+                                    int32_t flags, void* stream) {
   using namespace mi;
   if (num_seqs == 0) return MI_OK;
   if (!out || !q || !k_cache || !v_cache || !block_table || !seq_lens) return MI_ERR_INVALID_ARG;
@@ -486,7 +477,7 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   p.head_stride = cache_head_stride;
 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const bool packed = packed_pv_default() != 0;
+  const bool packed = (flags & MI_DECODE_PACKED_PV) != 0;
   if (dtype == MI_DTYPE_BF16) {
     return head_dim == 128 ? dispatch_group<bf16_tag, 128>(p, G, packed, s)
                            : dispatch_group<bf16_tag, 64>(p, G, packed, s);

@@ -16,6 +16,7 @@ MI_OK = 0
 MI_ERR_INVALID_ARG, MI_ERR_UNSUPPORTED, MI_ERR_WORKSPACE = -1, -2, -3
 MI_ERR_LAUNCH, MI_ERR_EXHAUSTED, MI_ERR_STATE = -4, -5, -6
 ABI_VERSION = 1
+MI_DECODE_PACKED_PV = 1
 
 # name -> (restype, argtypes); mirrors include/vllm_omni_amd.h declaration by declaration
 _P = c_void_p
@@ -33,7 +34,7 @@ SIGNATURES = {
     "mi_paged_attn_decode": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, c_int32, c_int32, c_float, c_int64, c_int64,
                                       c_int64, c_int64, c_int64, c_int32, _P, c_int64, c_int,
-                                      c_int, _P]),
+                                      c_int, c_int32, _P]),
     "mi_paged_attn_prefill": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                                        c_int64, c_int64, c_int64, c_int64, c_int64, c_int, _P]),
@@ -43,6 +44,8 @@ SIGNATURES = {
     "mi_silu_and_mul": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_mask_logits_argmax": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int, _P]),
+    "mi_talker_decode_embeds": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64,
+                                         c_int, _P]),
     "mi_dynamic_int8_quant": (c_int, [_P, _P, _P, c_int32, c_int32, c_int64, c_int, _P]),
     "mi_int8_gemm_dequant": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64,
                                       c_int, _P]),

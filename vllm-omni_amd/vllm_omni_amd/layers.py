@@ -1,0 +1,358 @@
+"""Host-side mirror of the upstream layers the talker is wired from.
+
+Same names, argument meaning and call order as the classes imported at
+vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:10-17 (``RMSNorm``, ``SiluAndMul``,
+``get_rope``, ``Attention``, ``QKVParallelLinear``, ``MergedColumnParallelLinear``,
+``RowParallelLinear``).  Every forward is a call into the HIP kernels (``ops``) except the dense
+GEMMs, which are library GEMMs (hipBLASLt through ``torch.nn.functional.linear``; SURVEY A10
+"not a named kernel").  Inference only; parameters are plain tensors.
+"""
+from __future__ import annotations
+
+import math
+from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                          tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
+from .kv_cache import normalize_layer_kv
+
+
+# ------------------------------------------------------------------ forward context
+@dataclass
+class AttentionMetadata:
+    """What the attention kernels need for one step (built by the runner each step).
+
+    Mirrors the fields upstream's metadata builders produce and the reference forwards through
+    ``set_forward_context(attn_metadata, ..., slot_mapping=...)``
+    (vllm_omni/worker/gpu_ar_model_runner.py:493-510).  Requests are ordered decodes-first.
+    """
+
+    num_actual_tokens: int
+    max_query_len: int
+    query_start_loc: torch.Tensor  # int32 [num_reqs + 1], device
+    seq_lens: torch.Tensor         # int32 [num_reqs], device (context INCLUDING this step's tokens)
+    max_seq_len: int               # host upper bound of seq_lens (sizes the decode launch)
+    block_table: torch.Tensor      # int32 [num_reqs, max_blocks], device
+    slot_mapping: torch.Tensor     # int64 [num_tokens_padded], device, -1 = padding
+    num_reqs: int = 0
+    num_decodes: int = 0           # leading requests with query_len == 1
+    decode_partition_size: int = 0
+    decode_workspace: Optional[torch.Tensor] = None
+
+
+@dataclass
+class ForwardContext:
+    attn_metadata: Optional[AttentionMetadata] = None
+    slot_mapping: Optional[torch.Tensor] = None
+
+
+_FORWARD_CONTEXT: Optional[ForwardContext] = None
+
+
+def get_forward_context() -> ForwardContext:
+    if _FORWARD_CONTEXT is None:
+        raise RuntimeError("forward context is not set; wrap the model call in set_forward_context()")
+    return _FORWARD_CONTEXT
+
+
+@contextmanager
+def set_forward_context(attn_metadata: Optional[AttentionMetadata], slot_mapping: Optional[torch.Tensor] = None):
+    global _FORWARD_CONTEXT
+    prev = _FORWARD_CONTEXT
+    _FORWARD_CONTEXT = ForwardContext(attn_metadata, slot_mapping if slot_mapping is not None
+                                      else (attn_metadata.slot_mapping if attn_metadata else None))
+    try:
+        yield _FORWARD_CONTEXT
+    finally:
+        _FORWARD_CONTEXT = prev
+
+
+# --------------------------------------------------------------------------- norms
+class RMSNorm:
+    """``RMSNorm(hidden, eps)``: ``norm(x)`` and ``norm(x, residual) -> (normed, new_residual)``
+    (qwen2_old.py:202-203,212-216,223).  The fused form works IN PLACE on both arguments."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6, dtype=torch.bfloat16, device=None):
+        self.weight = torch.ones(hidden_size, dtype=dtype, device=device)
+        self.variance_epsilon = eps
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None):
+        if residual is None:
+            return ops.rms_norm(x, self.weight, self.variance_epsilon)
+        ops.fused_add_rms_norm(x, residual, self.weight, self.variance_epsilon)
+        return x, residual
+
+
+class SiluAndMul:
+    """``out = silu(x[..., :d]) * x[..., d:]`` (qwen2_old.py:63,67)."""
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.silu_and_mul(x)
+
+
+# ---------------------------------------------------------------------------- rope
+def build_cos_sin_cache(rot_dim: int, max_position: int, base: float, device=None,
+                        table_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """fp32 [max_position, rot_dim] = cos | sin, inv_freq = base^(-2i/rot_dim) (upstream
+    ``get_rope`` table layout).  ``table_dtype`` other than fp32 ROUNDS the table through that
+    dtype first (upstream casts its table to the model dtype; the kernel always reads fp32)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, rot_dim, 2, dtype=torch.float32) / rot_dim))
+    t = torch.arange(max_position, dtype=torch.float32)
+    freqs = torch.outer(t, inv_freq)
+    table = torch.cat([freqs.cos(), freqs.sin()], dim=-1)
+    if table_dtype != torch.float32:
+        table = table.to(table_dtype).to(torch.float32)
+    return table.to(device) if device is not None else table
+
+
+class RotaryEmbedding:
+    """Neox-style rotary embedding; ``forward(positions, q, k)`` rotates in place and returns
+    ``(q, k)`` like upstream's op (qwen2_old.py:153).  ``positions`` [T] or [3, T] (M-RoPE)."""
+
+    def __init__(self, head_size: int, rotary_dim: int, max_position: int, base: float, is_neox_style: bool = True,
+                 mrope_section: Optional[Sequence[int]] = None, device=None):
+        if not is_neox_style:
+            raise NotImplementedError("only neox (rotate-half) pairing is on the talker path (qwen2_old.py:129)")
+        self.head_size = head_size
+        self.rotary_dim = rotary_dim
+        self.max_position_embeddings = max_position
+        self.base = base
+        self.mrope_section = list(mrope_section) if mrope_section else None
+        self.cos_sin_cache = build_cos_sin_cache(rotary_dim, max_position, base, device)
+
+    def _section(self, positions: torch.Tensor):
+        if positions.dim() == 2:
+            if self.mrope_section is None:
+                raise ValueError("[3, T] positions need rope_parameters['mrope_section']")
+            return torch.tensor(self.mrope_section, dtype=torch.int32)
+        return None
+
+    def __call__(self, positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor):
+        ops.rope_neox_and_cache(q, k, None, positions, self.cos_sin_cache, self.head_size,
+                                mrope_section=self._section(positions))
+        return q, k
+
+    forward = __call__
+
+
+def get_rope(head_size: int, max_position: int, is_neox_style: bool = True, rope_parameters: Optional[dict] = None,
+             device=None) -> RotaryEmbedding:
+    """``get_rope(head_size=, max_position=, is_neox_style=True, rope_parameters={"base": θ, **scaling})``
+    as called at qwen2_old.py:126-134.  An ``mrope_section`` entry selects M-RoPE."""
+    rp = dict(rope_parameters or {})
+    base = float(rp.get("base", rp.get("rope_theta", 10000.0)))
+    return RotaryEmbedding(head_size, head_size, max_position, base, is_neox_style, rp.get("mrope_section"), device)
+
+
+# ------------------------------------------------------------------------- attention
+class MI355XAttentionBackend:
+    """Backend descriptor, in the terms the reference probes on upstream's ``AttentionBackend``
+    (vllm_omni/worker/gpu_ar_model_runner.py:431-435; cache shape = layout A2)."""
+
+    forward_includes_kv_cache_update = True
+    accept_output_buffer = True
+
+    @staticmethod
+    def get_name() -> str:
+        return "MI355X_HIP_ATTN"
+
+    @staticmethod
+    def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int, head_size: int) -> tuple[int, ...]:
+        return (num_blocks, 2, block_size, num_kv_heads, head_size)
+
+    @staticmethod
+    def get_supported_head_sizes() -> list[int]:
+        return [64, 128]
+
+    @staticmethod
+    def get_supported_block_sizes() -> list[int]:
+        return [8, 16, 32]
+
+
+class Attention:
+    """``Attention(num_heads, head_size, scale, num_kv_heads=...)``; ``forward(q, k, v)`` writes K/V
+    into the paged cache at ``slot_mapping`` and attends over ``block_table`` (qwen2_old.py:135-144,154).
+    """
+
+    backend = MI355XAttentionBackend
+
+    def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
+                 prefix: str = ""):
+        self.num_heads = num_heads
+        self.head_size = head_size
+        self.scale = scale
+        self.num_kv_heads = num_kv_heads or num_heads
+        self.layer_name = prefix
+        self.kv_cache = None  # bound by the runner (bind_kv_cache)
+        self._kb = self._vb = None
+
+    def bind_kv_cache(self, layer_kv) -> None:
+        pair = normalize_layer_kv(layer_kv)
+        if pair is None:
+            raise ValueError(f"{self.layer_name}: unsupported KV cache layout")
+        self.kv_cache = layer_kv
+        self._kb, self._vb = pair
+
+    def _attend(self, q: torch.Tensor, md: AttentionMetadata, out: torch.Tensor) -> torch.Tensor:
+        nd = md.num_decodes
+        if nd > 0:
+            ops.paged_attn_decode(out[:nd], q[:nd], self._kb, self._vb, md.block_table[:nd], md.seq_lens[:nd],
+                                  md.max_seq_len, self.scale, partition_size=md.decode_partition_size,
+                                  workspace=md.decode_workspace)
+        if nd < md.num_reqs:
+            t0 = nd  # decodes come first and have one token each
+            ops.paged_attn_prefill(out[t0:md.num_actual_tokens], q[t0:md.num_actual_tokens], self._kb, self._vb,
+                                   md.block_table[nd:md.num_reqs], md.seq_lens[nd:md.num_reqs],
+                                   md.query_start_loc[nd:md.num_reqs + 1] - nd, md.max_query_len, self.scale)
+        return out
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, output: Optional[torch.Tensor] = None):
+        md = get_forward_context().attn_metadata
+        out = torch.empty_like(q) if output is None else output
+        if md is None:  # profile / warm-up run without a cache: shape-only
+            return out.zero_()
+        ops.reshape_and_cache(k, v, self._kb, self._vb, md.slot_mapping)
+        return self._attend(q, md, out)
+
+    __call__ = forward
+
+    def forward_fused_rope(self, rope: RotaryEmbedding, positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+                           v: torch.Tensor, q_norm_weight=None, k_norm_weight=None, norm_eps: float = 1e-6,
+                           output: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(q/k-norm ->) RoPE -> KV write in ONE launch, then attention: the same result as
+        ``rope(positions, q, k)`` followed by ``forward(q, k, v)`` with one launch fewer per layer."""
+        md = get_forward_context().attn_metadata
+        out = torch.empty_like(q) if output is None else output
+        sec = rope._section(positions)
+        if md is None:
+            ops.rope_neox_and_cache(q, k, None, positions, rope.cos_sin_cache, self.head_size, mrope_section=sec,
+                                    q_norm_weight=q_norm_weight, k_norm_weight=k_norm_weight, norm_eps=norm_eps)
+            return out.zero_()
+        ops.rope_neox_and_cache(q, k, v, positions, rope.cos_sin_cache, self.head_size, self._kb, self._vb,
+                                md.slot_mapping, mrope_section=sec, q_norm_weight=q_norm_weight,
+                                k_norm_weight=k_norm_weight, norm_eps=norm_eps)
+        return self._attend(q, md, out)
+
+
+# --------------------------------------------------------------------------- linears
+def _init_weight(out_f: int, in_f: int, dtype, device, generator=None, std: float = 0.02) -> torch.Tensor:
+    w = torch.empty(out_f, in_f, dtype=torch.float32, device=device)
+    w.normal_(0.0, std, generator=generator)
+    return w.to(dtype)
+
+
+class ColumnParallelLinear:
+    """y = x W^T (+ b), output features sharded over TP ranks (no communication)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, dtype=torch.bfloat16, device=None,
+                 generator=None, gather_output: bool = False):
+        self.tp_size = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        if output_size % self.tp_size:
+            raise ValueError("output_size not divisible by tp_size")
+        self.input_size, self.output_size = input_size, output_size
+        self.output_size_per_partition = output_size // self.tp_size
+        self.gather_output = gather_output
+        self.weight = _init_weight(self.output_size_per_partition, input_size, dtype, device, generator)
+        self.bias = torch.zeros(self.output_size_per_partition, dtype=dtype, device=device) if bias else None
+
+    def __call__(self, x: torch.Tensor):
+        y = F.linear(x, self.weight, self.bias)
+        if self.gather_output:
+            y = tensor_model_parallel_all_gather(y)
+        return y, None
+
+
+class MergedColumnParallelLinear(ColumnParallelLinear):
+    """Several column-parallel projections fused along the output dim (gate_up_proj,
+    qwen2_old.py:47-53); each rank holds its shard of EACH sub-projection, concatenated."""
+
+    def __init__(self, input_size: int, output_sizes: Sequence[int], bias: bool = False, **kw):
+        self.output_sizes = list(output_sizes)
+        super().__init__(input_size, sum(output_sizes), bias=bias, **kw)
+
+
+class QKVParallelLinear(ColumnParallelLinear):
+    """Fused q/k/v projection with head-wise sharding and KV-head replication
+    (qwen2_old.py:109-117; partition rules :89-102)."""
+
+    def __init__(self, hidden_size: int, head_size: int, total_num_heads: int, total_num_kv_heads: int,
+                 bias: bool = True, dtype=torch.bfloat16, device=None, generator=None):
+        from .distributed import partition_heads
+
+        self.tp_size = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        self.num_heads, self.num_kv_heads, self.num_kv_head_replicas = partition_heads(
+            total_num_heads, total_num_kv_heads, self.tp_size)
+        self.head_size = head_size
+        self.input_size = hidden_size
+        self.output_size_per_partition = (self.num_heads + 2 * self.num_kv_heads) * head_size
+        self.output_size = (total_num_heads + 2 * total_num_kv_heads) * head_size
+        self.gather_output = False
+        self.weight = _init_weight(self.output_size_per_partition, hidden_size, dtype, device, generator)
+        self.bias = torch.zeros(self.output_size_per_partition, dtype=dtype, device=device) if bias else None
+
+
+class RowParallelLinear:
+    """y = sum_ranks(x_shard W_shard^T) (+ b): input features sharded, TP all-reduce on the
+    result (o_proj / down_proj, qwen2_old.py:54-60,118-124)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, dtype=torch.bfloat16, device=None,
+                 generator=None, reduce_results: bool = True):
+        self.tp_size = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        if input_size % self.tp_size:
+            raise ValueError("input_size not divisible by tp_size")
+        self.input_size, self.output_size = input_size, output_size
+        self.input_size_per_partition = input_size // self.tp_size
+        self.reduce_results = reduce_results
+        self.weight = _init_weight(output_size, self.input_size_per_partition, dtype, device, generator)
+        self.bias = torch.zeros(output_size, dtype=dtype, device=device) if bias else None
+
+    def __call__(self, x: torch.Tensor):
+        # bias is added once (rank 0) so the all-reduced sum carries it exactly once
+        y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        if self.reduce_results:
+            y = tensor_model_parallel_all_reduce(y)
+        return y, None
+
+
+# ------------------------------------------------------- weight sharding (pure indexing)
+def shard_column(weight: torch.Tensor, tp_size: int, tp_rank: int) -> torch.Tensor:
+    per = weight.shape[0] // tp_size
+    return weight[tp_rank * per:(tp_rank + 1) * per]
+
+
+def shard_row(weight: torch.Tensor, tp_size: int, tp_rank: int) -> torch.Tensor:
+    per = weight.shape[1] // tp_size
+    return weight[:, tp_rank * per:(tp_rank + 1) * per]
+
+
+def shard_merged_column(weight: torch.Tensor, output_sizes: Sequence[int], tp_size: int, tp_rank: int) -> torch.Tensor:
+    parts, off = [], 0
+    for sz in output_sizes:
+        parts.append(shard_column(weight[off:off + sz], tp_size, tp_rank))
+        off += sz
+    return torch.cat(parts, dim=0)
+
+
+def shard_qkv(weight: torch.Tensor, head_size: int, total_heads: int, total_kv_heads: int, tp_size: int,
+              tp_rank: int) -> torch.Tensor:
+    """Rows of the fused [q | k | v] weight (or bias) that ``tp_rank`` owns; KV heads are replicated
+    when ``total_kv_heads < tp_size`` (qwen2_old.py:94-102)."""
+    from .distributed import kv_head_for_rank, partition_heads
+
+    nq, _, _ = partition_heads(total_heads, total_kv_heads, tp_size)
+    q_end = total_heads * head_size
+    k_end = q_end + total_kv_heads * head_size
+    q = weight[tp_rank * nq * head_size:(tp_rank + 1) * nq * head_size]
+    kvr = kv_head_for_rank(total_kv_heads, tp_size, tp_rank)
+    k = weight[q_end + kvr.start * head_size:q_end + kvr.stop * head_size]
+    v = weight[k_end + kvr.start * head_size:k_end + kvr.stop * head_size]
+    return torch.cat([q, k, v], dim=0)

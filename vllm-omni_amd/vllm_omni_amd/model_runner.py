@@ -1,0 +1,537 @@
+"""Decode-step driver: persistent batch, vectorised input prep, hipGraph replay.
+
+Mirrors the two-phase contract of ``GPUARModelRunner``
+(vllm_omni/worker/gpu_ar_model_runner.py:262-624 ``execute_model`` -> ``None`` with stashed state,
+:676-953 ``sample_tokens`` -> ``OmniModelRunnerOutput``; out-of-order calls raise
+``RuntimeError("State error: ...")`` :268-269) and the persistent-batch update of
+``OmniGPUModelRunner._update_states`` (vllm_omni/worker/gpu_model_runner.py:241-556).
+
+What is restructured for MI355X (SURVEY §3 hot loop 3, §7 "host overhead at bs=256"):
+  * no per-request Python in the steady-state decode step: positions / slots / seq_lens are numpy
+    vector ops + one C call, one pinned H2D copy each;
+  * the talker's per-request ``preprocess`` hook (``thinker_reply_part[0] + embed(last token)``,
+    qwen2_5_omni.py:766-806) is one batched gather-add over a device-resident reply pool;
+  * the 28-layer step (+ logits, mask, argmax) of a pure-decode batch is captured in a hipGraph
+    per batch size and replayed; the reference ships ``enforce_eager: true``
+    (vllm_omni/platforms/rocm/stage_configs/qwen2_5_omni.yaml:44);
+  * hidden states / sampled ids leave through pinned buffers on a side stream
+    (the reference's synchronous ``hidden_states.to("cpu")``, gpu_ar_model_runner.py:835).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .block_table import MultiGroupBlockTable
+from .kv_cache import KVCacheSpec, allocate_kv_cache, extract_request_kv
+from .layers import AttentionMetadata, set_forward_context
+from .sched_output import (EMPTY_MODEL_RUNNER_OUTPUT, CachedRequestData, NewRequestData, OmniModelRunnerOutput,
+                           SamplingParams, SchedulerOutput)
+from .talker import Qwen2_5OmniTalkerForConditionalGeneration, TalkerConfig
+
+
+@dataclass
+class CachedRequestState:
+    req_id: str
+    prompt_token_ids: list[int]
+    sampling_params: SamplingParams
+    block_ids: tuple[list[int], ...]
+    num_computed_tokens: int
+    output_token_ids: list[int] = field(default_factory=list)
+    prompt_embeds: Optional[torch.Tensor] = None          # [prompt_len, E] talker prefill embeddings
+    additional_information: Optional[dict] = None
+
+    @property
+    def num_tokens(self) -> int:
+        return len(self.prompt_token_ids) + len(self.output_token_ids)
+
+
+class InputBatch:
+    """Persistent batch: dense rows [0, num_reqs), condensed on removal."""
+
+    def __init__(self, max_num_reqs: int, max_model_len: int, max_num_batched_tokens: int, block_size: int, device):
+        self.max_num_reqs = max_num_reqs
+        self.req_ids: list[str] = []
+        self.req_id_to_index: dict[str, int] = {}
+        self.num_computed_tokens_cpu = np.zeros(max_num_reqs, dtype=np.int64)
+        self.num_prompt_tokens = np.zeros(max_num_reqs, dtype=np.int64)
+        self.last_token_ids_cpu = np.zeros(max_num_reqs, dtype=np.int64)
+        self.reply_offset = np.full(max_num_reqs, -1, dtype=np.int64)   # row of the next reply vector, -1 = none
+        self.reply_end = np.zeros(max_num_reqs, dtype=np.int64)
+        self.block_table = MultiGroupBlockTable(max_num_reqs, max_model_len, max_num_batched_tokens, [block_size],
+                                                device)
+
+    @property
+    def num_reqs(self) -> int:
+        return len(self.req_ids)
+
+    def add_request(self, st: CachedRequestState) -> int:
+        i = self.num_reqs
+        if i >= self.max_num_reqs:
+            raise RuntimeError("persistent batch is full (max_num_reqs)")
+        self.req_ids.append(st.req_id)
+        self.req_id_to_index[st.req_id] = i
+        self.num_computed_tokens_cpu[i] = st.num_computed_tokens
+        self.num_prompt_tokens[i] = len(st.prompt_token_ids)
+        last = st.output_token_ids[-1] if st.output_token_ids else (st.prompt_token_ids[-1] if st.prompt_token_ids else 0)
+        self.last_token_ids_cpu[i] = last
+        self.reply_offset[i] = -1
+        self.reply_end[i] = 0
+        self.block_table.add_row(st.block_ids, i)
+        return i
+
+    def remove_request(self, req_id: str) -> None:
+        """Remove and condense: the last row moves into the hole (one row move, no full shift)."""
+        i = self.req_id_to_index.pop(req_id, None)
+        if i is None:
+            return
+        last = self.num_reqs - 1
+        if i != last:
+            moved = self.req_ids[last]
+            self.req_ids[i] = moved
+            self.req_id_to_index[moved] = i
+            for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.last_token_ids_cpu,
+                        self.reply_offset, self.reply_end):
+                arr[i] = arr[last]
+            self.block_table.move_row(last, i)
+        self.block_table.clear_row(last)
+        self.req_ids.pop()
+
+    def swap(self, a: int, b: int) -> None:
+        if a == b:
+            return
+        ra, rb = self.req_ids[a], self.req_ids[b]
+        self.req_ids[a], self.req_ids[b] = rb, ra
+        self.req_id_to_index[ra], self.req_id_to_index[rb] = b, a
+        for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.last_token_ids_cpu, self.reply_offset,
+                    self.reply_end):
+            arr[[a, b]] = arr[[b, a]]
+        self.block_table.swap_row(a, b)
+
+
+@dataclass
+class ExecuteModelState:
+    """Ephemeral state handed from execute_model() to sample_tokens()."""
+
+    scheduler_output: SchedulerOutput
+    logits: torch.Tensor
+    sampled_ids: Optional[torch.Tensor]       # greedy ids already computed by the fused mask+argmax
+    hidden_states: torch.Tensor
+    num_reqs: int
+    num_tokens: int
+    query_start_loc_np: np.ndarray
+    kv_extracted_req_ids: Optional[list[str]]
+
+
+class GPUARModelRunner:
+    def __init__(self, config: TalkerConfig, device: torch.device, dtype: torch.dtype = torch.bfloat16,
+                 max_num_reqs: int = 256, max_model_len: int = 4096, max_num_batched_tokens: int = 8192,
+                 block_size: int = 16, kv_layout: str = "NB2", enforce_eager: bool = False,
+                 engine_output_type: str = "latent", max_reply_rows: int = 0, seed: Optional[int] = 0):
+        from .distributed import get_parallel_state
+
+        self.config = config
+        self.device = device
+        self.dtype = dtype
+        self.max_num_reqs = max_num_reqs
+        self.max_model_len = max_model_len
+        self.max_num_batched_tokens = max(max_num_batched_tokens, max_num_reqs)
+        self.block_size = block_size
+        self.kv_layout = kv_layout
+        self.enforce_eager = enforce_eager
+        self.engine_output_type = engine_output_type
+        self.seed = seed
+        self.parallel = get_parallel_state()
+        self.model: Optional[Qwen2_5OmniTalkerForConditionalGeneration] = None
+        self.kv_caches: list = []
+        self.requests: dict[str, CachedRequestState] = {}
+        self.input_batch = InputBatch(max_num_reqs, max_model_len, self.max_num_batched_tokens, block_size, device)
+        self.execute_model_state: Optional[ExecuteModelState] = None
+        self.kv_extracted: dict[str, Any] = {}
+        self._graphs: dict[int, tuple[torch.cuda.CUDAGraph, dict]] = {}
+        self.max_reply_rows = max_reply_rows
+        self._reply_pool: Optional[torch.Tensor] = None
+        self._reply_used = 0
+        self._alloc_buffers()
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc_buffers(self) -> None:
+        from .block_table import CpuGpuBuffer
+
+        dev, n, t = self.device, self.max_num_reqs, self.max_num_batched_tokens
+        self.positions = CpuGpuBuffer(t, dtype=torch.int64, device=dev)
+        self.seq_lens = CpuGpuBuffer(n, dtype=torch.int32, device=dev)
+        self.query_start_loc = CpuGpuBuffer(n + 1, dtype=torch.int32, device=dev)
+        self.last_token_ids = CpuGpuBuffer(n, dtype=torch.int64, device=dev)
+        self.reply_idx = CpuGpuBuffer(n, dtype=torch.int64, device=dev)
+        self.logits_indices = CpuGpuBuffer(n, dtype=torch.int64, device=dev)
+        on_gpu = torch.device(dev).type == "cuda"
+        e = self.config.embedding_size
+        self.inputs_embeds = torch.zeros(t, e, dtype=self.dtype, device=dev)
+        self.sampled_ids_gpu = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.sampled_ids_cpu = torch.zeros(n, dtype=torch.int64, pin_memory=on_gpu)
+        self.hidden_cpu = torch.zeros(t, self.config.hidden_size, dtype=self.dtype, pin_memory=on_gpu)
+        self.copy_stream = torch.cuda.Stream(device=dev) if on_gpu else None
+        self.copy_done = torch.cuda.Event() if on_gpu else None
+        self._decode_ws: Optional[torch.Tensor] = None
+        self._decode_part = 0
+
+    # -------------------------------------------------------------------- model
+    def load_model(self) -> None:
+        self.model = Qwen2_5OmniTalkerForConditionalGeneration(self.config, self.dtype, self.device, self.seed)
+        if self.max_reply_rows:
+            self._reply_pool = torch.zeros(self.max_reply_rows, self.config.embedding_size, dtype=self.dtype,
+                                           device=self.device)
+
+    def get_model(self):
+        return self.model
+
+    def get_kv_cache_spec(self) -> KVCacheSpec:
+        a = self.model.language_model.model.layers[0].self_attn
+        return KVCacheSpec(self.block_size, a.num_kv_heads, a.head_dim, self.dtype)
+
+    def initialize_kv_cache(self, num_blocks: int) -> None:
+        spec = self.get_kv_cache_spec()
+        self.num_gpu_blocks = num_blocks
+        self.kv_caches = allocate_kv_cache(self.config.num_hidden_layers, num_blocks, spec, self.device, self.kv_layout)
+        for layer, kv in zip(self.model.language_model.model.layers, self.kv_caches):
+            layer.self_attn.attn.bind_kv_cache(kv)
+        a = self.model.language_model.model.layers[0].self_attn
+        self._decode_part = ops.decode_auto_partition(self.max_num_reqs, a.num_kv_heads, self.max_model_len)
+        nbytes = ops.decode_workspace_bytes(self.max_num_reqs, a.num_heads, a.head_dim, self.max_model_len,
+                                            self._decode_part)
+        self._decode_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+
+    def _zero_block_ids(self, block_ids: list[int]) -> None:
+        idx = torch.as_tensor(block_ids, dtype=torch.int64, device=self.device)
+        for kv in self.kv_caches:
+            from .kv_cache import normalize_layer_kv
+            kb, vb = normalize_layer_kv(kv)
+            kb.index_fill_(0, idx, 0)
+            vb.index_fill_(0, idx, 0)
+
+    # ------------------------------------------------------------ state update
+    def _update_states(self, so: SchedulerOutput) -> None:
+        ib = self.input_batch
+        for rid in so.finished_req_ids:
+            self.requests.pop(rid, None)
+            ib.remove_request(rid)
+        if so.new_block_ids_to_zero:
+            self._zero_block_ids(so.new_block_ids_to_zero)
+        cached = so.scheduled_cached_reqs
+        scheduled = so.num_scheduled_tokens.keys()
+        unscheduled = [r for r in ib.req_ids if r not in scheduled or r in cached.resumed_req_ids]
+        for rid in unscheduled:
+            ib.remove_request(rid)
+
+        to_add: list[CachedRequestState] = []
+        for nr in so.scheduled_new_reqs:
+            st = CachedRequestState(nr.req_id, list(nr.prompt_token_ids), nr.sampling_params,
+                                    tuple(list(b) for b in nr.block_ids), nr.num_computed_tokens,
+                                    prompt_embeds=nr.prompt_embeds, additional_information=nr.additional_information)
+            self.requests[nr.req_id] = st
+            to_add.append(st)
+
+        for i, rid in enumerate(cached.req_ids):
+            st = self.requests[rid]
+            st.num_computed_tokens = cached.num_computed_tokens[i]
+            new_ids = cached.new_block_ids[i] if cached.new_block_ids else None
+            resumed = rid in cached.resumed_req_ids
+            if not resumed:
+                if new_ids is not None:
+                    for have, add in zip(st.block_ids, new_ids):
+                        have.extend(add)
+            else:
+                assert new_ids is not None
+                st.block_ids = tuple(list(b) for b in new_ids)
+            idx = ib.req_id_to_index.get(rid)
+            if idx is None:
+                to_add.append(st)
+                continue
+            ib.num_computed_tokens_cpu[idx] = st.num_computed_tokens
+            if new_ids is not None:
+                ib.block_table.append_row(new_ids, idx)
+        for st in to_add:
+            i = ib.add_request(st)
+            self._register_reply_part(st, i)
+
+    def _register_reply_part(self, st: CachedRequestState, row: int) -> None:
+        """Move a request's ``thinker_reply_part`` rows (one consumed per decode step) into the
+        device-resident pool; the batch rows only keep [offset, end) cursors into it."""
+        info = st.additional_information or {}
+        rp = info.get("thinker_reply_part")
+        if not isinstance(rp, torch.Tensor) or rp.numel() == 0:
+            return
+        if self._reply_pool is None:
+            raise RuntimeError("runner built with max_reply_rows=0 but a request carries thinker_reply_part")
+        n = rp.shape[0]
+        if self._reply_used + n > self._reply_pool.shape[0]:
+            self._reply_used = 0  # ring reuse: rows of finished requests are dead by construction
+        self._reply_pool[self._reply_used:self._reply_used + n].copy_(rp.to(self.dtype), non_blocking=True)
+        self.input_batch.reply_offset[row] = self._reply_used
+        self.input_batch.reply_end[row] = self._reply_used + n
+        self._reply_used += n
+
+    # ----------------------------------------------------------- input preparation
+    def _reorder_decodes_first(self, num_sched: np.ndarray) -> np.ndarray:
+        """Stable partition: requests with one scheduled token first (the attention metadata
+        assumes decodes-first, as upstream backends request through ``reorder_batch``)."""
+        ib = self.input_batch
+        n = ib.num_reqs
+        is_dec = num_sched[:n] == 1
+        if is_dec.all() or not is_dec.any():
+            return num_sched
+        i, j = 0, n - 1
+        while True:
+            while i < n and is_dec[i]:
+                i += 1
+            while j >= 0 and not is_dec[j]:
+                j -= 1
+            if i >= j:
+                break
+            ib.swap(i, j)
+            num_sched[[i, j]] = num_sched[[j, i]]
+            is_dec[[i, j]] = is_dec[[j, i]]
+        return num_sched
+
+    def _prepare_inputs(self, so: SchedulerOutput):
+        ib = self.input_batch
+        n = ib.num_reqs
+        num_sched = np.fromiter((so.num_scheduled_tokens[r] for r in ib.req_ids), dtype=np.int64, count=n)
+        num_sched = self._reorder_decodes_first(num_sched)
+        total = int(num_sched.sum())
+        if total > self.max_num_batched_tokens:
+            raise RuntimeError("scheduled more tokens than max_num_batched_tokens")
+        qsl = self.query_start_loc.np
+        qsl[0] = 0
+        np.cumsum(num_sched, out=qsl[1:n + 1])
+        computed = ib.num_computed_tokens_cpu[:n]
+        if total == n:  # pure decode: one token per request
+            req_idx = np.arange(n, dtype=np.int32)
+            pos = computed.copy()
+        else:
+            req_idx = np.repeat(np.arange(n, dtype=np.int32), num_sched)
+            pos = np.arange(total, dtype=np.int64) - np.repeat(qsl[:n].astype(np.int64), num_sched) + computed[req_idx]
+        self.positions.np[:total] = pos
+        seq = (computed + num_sched).astype(np.int32)
+        self.seq_lens.np[:n] = seq
+        max_seq_len = int(seq.max())
+        if max_seq_len > self.max_model_len:
+            raise RuntimeError(f"sequence length {max_seq_len} exceeds max_model_len {self.max_model_len}")
+        ib.block_table.compute_slot_mapping(req_idx, pos)
+        self.logits_indices.np[:n] = qsl[1:n + 1] - 1
+        num_decodes = int((num_sched == 1).sum())
+        return n, total, num_sched, max_seq_len, num_decodes
+
+    def _commit_inputs(self, n: int, total: int, padded_total: int):
+        ib = self.input_batch
+        self.positions.copy_to_gpu(total)
+        self.seq_lens.copy_to_gpu(n)
+        self.query_start_loc.copy_to_gpu(n + 1)
+        self.logits_indices.copy_to_gpu(n)
+        ib.block_table.commit_block_table(n)
+        ib.block_table.commit_slot_mapping(total, padded_total)
+
+    def _build_metadata(self, n, total, max_query_len, max_seq_len_bound, num_decodes) -> AttentionMetadata:
+        bt = self.input_batch.block_table[0]
+        return AttentionMetadata(
+            num_actual_tokens=total, max_query_len=max_query_len, query_start_loc=self.query_start_loc.gpu[:n + 1],
+            seq_lens=self.seq_lens.gpu[:n], max_seq_len=max_seq_len_bound, block_table=bt.block_table.gpu[:n],
+            slot_mapping=bt.slot_mapping.gpu[:total], num_reqs=n, num_decodes=num_decodes,
+            decode_partition_size=self._decode_part, decode_workspace=self._decode_ws)
+
+    def _preprocess_embeds(self, n: int, total: int, num_sched: np.ndarray, num_decodes: int) -> None:
+        """Fill ``self.inputs_embeds[:total]`` (the model's ``preprocess`` hook, batched)."""
+        ib = self.input_batch
+        if num_decodes:
+            nd = num_decodes
+            self.last_token_ids.np[:nd] = ib.last_token_ids_cpu[:nd]
+            off = ib.reply_offset[:nd]
+            has = (off >= 0) & (off < ib.reply_end[:nd])
+            self.reply_idx.np[:nd] = np.where(has, off, -1)
+            ib.reply_offset[:nd] = np.where(has, off + 1, off)   # consume one reply row per step
+            self.last_token_ids.copy_to_gpu(nd)
+            self.reply_idx.copy_to_gpu(nd)
+            self._decode_embeds(nd)
+        # prefill rows: per-request prompt embeddings (thinker hidden states) or token embeddings
+        t0 = num_decodes
+        for i in range(num_decodes, n):
+            st = self.requests[ib.req_ids[i]]
+            k = int(num_sched[i])
+            c = int(ib.num_computed_tokens_cpu[i])
+            if st.prompt_embeds is not None:
+                self.inputs_embeds[t0:t0 + k].copy_(st.prompt_embeds[c:c + k].to(self.dtype), non_blocking=True)
+            else:
+                ids = torch.as_tensor((st.prompt_token_ids + st.output_token_ids)[c:c + k], dtype=torch.int64)
+                self.inputs_embeds[t0:t0 + k] = self.model.embed_input_ids(ids.to(self.device))
+            t0 += k
+
+    def _decode_embeds(self, nd: int) -> None:
+        ops.talker_decode_embeds(self.inputs_embeds[:nd], self.model.language_model.model.embed_tokens,
+                                 self.last_token_ids.gpu[:nd], self._reply_pool,
+                                 self.reply_idx.gpu[:nd] if self._reply_pool is not None else None)
+
+    # ------------------------------------------------------------------- forward
+    def _forward(self, n: int, total: int, md: AttentionMetadata):
+        """Model forward + logits + fused mask/argmax on the static buffers."""
+        with set_forward_context(md):
+            hidden = self.model(input_ids=None, positions=self.positions.gpu[:total],
+                                inputs_embeds=self.inputs_embeds[:total])
+        sample_h = hidden if total == n else hidden.index_select(0, self.logits_indices.gpu[:n])
+        logits, ids = self.model.compute_logits_and_greedy(sample_h, self.sampled_ids_gpu[:n])
+        return hidden, logits, ids
+
+    def _can_use_graph(self, n: int, total: int) -> bool:
+        return (not self.enforce_eager and total == n and torch.device(self.device).type == "cuda"
+                and self.parallel.tp_size == 1)
+
+    def capture_model(self, batch_sizes: Optional[list[int]] = None) -> None:
+        for b in batch_sizes or []:
+            self._capture(b)
+
+    def _capture(self, n: int):
+        """Capture the pure-decode step for batch size ``n`` (grid sized for max_model_len)."""
+        md = self._build_metadata(n, n, 1, self.max_model_len, n)
+        # warm-up on a side stream (library handles, hipBLASLt heuristics), then capture
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._decode_embeds(n)
+                self._forward(n, n, md)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_embeds(n)
+            hidden, logits, ids = self._forward(n, n, md)
+        self._graphs[n] = (g, {"hidden": hidden, "logits": logits, "ids": ids})
+        return self._graphs[n]
+
+    # ---------------------------------------------------------------- the step
+    @torch.inference_mode()
+    def execute_model(self, scheduler_output: SchedulerOutput, intermediate_tensors=None):
+        if self.execute_model_state is not None:
+            raise RuntimeError("State error: sample_tokens() must be called after execute_model() returns None.")
+        kv_done = None
+        if scheduler_output.finished_requests_needing_kv_transfer:
+            kv_done = self._extract_finished_kv(scheduler_output.finished_requests_needing_kv_transfer)
+        self._update_states(scheduler_output)
+        if not scheduler_output.total_num_scheduled_tokens:
+            if kv_done:
+                return OmniModelRunnerOutput([], {}, [], [], kv_extracted_req_ids=kv_done)
+            return EMPTY_MODEL_RUNNER_OUTPUT
+        n, total, num_sched, max_seq_len, num_decodes = self._prepare_inputs(scheduler_output)
+        use_graph = self._can_use_graph(n, total)
+        self._commit_inputs(n, total, total)
+        if use_graph:
+            entry = self._graphs.get(n)
+            if entry is None:
+                # first time at this batch size: fill the static inputs once, then capture
+                self._preprocess_host_only(n, num_decodes)
+                entry = self._capture(n)
+            else:
+                self._preprocess_host_only(n, num_decodes)
+            g, outs = entry
+            g.replay()
+            hidden, logits, ids = outs["hidden"], outs["logits"], outs["ids"]
+        else:
+            self._preprocess_embeds(n, total, num_sched, num_decodes)
+            md = self._build_metadata(n, total, int(num_sched.max()), max_seq_len, num_decodes)
+            hidden, logits, ids = self._forward(n, total, md)
+        self.execute_model_state = ExecuteModelState(scheduler_output, logits, ids, hidden, n, total,
+                                                     self.query_start_loc.np[:n + 1].copy(), kv_done)
+        return None
+
+    def _preprocess_host_only(self, n: int, num_decodes: int) -> None:
+        """Graph path: only the host->device index copies; the gather-add itself is in the graph."""
+        ib = self.input_batch
+        self.last_token_ids.np[:n] = ib.last_token_ids_cpu[:n]
+        off = ib.reply_offset[:n]
+        has = (off >= 0) & (off < ib.reply_end[:n])
+        self.reply_idx.np[:n] = np.where(has, off, -1)
+        ib.reply_offset[:n] = np.where(has, off + 1, off)
+        self.last_token_ids.copy_to_gpu(n)
+        self.reply_idx.copy_to_gpu(n)
+
+    @torch.inference_mode()
+    def sample_tokens(self, grammar_output=None) -> OmniModelRunnerOutput:
+        st = self.execute_model_state
+        if st is None:
+            raise RuntimeError("State error: sample_tokens() called without a preceding execute_model().")
+        self.execute_model_state = None
+        ib = self.input_batch
+        n = st.num_reqs
+        ids = st.sampled_ids
+        # non-greedy requests: temperature / top-k / top-p on the masked logits
+        params = [self.requests[r].sampling_params for r in ib.req_ids[:n]]
+        if any(p.temperature > 0 for p in params):
+            ids = self._sample_random(st.logits, params, ids)
+        # D2H on the side stream through pinned buffers (ids + hidden states)
+        cur = torch.cuda.current_stream() if self.copy_stream is not None else None
+        want_hidden = self.engine_output_type != "text"
+        if self.copy_stream is not None:
+            self.copy_stream.wait_stream(cur)
+            with torch.cuda.stream(self.copy_stream):
+                self.sampled_ids_cpu[:n].copy_(ids[:n], non_blocking=True)
+                if want_hidden:
+                    self.hidden_cpu[:st.num_tokens].copy_(st.hidden_states[:st.num_tokens], non_blocking=True)
+                self.copy_done.record(self.copy_stream)
+            self.copy_done.synchronize()
+        else:
+            self.sampled_ids_cpu[:n].copy_(ids[:n])
+            if want_hidden:
+                self.hidden_cpu[:st.num_tokens].copy_(st.hidden_states[:st.num_tokens])
+        ids_np = self.sampled_ids_cpu[:n].numpy()
+        # bookkeeping, vectorised: last token per row feeds the next step's embedding lookup
+        ib.last_token_ids_cpu[:n] = ids_np
+        sampled = ids_np.reshape(n, 1).tolist()
+        for rid, tok in zip(ib.req_ids[:n], ids_np.tolist()):
+            self.requests[rid].output_token_ids.append(tok)
+        pooler: list[Optional[dict[str, Any]]]
+        if want_hidden:
+            q = st.query_start_loc_np
+            chunks = torch.split(self.hidden_cpu[:st.num_tokens], np.diff(q).tolist())
+            pooler = [{"hidden": c} for c in chunks]
+        else:
+            pooler = [None] * n
+        return OmniModelRunnerOutput(list(ib.req_ids[:n]), dict(ib.req_id_to_index), sampled, pooler,
+                                     kv_extracted_req_ids=st.kv_extracted_req_ids)
+
+    def _sample_random(self, logits: torch.Tensor, params: list[SamplingParams], greedy_ids: torch.Tensor):
+        """Temperature / top-k / top-p sampling for rows that ask for it (host-side mirror of the
+        sampler the shipped talker config uses: T=0.9, top_p=0.8, top_k=40)."""
+        n = logits.shape[0]
+        lf = logits[:n].float()
+        temp = torch.tensor([p.temperature if p.temperature > 0 else 1.0 for p in params], device=lf.device)
+        lf = lf / temp.unsqueeze(-1)
+        top_k = max((p.top_k for p in params), default=0)
+        if top_k > 0:
+            kth = torch.topk(lf, min(top_k, lf.shape[-1]), dim=-1).values[:, -1:]
+            lf = lf.masked_fill(lf < kth, float("-inf"))
+        probs = torch.softmax(lf, dim=-1)
+        top_p = min((p.top_p for p in params), default=1.0)
+        if top_p < 1.0:
+            sp, si = torch.sort(probs, dim=-1, descending=True)
+            keep = (sp.cumsum(-1) - sp) < top_p
+            probs = torch.zeros_like(probs).scatter_(-1, si, sp * keep)
+            probs = probs / probs.sum(-1, keepdim=True)
+        drawn = torch.multinomial(probs, 1).squeeze(-1)
+        is_greedy = torch.tensor([p.temperature <= 0 for p in params], device=lf.device)
+        return torch.where(is_greedy, greedy_ids[:n], drawn)
+
+    # ---------------------------------------------------------------- KV hand-off
+    def _extract_finished_kv(self, finished: dict[str, dict]) -> list[str]:
+        """Gather finished requests' K/V before their blocks are reused (A2 consumer;
+        kv_transfer_manager.py:721-862).  Results are kept in ``self.kv_extracted``."""
+        done = []
+        for rid, info in finished.items():
+            keys, vals = extract_request_kv(self.kv_caches, info.get("block_ids", []), int(info.get("seq_len", 0)))
+            self.kv_extracted[rid] = {"key_cache": keys, "value_cache": vals, "block_ids": info.get("block_ids", []),
+                                      "metadata": {"block_size": self.block_size, "num_layers": len(self.kv_caches),
+                                                   "dtype": str(self.dtype), "seq_len": int(info.get("seq_len", 0))}}
+            done.append(rid)
+        return done

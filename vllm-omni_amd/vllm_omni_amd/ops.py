@@ -109,6 +109,10 @@ def rope_neox_and_cache(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tens
 
 
 # --------------------------------------------------------------------------- A5
+# Default P.V contraction mode of the decode kernel (see include/vllm_omni_amd.h, flags).
+DECODE_PACKED_PV = False
+
+
 def decode_auto_partition(num_seqs: int, num_kv_heads: int, max_seq_len: int) -> int:
     return int(lib.mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len))
 
@@ -121,13 +125,14 @@ def decode_workspace_bytes(num_seqs: int, num_q_heads: int, head_dim: int, max_s
 
 def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                       block_table: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, scale: float,
-                      num_kv_heads: Optional[int] = None, partition_size: int = 0,
-                      workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      partition_size: int = 0, workspace: Optional[torch.Tensor] = None,
+                      packed_pv: Optional[bool] = None) -> torch.Tensor:
     """out[s, h] = softmax(q[s,h] . K^T * scale) . V over the paged cache (one query per sequence).
 
     q, out: [S, nq*d] (or [S, nq, d]); block_table int32 [S, max_blocks]; seq_lens int32 [S].
     ``max_seq_len`` is a host-side upper bound of seq_lens (sizes the launch).
-    ``out`` may be fp32 for parity measurement.  Returns ``out``.
+    ``out`` may be fp32 for parity measurement.  ``packed_pv``: round P to the cache dtype and
+    use dot2 for P.V (None = module default ``DECODE_PACKED_PV``).  Returns ``out``.
     """
     _gpu(out, q, k_cache, v_cache, block_table, seq_lens, workspace)
     nb, bs, hkv, d = k_cache.shape
@@ -150,7 +155,8 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
         block_table.stride(0), int(max_seq_len), float(scale), q.stride(0), out.stride(0), cb, ct, ch,
         int(partition_size), _p(workspace),
         workspace.numel() * workspace.element_size() if workspace is not None else 0,
-        _dt(q.dtype), _dt(out.dtype), _stream()))
+        _dt(q.dtype), _dt(out.dtype),
+        _C.MI_DECODE_PACKED_PV if (DECODE_PACKED_PV if packed_pv is None else packed_pv) else 0, _stream()))
     return out
 
 
@@ -224,6 +230,20 @@ def mask_logits_argmax(logits: torch.Tensor, ranges: Sequence[tuple[int, int]] =
         _p(logits), _p(ids), t, v, logits.stride(0), r[0][0], r[0][1], r[1][0], r[1][1], int(col),
         _dt(logits.dtype), _stream()))
     return ids
+
+
+def talker_decode_embeds(out: torch.Tensor, embed_table: torch.Tensor, token_ids: torch.Tensor,
+                         reply_rows: Optional[torch.Tensor] = None, reply_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[t] = embed_table[token_ids[t]] (+ reply_rows[reply_idx[t]] where reply_idx[t] >= 0)."""
+    _gpu(out, embed_table, token_ids, reply_rows, reply_idx)
+    t = token_ids.shape[0]
+    if token_ids.dtype != torch.int64 or (reply_idx is not None and reply_idx.dtype != torch.int64):
+        raise TypeError("token_ids / reply_idx must be int64")
+    check("mi_talker_decode_embeds", lib.mi_talker_decode_embeds(
+        _p(out), _p(embed_table), _p(token_ids), _p(reply_rows), _p(reply_idx), t, embed_table.shape[1],
+        embed_table.shape[0], reply_rows.shape[0] if reply_rows is not None else 0, out.stride(0),
+        _dt(embed_table.dtype), _stream()))
+    return out
 
 
 # -------------------------------------------------------------------------- A13

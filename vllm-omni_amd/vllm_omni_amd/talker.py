@@ -1,7 +1,72 @@
-"""Host-side mirror of the talker model wiring (filled in below)."""
+"""Host-side mirror of the talker decoder stack (SURVEY §8a A10/A11 wiring; §8c "files a CPU
+restatement must follow").
+
+Layer order, residual flow, scale and rotary flags follow
+vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:37-69 (MLP), :72-156 (attention),
+:159-225 (decoder layer), :300-326 (model loop); the talker wrapper (projection, logits,
+``bad_word_processor``) follows qwen2_5_omni_talker.py:72-81,123-174; the per-step input
+fix-up follows qwen2_5_omni.py:766-806.
+"""
 from __future__ import annotations
 
-from typing import Optional
+import json
+import os
+from dataclasses import asdict, dataclass, field
+from typing import Iterable, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size
+from .layers import (Attention, MergedColumnParallelLinear, QKVParallelLinear, RMSNorm, RowParallelLinear,
+                     SiluAndMul, _init_weight, get_rope, shard_column, shard_merged_column, shard_qkv, shard_row)
+from .distributed import tensor_model_parallel_all_gather
+
+CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+
+
+@dataclass
+class TalkerConfig:
+    """Shape parameters of a talker decoder.  ``qwen2_5_omni_talker.json`` holds the
+    ``transformers 5.15.0`` class defaults of ``Qwen2_5OmniTalkerConfig`` captured offline (the
+    released checkpoint's config.json could not be fetched)."""
+
+    name: str = "qwen2_5_omni_talker"
+    hidden_size: int = 3584
+    embedding_size: int = 3584
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 28
+    num_key_value_heads: int = 4
+    head_dim: int = 128
+    intermediate_size: int = 18944
+    vocab_size: int = 8448
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    max_position_embeddings: int = 32768
+    mrope_section: Optional[list[int]] = None
+    qk_norm: bool = False  # Qwen3 family: per-head RMSNorm on q and k before RoPE
+    attention_bias: bool = True
+    tts_codec_start_token_id: Optional[int] = 8293
+    tts_codec_end_token_id: Optional[int] = 8294
+    tts_codec_pad_token_id: Optional[int] = 8292
+    tts_codec_mask_token_id: Optional[int] = 8296
+
+    @classmethod
+    def from_json(cls, path_or_name: str) -> "TalkerConfig":
+        path = path_or_name if os.path.exists(path_or_name) else os.path.join(CONFIG_DIR, path_or_name + ".json")
+        with open(path) as f:
+            d = json.load(f)
+        known = {k: v for k, v in d.items() if k in cls.__dataclass_fields__}
+        return cls(**known)
+
+    def num_params(self) -> int:
+        h, i, d = self.hidden_size, self.intermediate_size, self.head_dim
+        qkv = h * (self.num_attention_heads + 2 * self.num_key_value_heads) * d
+        per_layer = qkv + (self.num_attention_heads + 2 * self.num_key_value_heads) * d * self.attention_bias \
+            + self.num_attention_heads * d * h + 3 * h * i + 2 * h
+        return self.num_hidden_layers * per_layer + h + self.vocab_size * h \
+            + self.vocab_size * self.embedding_size + self.embedding_size * h + h
 
 
 def bad_word_mask_spec(vocab: int, suppress_start_id: Optional[int], end_id: Optional[int],
@@ -24,3 +89,230 @@ def bad_word_mask_spec(vocab: int, suppress_start_id: Optional[int], end_id: Opt
         else:
             ranges.append((suppress_start_id, vocab))
     return ranges, (-1 if bos_id is None else int(bos_id))
+
+
+class Qwen2MLP:
+    """gate_up (merged column-parallel) -> SiluAndMul -> down (row-parallel + all-reduce)."""
+
+    def __init__(self, cfg: TalkerConfig, dtype, device, generator=None):
+        self.gate_up_proj = MergedColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size] * 2, bias=False,
+                                                       dtype=dtype, device=device, generator=generator)
+        self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False, dtype=dtype,
+                                           device=device, generator=generator)
+        self.act_fn = SiluAndMul()
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        gate_up, _ = self.gate_up_proj(x)
+        x = self.act_fn(gate_up)
+        x, _ = self.down_proj(x)
+        return x
+
+
+class Qwen2Attention:
+    def __init__(self, cfg: TalkerConfig, dtype, device, prefix: str, generator=None):
+        self.total_num_heads = cfg.num_attention_heads
+        self.total_num_kv_heads = cfg.num_key_value_heads
+        self.head_dim = cfg.head_dim
+        self.qkv_proj = QKVParallelLinear(cfg.hidden_size, self.head_dim, self.total_num_heads,
+                                          self.total_num_kv_heads, bias=cfg.attention_bias, dtype=dtype, device=device,
+                                          generator=generator)
+        self.num_heads = self.qkv_proj.num_heads
+        self.num_kv_heads = self.qkv_proj.num_kv_heads
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.scaling = self.head_dim ** -0.5
+        self.o_proj = RowParallelLinear(self.total_num_heads * self.head_dim, cfg.hidden_size, bias=False,
+                                        dtype=dtype, device=device, generator=generator)
+        rp = {"base": cfg.rope_theta}
+        if cfg.mrope_section:
+            rp["mrope_section"] = cfg.mrope_section
+        self.rotary_pos_emb = get_rope(head_size=self.head_dim, max_position=cfg.max_position_embeddings,
+                                       is_neox_style=True, rope_parameters=rp, device=device)
+        self.attn = Attention(self.num_heads, self.head_dim, self.scaling, num_kv_heads=self.num_kv_heads,
+                              prefix=f"{prefix}.attn")
+        self.q_norm = self.k_norm = None
+        self.norm_eps = cfg.rms_norm_eps
+        if cfg.qk_norm:
+            self.q_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps, dtype, device)
+            self.k_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps, dtype, device)
+
+    def __call__(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
+        qkv, _ = self.qkv_proj(hidden_states)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        # rotary_pos_emb(positions, q, k) + attn(q, k, v) of qwen2_old.py:153-154, fused:
+        # (q/k-norm ->) RoPE -> KV write in one launch, then paged attention.
+        attn_output = self.attn.forward_fused_rope(
+            self.rotary_pos_emb, positions, q, k, v,
+            q_norm_weight=self.q_norm.weight if self.q_norm else None,
+            k_norm_weight=self.k_norm.weight if self.k_norm else None, norm_eps=self.norm_eps)
+        output, _ = self.o_proj(attn_output)
+        return output
+
+
+class Qwen2DecoderLayer:
+    def __init__(self, cfg: TalkerConfig, dtype, device, prefix: str, generator=None):
+        self.self_attn = Qwen2Attention(cfg, dtype, device, f"{prefix}.self_attn", generator)
+        self.mlp = Qwen2MLP(cfg, dtype, device, generator)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
+
+    def __call__(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class Qwen2Model:
+    def __init__(self, cfg: TalkerConfig, dtype, device, prefix: str = "model", generator=None):
+        self.config = cfg
+        # embedding table: replicated on every TP rank (60 MB at the talker shape)
+        self.embed_tokens = _init_weight(cfg.vocab_size, cfg.embedding_size, dtype, device, generator)
+        self.layers = [Qwen2DecoderLayer(cfg, dtype, device, f"{prefix}.layers.{i}", generator)
+                       for i in range(cfg.num_hidden_layers)]
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
+
+    def embed_input_ids(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return F.embedding(input_ids, self.embed_tokens)
+
+    def __call__(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None) -> torch.Tensor:
+        hidden_states = inputs_embeds if inputs_embeds is not None else self.embed_input_ids(input_ids)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class Qwen2ForCausalLM:
+    """``Qwen2ForCausalLM_old``: model + vocab-parallel lm_head (qwen2_old.py:380-449)."""
+
+    def __init__(self, cfg: TalkerConfig, dtype, device, generator=None):
+        self.config = cfg
+        self.model = Qwen2Model(cfg, dtype, device, generator=generator)
+        tp = get_tensor_model_parallel_world_size()
+        if cfg.vocab_size % tp:
+            raise ValueError("vocab_size not divisible by tp_size")
+        self.lm_head = _init_weight(cfg.vocab_size // tp, cfg.hidden_size, dtype, device, generator)
+
+    def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        logits = F.linear(hidden_states, self.lm_head)
+        return tensor_model_parallel_all_gather(logits)
+
+
+class Qwen2_5OmniTalkerForConditionalGeneration:
+    """Talker = ``thinker_to_talker_proj`` (Linear embedding_size -> hidden) + Qwen2 decoder
+    (qwen2_5_omni_talker.py:72-81); ``forward`` consumes ``inputs_embeds`` (:123-148)."""
+
+    has_preprocess = True
+
+    def __init__(self, cfg: TalkerConfig, dtype=torch.bfloat16, device=None, seed: Optional[int] = 0):
+        self.config = cfg
+        self.dtype = dtype
+        self.device = device
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=device)
+            # every TP rank draws its own shard; tests that need identical full weights use load_weights()
+            gen.manual_seed(seed + 1000 * get_tensor_model_parallel_rank())
+        self.thinker_to_talker_proj_weight = _init_weight(cfg.hidden_size, cfg.embedding_size, dtype, device, gen)
+        self.thinker_to_talker_proj_bias = torch.zeros(cfg.hidden_size, dtype=dtype, device=device)
+        self.language_model = Qwen2ForCausalLM(cfg, dtype, device, gen)
+        self.suppress_start_id: Optional[int] = None
+
+    # ---- reference-named surface --------------------------------------------------
+    def get_language_model(self):
+        return self.language_model
+
+    def embed_input_ids(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return self.language_model.model.embed_input_ids(input_ids)
+
+    def set_suppress_start_id(self, start_id: int) -> None:
+        self.suppress_start_id = start_id
+
+    def forward(self, input_ids=None, positions=None, intermediate_tensors=None, inputs_embeds=None, **kwargs):
+        assert input_ids is not None or inputs_embeds is not None, "input_ids or inputs_embeds must be provided"
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_input_ids(input_ids)  # profile run
+        inputs_embeds = F.linear(inputs_embeds, self.thinker_to_talker_proj_weight, self.thinker_to_talker_proj_bias)
+        return self.language_model.model(None, positions, intermediate_tensors, inputs_embeds=inputs_embeds)
+
+    __call__ = forward
+
+    def mask_spec(self, vocab: Optional[int] = None):
+        return bad_word_mask_spec(vocab or self.config.vocab_size, self.suppress_start_id,
+                                  self.config.tts_codec_end_token_id, self.config.tts_codec_start_token_id)
+
+    def bad_word_processor(self, logits: torch.Tensor) -> torch.Tensor:
+        ranges, col = self.mask_spec(logits.size(-1))
+        ops.mask_logits_argmax(logits.view(-1, logits.size(-1)), ranges, col)
+        return logits
+
+    def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        logits = self.language_model.compute_logits(hidden_states)
+        return self.bad_word_processor(logits)
+
+    def compute_logits_and_greedy(self, hidden_states: torch.Tensor, ids: Optional[torch.Tensor] = None):
+        """compute_logits + greedy argmax with the mask and argmax fused in one launch."""
+        logits = self.language_model.compute_logits(hidden_states)
+        ranges, col = self.mask_spec(logits.size(-1))
+        ids = ops.mask_logits_argmax(logits, ranges, col, ids)
+        return logits, ids
+
+    def decode_one_step_embeds(self, last_token_ids: torch.Tensor, step_vec: Optional[torch.Tensor]) -> torch.Tensor:
+        """Per-step talker input: ``thinker_reply_part[step] + embed(last codec token)``
+        (``_thinker_to_talker_decode_one_step``, qwen2_5_omni.py:796-804), for the whole batch."""
+        e = self.embed_input_ids(last_token_ids)
+        return e if step_vec is None else step_vec.to(e.dtype) + e
+
+    # ---- weights ------------------------------------------------------------------
+    def named_weights(self) -> Iterable[tuple[str, torch.Tensor]]:
+        yield "thinker_to_talker_proj.weight", self.thinker_to_talker_proj_weight
+        yield "thinker_to_talker_proj.bias", self.thinker_to_talker_proj_bias
+        lm = self.language_model
+        yield "language_model.lm_head.weight", lm.lm_head
+        yield "language_model.model.embed_tokens.weight", lm.model.embed_tokens
+        yield "language_model.model.norm.weight", lm.model.norm.weight
+        for i, layer in enumerate(lm.model.layers):
+            p = f"language_model.model.layers.{i}."
+            a, m = layer.self_attn, layer.mlp
+            yield p + "self_attn.qkv_proj.weight", a.qkv_proj.weight
+            if a.qkv_proj.bias is not None:
+                yield p + "self_attn.qkv_proj.bias", a.qkv_proj.bias
+            yield p + "self_attn.o_proj.weight", a.o_proj.weight
+            if a.q_norm is not None:
+                yield p + "self_attn.q_norm.weight", a.q_norm.weight
+                yield p + "self_attn.k_norm.weight", a.k_norm.weight
+            yield p + "mlp.gate_up_proj.weight", m.gate_up_proj.weight
+            yield p + "mlp.down_proj.weight", m.down_proj.weight
+            yield p + "input_layernorm.weight", layer.input_layernorm.weight
+            yield p + "post_attention_layernorm.weight", layer.post_attention_layernorm.weight
+
+    def load_weights(self, full: dict[str, torch.Tensor]) -> set[str]:
+        """Copy UNSHARDED weights (fused names as in ``named_weights``) into this rank's shards."""
+        cfg = self.config
+        tp, r = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        loaded = set()
+        for name, dst in self.named_weights():
+            if name not in full:
+                continue
+            w = full[name]
+            if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
+                w = shard_qkv(w, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, tp, r)
+            elif name.endswith("gate_up_proj.weight"):
+                w = shard_merged_column(w, [cfg.intermediate_size] * 2, tp, r)
+            elif name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+                w = shard_row(w, tp, r)
+            elif name.endswith("lm_head.weight"):
+                w = shard_column(w, tp, r)
+            dst.copy_(w.to(dst.dtype))
+            loaded.add(name)
+        return loaded
+
+    def weight_bytes(self) -> int:
+        return sum(w.numel() * w.element_size() for _, w in self.named_weights())
