@@ -43,9 +43,20 @@ def talker_step(cfg, weights: dict, inputs_embeds: torch.Tensor, positions: torc
     Returns (hidden [T, H] after the final norm, as fp32 values on the ``round_to`` grid).
     """
     rt = round_to
-    d, nq, nkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
-    t = inputs_embeds.shape[0]
     h = _lin(inputs_embeds.to(F32), weights["thinker_to_talker_proj.weight"], weights["thinker_to_talker_proj.bias"], rt)
+    return decoder_stack(cfg, weights, h, positions, kv_caches, block_table, seq_lens, query_start_loc, slot_map,
+                         cos_sin_cache, round_to, num_layers)
+
+
+def decoder_stack(cfg, weights: dict, h: torch.Tensor, positions: torch.Tensor, kv_caches: Sequence,
+                  block_table: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
+                  slot_map: torch.Tensor, cos_sin_cache: torch.Tensor, round_to: Optional[torch.dtype] = None,
+                  num_layers: Optional[int] = None):
+    """``Qwen2Model.forward`` on already-projected embeddings ``h`` [T, H] (qwen2_old.py:300-326)."""
+    rt = round_to
+    d, nq, nkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+    t = h.shape[0]
+    h = h.to(F32)
     residual = None
     nl = cfg.num_hidden_layers if num_layers is None else num_layers
     pos1d = positions if positions.dim() == 1 else positions

@@ -1,0 +1,120 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vllm_omni_amd.h declares; host-side
+entry points (block pool, slot mapping) behave as the oracle says.  No GPU compute call is made here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "vllm_omni_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from vllm_omni_amd import _C
+
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(_C.lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_C.SIGNATURES) == declared, "ctypes signature table and header disagree"
+    assert _C.lib.mi_abi_version() == _C.ABI_VERSION
+    assert _C.lib.mi_error_string(_C.MI_ERR_EXHAUSTED).decode().startswith("KV block pool")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import importlib
+    import sys
+
+    import vllm_omni_amd._C as C
+
+    monkeypatch.setattr(C, "_LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        C._load()
+
+
+def test_ops_reject_cpu_tensors():
+    from vllm_omni_amd import ops
+
+    x = torch.randn(2, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.rms_norm(x, torch.ones(64, dtype=torch.bfloat16), 1e-6)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.silu_and_mul(x)
+
+
+def test_argument_validation_without_gpu():
+    """Invalid-argument paths return before any launch, so they are checkable without a GPU."""
+    from vllm_omni_amd import _C
+
+    lib = _C.lib
+    assert lib.mi_rms_norm(None, None, None, 1e-6, 4, 64, 64, 64, _C.MI_DTYPE_BF16, None) == _C.MI_ERR_INVALID_ARG
+    assert lib.mi_rms_norm(None, None, None, 1e-6, 0, 64, 64, 64, _C.MI_DTYPE_BF16, None) == _C.MI_OK  # empty
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p = (p + 15) & ~15
+    assert lib.mi_paged_attn_decode(p, p, p, p, p, p, 2, 8, 2, 96, 16, 4, 64, 1.0, 768, 768, 1, 1, 1, 0, None, 0,
+                                    _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, 0, None) == _C.MI_ERR_UNSUPPORTED
+    assert lib.mi_paged_attn_decode(p, p, p, p, p, p, 2, 8, 3, 128, 16, 4, 64, 1.0, 1024, 1024, 8, 8, 8, 0, None, 0,
+                                    _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, 0, None) == _C.MI_ERR_INVALID_ARG
+    assert lib.mi_paged_attn_decode(p, p, p, p, p, p, 2, 8, 2, 128, 12, 4, 64, 1.0, 1024, 1024, 8, 8, 8, 0, None, 0,
+                                    _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, 0, None) == _C.MI_ERR_UNSUPPORTED
+    assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 512) == 256 * 28 * 8 * 130 * 4
+    assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 4096) == 0
+    part = lib.mi_paged_attn_decode_auto_partition(256, 4, 4096)
+    assert part % 16 == 0 and 128 <= part <= 4096
+
+
+def test_blockpool_fifo_refcount_and_null_block():
+    from vllm_omni_amd import _C
+
+    lib = _C.lib
+    pool = lib.mi_blockpool_create(6)
+    assert pool and lib.mi_blockpool_num_free(pool) == 5 and lib.mi_blockpool_num_blocks(pool) == 6
+    ids = (ctypes.c_int32 * 3)()
+    assert lib.mi_blockpool_alloc(pool, 3, ids) == _C.MI_OK and list(ids) == [1, 2, 3]   # never the null block 0
+    big = (ctypes.c_int32 * 3)()
+    assert lib.mi_blockpool_alloc(pool, 3, big) == _C.MI_ERR_EXHAUSTED                   # all-or-nothing
+    assert lib.mi_blockpool_num_free(pool) == 2
+    two = (ctypes.c_int32 * 1)(2)
+    assert lib.mi_blockpool_ref(pool, two, 1) == _C.MI_OK and lib.mi_blockpool_refcount(pool, 2) == 2
+    assert lib.mi_blockpool_free(pool, ids, 3) == _C.MI_OK
+    assert lib.mi_blockpool_num_free(pool) == 4 and lib.mi_blockpool_refcount(pool, 2) == 1  # still referenced
+    nxt = (ctypes.c_int32 * 4)()
+    assert lib.mi_blockpool_alloc(pool, 4, nxt) == _C.MI_OK and list(nxt) == [4, 5, 1, 3]   # FIFO: freed go to the tail
+    assert lib.mi_blockpool_free(pool, (ctypes.c_int32 * 1)(0), 1) == _C.MI_ERR_STATE       # null block
+    assert lib.mi_blockpool_free(pool, (ctypes.c_int32 * 1)(9), 1) == _C.MI_ERR_STATE       # out of range
+    assert lib.mi_blockpool_free(pool, two, 1) == _C.MI_OK
+    assert lib.mi_blockpool_free(pool, two, 1) == _C.MI_ERR_STATE                           # double free
+    assert lib.mi_blockpool_create(1) is None
+    lib.mi_blockpool_destroy(pool)
+
+
+def test_slot_mapping_matches_oracle_bit_exact():
+    from vllm_omni_amd import _C
+
+    rng = np.random.default_rng(0)
+    for bs in (4, 8, 16, 32):
+        nreq, maxb = 7, 9
+        table = rng.integers(1, 1000, size=(nreq, maxb), dtype=np.int32)
+        t = 61
+        req = rng.integers(0, nreq, size=t).astype(np.int32)
+        pos = rng.integers(0, maxb * bs, size=t).astype(np.int64)
+        out = np.full(t, -7, dtype=np.int64)
+        rc = _C.lib.mi_compute_slot_mapping(out.ctypes.data, table.ctypes.data, maxb, req.ctypes.data, pos.ctypes.data, t, bs)
+        assert rc == _C.MI_OK
+        exp = ref_ops.slot_mapping(torch.from_numpy(table), torch.from_numpy(req), torch.from_numpy(pos), bs)
+        assert np.array_equal(out, exp.numpy())
+    bad = np.array([maxb * 32], dtype=np.int64)
+    assert _C.lib.mi_compute_slot_mapping(out.ctypes.data, table.ctypes.data, maxb, req.ctypes.data, bad.ctypes.data, 1,
+                                          32) == _C.MI_ERR_INVALID_ARG

@@ -1,0 +1,210 @@
+"""CPU: host-side logic of the path — block manager façade, block table / slot mapping, persistent
+batch, platform plugin surface, head partition rules.  No GPU compute."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops
+
+
+# ------------------------------------------------------------------------- KV block manager (A1)
+def _req(rid, n_prompt, computed=0):
+    from vllm_omni_amd.sched_output import Request
+
+    r = Request(rid, list(range(n_prompt)))
+    r.num_computed_tokens = computed
+    return r
+
+
+def test_allocate_slots_growth_and_exhaustion():
+    from vllm_omni_amd.kv_cache import KVCacheBlocks, KVCacheManager
+
+    m = KVCacheManager(num_blocks=8, block_size=16)  # 7 usable blocks
+    m.new_step_starts()
+    a = _req("a", 40)
+    got = m.allocate_slots(a, 40)
+    assert isinstance(got, KVCacheBlocks) and got.get_block_ids() == ([1, 2, 3],)   # ceil(40/16) = 3, never block 0
+    assert m.get_block_ids("a") == ([1, 2, 3],)
+    a.num_computed_tokens = 40
+    for step in range(8):                      # tokens 41..48 fit in block 3
+        assert m.allocate_slots(a, 1).get_block_ids() == ([],)
+        a.num_computed_tokens += 1
+    assert m.allocate_slots(a, 1).get_block_ids() == ([4],)   # token 49 opens a new block
+    a.num_computed_tokens += 1
+    assert m.allocate_slots(a, 1, num_lookahead_tokens=16).get_block_ids() == ([5],)  # lookahead rounds up
+    b = _req("b", 64)
+    assert m.allocate_slots(b, 64) is None      # needs 4, only 2 free: None, and nothing taken
+    assert m.block_pool.get_num_free_blocks() == 2 and m.get_block_ids("b") == ([],)
+    assert m.get_num_common_prefix_blocks("a") == [5]
+    m.free(a)
+    assert m.block_pool.get_num_free_blocks() == 7 and m.get_block_ids("a") == ([],)
+    got_b = m.allocate_slots(b, 64)
+    assert got_b is not None and len(got_b.blocks[0]) == 4
+    assert 0 not in got_b.blocks[0]
+    assert 0.0 < m.usage <= 1.0
+
+
+def test_events_and_new_block_ids_tracking():
+    from vllm_omni_amd.kv_cache import BlockRemoved, BlockStored, KVCacheManager
+
+    m = KVCacheManager(16, 4, enable_kv_cache_events=True, track_new_block_ids=True)
+    r = _req("x", 9)
+    m.allocate_slots(r, 9)
+    assert m.take_new_block_ids() == [1, 2, 3] and m.take_new_block_ids() == []
+    m.free(r)
+    ev = m.take_events()
+    assert isinstance(ev[0], BlockStored) and isinstance(ev[1], BlockRemoved) and m.take_events() == []
+
+
+def test_truncation_rule_matches_scheduler():
+    """ceil(seq_len / block_size) leading ids (omni_ar_scheduler.py:644-651)."""
+    from vllm_omni_amd.kv_cache import KVCacheManager
+
+    m = KVCacheManager(32, 8)
+    r = _req("t", 30)
+    m.allocate_slots(r, 30, num_lookahead_tokens=8)
+    ids = m.get_block_ids("t")[0]
+    assert len(ids) == 5
+    assert ref_ops.truncate_block_ids(ids, 20, 8) == ids[:3]
+
+
+def test_kv_budget_and_layouts():
+    from vllm_omni_amd.kv_cache import (KVCacheSpec, allocate_kv_cache, determine_available_memory, extract_request_kv,
+                                        normalize_layer_kv, num_blocks_for_budget)
+
+    spec = KVCacheSpec(16, 4, 128, torch.bfloat16)
+    assert spec.page_bytes == 32768                                   # 32 KiB / block / layer
+    assert num_blocks_for_budget(int(270e9 * 0.9), 28, spec) == int(270e9 * 0.9) // 917504   # ~2.6e5 blocks (A1)
+    assert determine_available_memory(288 * 2**30, 0.9, 20 * 2**30) == int(288 * 2**30 * 0.9) - 20 * 2**30
+    assert determine_available_memory(100, 0.5, 80) == 0
+    assert determine_available_memory(100, 0.5, 80, kv_cache_memory_bytes=7) == 7
+    small = KVCacheSpec(8, 4, 16, torch.float32)
+    for layout in ("NB2", "2NB", "NB2_HEAD_MAJOR"):
+        caches = allocate_kv_cache(2, 10, small, "cpu", layout)
+        kb, vb = normalize_layer_kv(caches[0])
+        assert kb.shape == (10, 8, 4, 16) and vb.shape == kb.shape and kb.stride(3) == 1
+        kb.copy_(torch.randn(10, 8, 4, 16))
+        vb.copy_(torch.randn(10, 8, 4, 16))
+        keys, vals = extract_request_kv(caches, [1, 3, 5], 20)         # the reference's gather constants
+        exp = ref_ops.extract_kv(kb, vb, [1, 3, 5], 20)
+        assert keys[0].shape == (20, 4, 16) and torch.equal(keys[0], exp[0]) and torch.equal(vals[0], exp[1])
+        assert keys[1] is not None
+    with pytest.raises(ValueError):
+        allocate_kv_cache(1, 4, small, "cpu", "bogus")
+    keys, vals = extract_request_kv([torch.randn(3, 8, 4, 16), (torch.randn(3, 8, 4, 16), torch.randn(2, 8, 4, 16))],
+                                    [0, 1, 2], 32)
+    assert keys[0] is None and keys[1].shape == (16, 4, 16)           # invalid layer skipped; K/V overlap range
+
+
+# ------------------------------------------------------------------------- block table (A3)
+def test_block_table_rows_and_slot_mapping():
+    from vllm_omni_amd.block_table import PAD_SLOT_ID, MultiGroupBlockTable
+
+    bt = MultiGroupBlockTable(max_num_reqs=4, max_model_len=64, max_num_batched_tokens=32, block_sizes=[4], device=None)
+    bt.add_row(([2, 3],), 0)
+    bt.append_row(([9],), 0)
+    bt.add_row(([5],), 1)
+    t0 = bt[0]
+    assert t0.block_table.cpu[0, :3].tolist() == [2, 3, 9] and t0.num_blocks_per_row[0] == 3
+    assert len(bt.block_tables) == 1
+    # slots 8..15 <-> blocks 2,3 at block_size 4 (tests/core/test_prefix_cache.py:173-185)
+    bt.compute_slot_mapping(np.zeros(8, dtype=np.int32), np.arange(8))
+    assert t0.slot_mapping.cpu[:8].tolist() == list(range(8, 16))
+    req = np.array([0, 0, 1], dtype=np.int32)
+    pos = np.array([8, 11, 2])
+    bt.compute_slot_mapping(req, pos)
+    exp = ref_ops.slot_mapping(t0.block_table.cpu, torch.from_numpy(req), torch.from_numpy(pos), 4)
+    assert t0.slot_mapping.cpu[:3].tolist() == exp.tolist() == [36, 39, 22]
+    out = t0.commit_slot_mapping(3, 8)
+    assert out[3:8].tolist() == [PAD_SLOT_ID] * 5                      # padded tail never writes the cache
+    bt.swap_row(0, 1)
+    assert t0.block_table.cpu[1, :3].tolist() == [2, 3, 9] and t0.block_table.cpu[0, 0] == 5
+    bt.move_row(1, 2)
+    assert t0.block_table.cpu[2, :3].tolist() == [2, 3, 9] and t0.num_blocks_per_row[2] == 3
+    with pytest.raises(ValueError):
+        bt.append_row((list(range(20)),), 3)
+    with pytest.raises(Exception):
+        bt.compute_slot_mapping(np.zeros(1, dtype=np.int32), np.array([64 * 4]))   # past the table row
+
+
+def test_input_batch_condense_and_swap():
+    from vllm_omni_amd.model_runner import CachedRequestState, InputBatch
+    from vllm_omni_amd.sched_output import SamplingParams
+
+    ib = InputBatch(4, 64, 16, 4, None)
+    for i, name in enumerate("abc"):
+        ib.add_request(CachedRequestState(name, [1, 2, 3 + i], SamplingParams(), ([10 + i],), num_computed_tokens=i))
+    assert ib.req_ids == ["a", "b", "c"] and ib.last_token_ids_cpu[:3].tolist() == [3, 4, 5]
+    ib.remove_request("a")                                            # last row moves into the hole
+    assert ib.req_ids == ["c", "b"] and ib.req_id_to_index == {"c": 0, "b": 1}
+    assert ib.num_computed_tokens_cpu[:2].tolist() == [2, 1] and ib.block_table[0].block_table.cpu[0, 0] == 12
+    ib.swap(0, 1)
+    assert ib.req_ids == ["b", "c"] and ib.block_table[0].block_table.cpu[0, 0] == 11
+    ib.remove_request("zzz")                                          # unknown id: no-op
+    assert ib.num_reqs == 2
+
+
+# ------------------------------------------------------------------------- plugin boundary (L0)
+def test_platform_plugin_surface():
+    import vllm_omni_amd
+    from vllm_omni_amd.platform import AR_WORKER_QUALNAME, MI355XOmniPlatform, mi355x_platform_plugin
+
+    needed = ["get_omni_ar_worker_cls", "get_omni_generation_worker_cls", "get_default_stage_config_path",
+              "get_diffusion_attn_backend_cls", "supports_torch_inductor", "get_torch_device", "get_device_count",
+              "get_device_version", "synchronize", "get_free_memory", "set_device_control_env_var",
+              "unset_device_control_env_var", "create_autocast_context", "supports_cpu_offload", "supports_float64",
+              "get_profiler_cls", "check_if_supports_dtype"]
+    for name in needed:                                              # vllm_omni/platforms/interface.py:26-165
+        assert callable(getattr(MI355XOmniPlatform, name)), name
+    p = MI355XOmniPlatform()
+    assert p.is_rocm() and not p.is_cuda() and p.dist_backend == "nccl" and p.device_type == "cuda"
+    assert MI355XOmniPlatform.get_omni_ar_worker_cls() == AR_WORKER_QUALNAME
+    mod, cls = AR_WORKER_QUALNAME.rsplit(".", 1)
+    assert hasattr(__import__(mod, fromlist=[cls]), cls)             # the named worker class resolves
+    assert MI355XOmniPlatform.get_torch_device(3) == torch.device("cuda", 3)
+    MI355XOmniPlatform.check_if_supports_dtype(torch.bfloat16)
+    with pytest.raises(ValueError):
+        MI355XOmniPlatform.check_if_supports_dtype(torch.float64)
+    # no gfx950 GPU here -> the plugin declines (returns None) instead of half-activating
+    assert vllm_omni_amd.register_platform() is None or torch.cuda.is_available()
+    assert mi355x_platform_plugin() in (None, "vllm_omni_amd.platform.MI355XOmniPlatform")
+
+
+def test_worker_refuses_non_gpu_device():
+    from vllm_omni_amd.talker import TalkerConfig
+    from vllm_omni_amd.worker import GPUARWorker, WorkerConfig
+
+    w = GPUARWorker(WorkerConfig(TalkerConfig.from_json("mini_talker"), device_type="cpu"))
+    with pytest.raises(RuntimeError, match="Not support device type"):    # gpu_ar_worker.py:89-90
+        w.init_device()
+
+
+# ------------------------------------------------------------------------- TP head rules (A12)
+def test_partition_heads_rules():
+    from vllm_omni_amd.distributed import kv_head_for_rank, partition_heads
+
+    assert partition_heads(28, 4, 1) == (28, 4, 1)
+    assert partition_heads(28, 4, 2) == (14, 2, 1)
+    assert partition_heads(28, 4, 4) == (7, 1, 1)
+    with pytest.raises(ValueError):
+        partition_heads(28, 4, 8)                                     # 28 % 8 != 0 (qwen2_old.py:91)
+    assert partition_heads(16, 2, 8) == (2, 1, 4)                     # KV replication (qwen2_old.py:98-102)
+    assert [list(kv_head_for_rank(2, 8, r)) for r in range(8)] == [[0]] * 4 + [[1]] * 4
+    assert [list(kv_head_for_rank(4, 2, r)) for r in range(2)] == [[0, 1], [2, 3]]
+    with pytest.raises(ValueError):
+        partition_heads(16, 3, 2)
+
+
+def test_talker_config_shapes():
+    from vllm_omni_amd.talker import TalkerConfig, bad_word_mask_spec
+
+    c = TalkerConfig.from_json("qwen2_5_omni_talker")
+    assert (c.num_hidden_layers, c.hidden_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim,
+            c.intermediate_size, c.vocab_size) == (28, 3584, 28, 4, 128, 18944, 8448)
+    assert abs(c.num_params() - 6.57e9) < 0.05e9                      # 6.57 B params
+    assert bad_word_mask_spec(8448, 8296, 8294, 8293) == ([(8296, 8448)], 8293)
+    assert bad_word_mask_spec(8448, 8294, 8294, 8293) == ([(8295, 8448)], 8293)
+    assert bad_word_mask_spec(8448, 8000, 8294, None) == ([(8000, 8294), (8295, 8448)], -1)
+    assert bad_word_mask_spec(8448, None, 8294, 8293) == ([], 8293)
+    with pytest.raises(ValueError):
+        bad_word_mask_spec(8448, 8000, None, 1)

@@ -1,0 +1,127 @@
+"""AR worker: one OS process per GPU / TP rank (SURVEY §8b "Worker class", §3.2).
+
+Mirrors ``GPUARWorker`` (vllm_omni/worker/gpu_ar_worker.py:29-106) and ``OmniGPUWorkerBase``
+(vllm_omni/worker/base.py:49-156): ``init_device`` (set device, create the RCCL groups BEFORE the
+memory snapshot, refuse non-GPU devices), ``load_model``, ``determine_available_memory`` (KV budget),
+``initialize_cache``, ``execute_model`` / ``sample_tokens`` pass-through, ``profile``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .distributed import init_distributed_environment
+from .kv_cache import determine_available_memory, num_blocks_for_budget
+from .model_runner import GPUARModelRunner
+from .talker import TalkerConfig
+
+
+@dataclass
+class WorkerConfig:
+    model_config: TalkerConfig
+    dtype: torch.dtype = torch.bfloat16
+    tensor_parallel_size: int = 1
+    world_size: int = 1
+    gpu_memory_utilization: float = 0.9
+    kv_cache_memory_bytes: Optional[int] = None
+    block_size: int = 16
+    max_num_seqs: int = 256
+    max_model_len: int = 4096
+    max_num_batched_tokens: int = 32768
+    enforce_eager: bool = False
+    engine_output_type: str = "latent"
+    kv_layout: str = "NB2"
+    device_type: str = "cuda"
+    distributed_backend: str = "nccl"
+    seed: int = 0
+
+
+class GPUARWorker:
+    def __init__(self, config: WorkerConfig, local_rank: int = 0, rank: int = 0,
+                 distributed_init_method: Optional[str] = None, is_driver_worker: bool = True):
+        self.config = config
+        self.local_rank = local_rank
+        self.rank = rank
+        self.distributed_init_method = distributed_init_method
+        self.is_driver_worker = is_driver_worker
+        self.device: Optional[torch.device] = None
+        self.model_runner: Optional[GPUARModelRunner] = None
+        self.init_free_bytes = 0
+        self.total_bytes = 0
+        self._profiler = None
+
+    def init_device(self) -> None:
+        if self.config.device_type != "cuda":
+            # the reference refuses anything else the same way (gpu_ar_worker.py:89-90)
+            raise RuntimeError(f"Not support device type: {self.config.device_type}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("Not support device type: no ROCm GPU visible (the HIP kernels have no CPU path)")
+        self.device = torch.device("cuda", self.local_rank)
+        torch.cuda.set_device(self.device)
+        from .platform import MI355XOmniPlatform
+
+        MI355XOmniPlatform.check_if_supports_dtype(self.config.dtype)
+        # distributed groups first, so communicator buffers are inside the memory snapshot
+        init_distributed_environment(self.config.world_size, self.rank, self.config.tensor_parallel_size,
+                                     backend=self.config.distributed_backend,
+                                     init_method=self.distributed_init_method, device=self.device)
+        torch.cuda.empty_cache()
+        self.init_free_bytes, self.total_bytes = torch.cuda.mem_get_info(self.device)
+        self.model_runner = GPUARModelRunner(
+            self.config.model_config, self.device, self.config.dtype, max_num_reqs=self.config.max_num_seqs,
+            max_model_len=self.config.max_model_len, max_num_batched_tokens=self.config.max_num_batched_tokens,
+            block_size=self.config.block_size, kv_layout=self.config.kv_layout,
+            enforce_eager=self.config.enforce_eager, engine_output_type=self.config.engine_output_type,
+            seed=self.config.seed)
+
+    def load_model(self) -> None:
+        self.model_runner.load_model()
+
+    def get_model(self):
+        return self.model_runner.get_model()
+
+    @torch.inference_mode()
+    def determine_available_memory(self) -> int:
+        """Bytes available for the KV cache on this rank (base.py:77-156): requested =
+        total * gpu_memory_utilization; available = requested - what this process already holds
+        (weights + persistent buffers, read from the allocator; NVML per-PID accounting does not
+        exist on AMD, so this is the profiling branch base.py:134-154)."""
+        torch.cuda.synchronize()
+        free_now, total = torch.cuda.mem_get_info(self.device)
+        used_by_process = max(torch.cuda.memory_reserved(self.device), self.init_free_bytes - free_now)
+        return determine_available_memory(total, self.config.gpu_memory_utilization, used_by_process,
+                                          self.config.kv_cache_memory_bytes)
+
+    def get_kv_cache_spec(self):
+        return self.model_runner.get_kv_cache_spec()
+
+    def determine_num_available_blocks(self) -> int:
+        spec = self.get_kv_cache_spec()
+        return num_blocks_for_budget(self.determine_available_memory(), self.config.model_config.num_hidden_layers, spec)
+
+    def initialize_cache(self, num_gpu_blocks: int) -> None:
+        self.model_runner.initialize_kv_cache(num_gpu_blocks)
+
+    def compile_or_warm_up_model(self, batch_sizes: Optional[list[int]] = None) -> None:
+        if not self.config.enforce_eager:
+            self.model_runner.capture_model(batch_sizes)
+
+    def execute_model(self, scheduler_output, intermediate_tensors=None):
+        return self.model_runner.execute_model(scheduler_output, intermediate_tensors)
+
+    def sample_tokens(self, grammar_output=None):
+        return self.model_runner.sample_tokens(grammar_output)
+
+    def profile(self, is_start: bool = True, profile_prefix: Optional[str] = None) -> None:
+        """torch.profiler start/stop RPC (base.py:49-75); ranges show up as roctx under PyTorch-ROCm."""
+        if is_start:
+            self._profiler = torch.profiler.profile(
+                activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA])
+            self._profiler.__enter__()
+        elif self._profiler is not None:
+            self._profiler.__exit__(None, None, None)
+            if profile_prefix:
+                self._profiler.export_chrome_trace(f"{profile_prefix}_rank{self.rank}.json")
+            self._profiler = None
