@@ -126,6 +126,11 @@ int mi_paged_attn_decode(void* out, const void* q, const void* k_cache, const vo
 /* Partition size the auto heuristic would pick (exposed for bench/DESIGN). */
 int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
                                             int32_t max_seq_len);
+/* Partition size a call really uses: `requested` (0 = auto) capped at 64 KV blocks.  Size the
+ * workspace with THIS value. */
+int32_t mi_paged_attn_decode_effective_partition(int32_t num_seqs, int32_t num_kv_heads,
+                                                 int32_t max_seq_len, int32_t block_size,
+                                                 int32_t requested);
 
 /* ------------------------------------------------------------------------
  * A6 — paged-attention prefill / chunked prefill (q_len >= 1, varlen, causal

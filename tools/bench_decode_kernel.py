@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--layout", default="NB2")
     ap.add_argument("--parts", default="0,256,512,1024,2048,4096")
+    ap.add_argument("--modes", default="0,1", help="0 = exact fp32 P, 1 = packed PV")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -46,12 +47,12 @@ def main():
     algo_bytes = 2 * a.nkv * a.d * 2 * a.ctx * a.batch
     print(f"layout={a.layout} batch={a.batch} ctx={a.ctx} nq={a.nq} nkv={a.nkv} d={a.d} "
           f"algorithmic bytes/launch={algo_bytes / 1e9:.3f} GB")
-    for packed in (False, True):
+    for packed in [bool(int(x)) for x in a.modes.split(",")]:
         for ps in [int(x) for x in a.parts.split(",")]:
-            eff = ps or ops.decode_auto_partition(a.batch, a.nkv, a.ctx)
+            eff = ops.decode_auto_partition(a.batch, a.nkv, a.ctx, a.bs, ps)
             ws = torch.empty(max(1, ops.decode_workspace_bytes(a.batch, a.nq, a.d, a.ctx, eff)), dtype=torch.uint8,
                              device=dev)
-            for _ in range(3):
+            for _ in range(10):
                 ops.paged_attn_decode(out, q, kb, vb, table, seq_lens, a.ctx, a.d ** -0.5, partition_size=eff,
                                       workspace=ws, packed_pv=packed)
             torch.cuda.synchronize()

@@ -51,7 +51,7 @@ constexpr int kTile = 16;
 constexpr float kNegBig = -3.0e38f;
 
 template <typename Tag, int HD, int G, bool PACKED_PV>
-__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+__global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
   using E = Elem<Tag>;
   constexpr int LPT = HD / 8;      // lanes per token row
   constexpr int TPL = 64 / LPT;    // token rows per wave-load
@@ -97,12 +97,11 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
     return;
   }
 
-  const uint16_t* const kbase = reinterpret_cast<const uint16_t*>(p.k_cache);
-  const uint16_t* const vbase = reinterpret_cast<const uint16_t*>(p.v_cache);
   const int32_t* const bt_row = p.block_table + (int64_t)seq * p.block_table_stride;
   const int bs_mask = (1 << p.bs_log2) - 1;
   const int last_blk = (seq_len - 1) >> p.bs_log2;
   const int64_t lane_off = (int64_t)g * p.tok_stride + (int64_t)kvh * p.head_stride + c * 8;
+  const int limit = min(seq_len, t_end * kTile);
 
   // ---- q: G heads, this lane's 8 dims, kept packed for dot2 -------------
   uint4 qv[G];
@@ -122,130 +121,172 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
     for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
   }
 
+  // Block ids of this partition live in ONE VGPR (lane i = i-th block of the partition; the host
+  // caps a partition at 64 blocks) and are picked with v_readlane: the loop then issues nothing
+  // but K/V loads, so the in-order vmcnt queue never makes a tile wait behind a table fetch.
+  const int first_blk = (t_begin * kTile) >> p.bs_log2;
+  const int win_ids = bt_row[min(first_blk + lane, last_blk)];
+
+  // Addressing: the block base is wave-uniform (SGPR pair), the per-lane part is ONE constant
+  // 32-bit byte offset -> `global_load_dwordx4 v, v_off, s[base]` with no per-load VALU math.
+  const uint32_t lane_off_b = (uint32_t)(lane_off * 2);
+  const char* const kbase_b = reinterpret_cast<const char*>(p.k_cache);
+  const char* const vbase_b = reinterpret_cast<const char*>(p.v_cache);
+  constexpr int CH = NL >= 4 ? 2 : NL;  // wave-loads per chunk (8 tokens at head_dim 128)
+  // byte offset (wave-uniform) of the rows of wave-load i of tile t
+  auto row_base = [&](int t, int i) -> int64_t {
+    const int tok0 = t * kTile + i * TPL;
+    // clamp: rows past seq_len must not walk into unallocated table entries
+    const int blk = min(tok0 >> p.bs_log2, last_blk);
+    const int phys = __builtin_amdgcn_readlane(win_ids, blk - first_blk);
+    return ((int64_t)phys * p.blk_stride + (int64_t)(tok0 & bs_mask) * p.tok_stride) * 2;
+  };
+  // Loads are issued per chunk, in CONSUMPTION order (K chunk, then V chunk): vmcnt retires in
+  // order, so the wait in front of a chunk never covers loads issued after it.
+  auto load_k = [&](int t, int c0, uint4(&kr)[NL]) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      kr[c0 + i] = *reinterpret_cast<const uint4*>(kbase_b + row_base(t, c0 + i) + lane_off_b);
+  };
+  auto load_v = [&](int t, int c0, uint4(&vr)[NL]) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      vr[c0 + i] = *reinterpret_cast<const uint4*>(vbase_b + row_base(t, c0 + i) + lane_off_b);
+  };
   auto load_tile = [&](int t, uint4(&kr)[NL], uint4(&vr)[NL]) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int tok0 = t * kTile + i * TPL;  // wave-uniform
-      // clamp: rows past seq_len must not walk into unallocated table entries
-      const int blk = min(tok0 >> p.bs_log2, last_blk);
-      const int phys = bt_row[blk];
-      const int64_t e = (int64_t)phys * p.blk_stride + (int64_t)(tok0 & bs_mask) * p.tok_stride +
-                        lane_off;
-      kr[i] = *reinterpret_cast<const uint4*>(kbase + e);
-      vr[i] = *reinterpret_cast<const uint4*>(vbase + e);
+    for (int c0 = 0; c0 < NL; c0 += CH) {
+      load_k(t, c0, kr);
+      load_v(t, c0, vr);
     }
   };
 
-  auto compute = [&](int t, const uint4(&kr)[NL], const uint4(&vr_in)[NL]) {
-    // ---- scores: s[h][i] = q_h . k_(token i*TPL+g) -----------------------
-    float s[G][NL];
+  // A tile is consumed in chunks of CH wave-loads (8 tokens at head_dim 128): scores, online
+  // softmax update and P.V per chunk, which halves the live score/probability registers.
+  // Rolling ring: as soon as a chunk's registers have been consumed they are refilled with the
+  // same chunk of tile `t_next` (two tiles ahead), so ~2 tiles (16 KiB) per wave stay in flight
+  // with no registers beyond the two tile buffers.
+  auto compute = [&](int t, uint4(&kr)[NL], uint4(&vr_in)[NL], int t_next) {
+    const bool tail = (t + 1) * kTile > limit;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
+    for (int c0 = 0; c0 < NL; c0 += CH) {
+      // ---- scores: s[h][i] = q_h . k_(token (c0+i)*TPL+g) -------------------
+      float s[G][CH];
 #pragma unroll
-      for (int h = 0; h < G; ++h) {
-        float a = E::dot2(qv[h].x, kr[i].x, 0.f);
-        a = E::dot2(qv[h].y, kr[i].y, a);
-        a = E::dot2(qv[h].z, kr[i].z, a);
-        a = E::dot2(qv[h].w, kr[i].w, a);
-        s[h][i] = group_allreduce_sum<LPT>(a) * p.scale_log2e;
-      }
-    }
-    uint4 vr[NL];
+      for (int i = 0; i < CH; ++i) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) vr[i] = vr_in[i];
-    const bool tail = (t + 1) * kTile > seq_len;  // wave-uniform
-    if (tail) {
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const bool valid = t * kTile + i * TPL + g < seq_len;
-        if (!valid) {
-          vr[i] = make_uint4(0, 0, 0, 0);  // 0 * garbage must not make NaN
-#pragma unroll
-          for (int h = 0; h < G; ++h) s[h][i] = -INFINITY;
+        for (int h = 0; h < G; ++h) {
+          float a = E::dot2(qv[h].x, kr[c0 + i].x, 0.f);
+          a = E::dot2(qv[h].y, kr[c0 + i].y, a);
+          a = E::dot2(qv[h].z, kr[c0 + i].z, a);
+          a = E::dot2(qv[h].w, kr[c0 + i].w, a);
+          s[h][i] = group_allreduce_sum<LPT>(a) * p.scale_log2e;
         }
       }
-    }
-    // ---- online softmax (per lane group; groups merged after the loop) ----
-    bool moved = false;
-    float m_new[G];
+      __builtin_amdgcn_sched_barrier(0);
+      load_k(t_next, c0, kr);  // K chunk consumed -> refill it now
+      __builtin_amdgcn_sched_barrier(0);
+      uint4 vr[CH];
 #pragma unroll
-    for (int h = 0; h < G; ++h) {
-      float tm = s[h][0];
+      for (int i = 0; i < CH; ++i) vr[i] = vr_in[c0 + i];
+      // rows at or past `limit` (end of the sequence, or of this partition when the pipeline
+      // runs one tile over) contribute nothing: score -inf, V zeroed (0 * garbage != NaN)
+      if (tail) {
 #pragma unroll
-      for (int i = 1; i < NL; ++i) tm = fmaxf(tm, s[h][i]);
-      m_new[h] = fmaxf(m[h], tm);
-      moved |= (m_new[h] != m[h]);
-    }
-    if (__any(moved)) {
+        for (int i = 0; i < CH; ++i) {
+          const bool valid = t * kTile + (c0 + i) * TPL + g < limit;
+          if (!valid) {
+            vr[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-      for (int h = 0; h < G; ++h) {
-        const float alpha = fast_exp2(m[h] - m_new[h]);
-        m[h] = m_new[h];
-        l[h] *= alpha;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[h][e] *= alpha;
-      }
-    }
-    float pr[G][NL];
-#pragma unroll
-    for (int h = 0; h < G; ++h) {
-      float ls = 0.f;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        pr[h][i] = fast_exp2(s[h][i] - m[h]);
-        ls += pr[h][i];
-      }
-      l[h] += ls;
-    }
-    // ---- PV ---------------------------------------------------------------
-    if constexpr (PACKED_PV) {
-#pragma unroll
-      for (int i = 0; i < NL; i += 2) {
-        uint32_t pp[G];
-#pragma unroll
-        for (int h = 0; h < G; ++h) pp[h] = E::pack(pr[h][i], pr[h][i + 1]);
-        const uint32_t a[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
-        const uint32_t b[4] = {vr[i + 1].x, vr[i + 1].y, vr[i + 1].z, vr[i + 1].w};
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          // (tok i, tok i+1) pairs for dims 2w and 2w+1
-          const uint32_t lo = __builtin_amdgcn_perm(b[w], a[w], 0x05040100u);
-          const uint32_t hi = __builtin_amdgcn_perm(b[w], a[w], 0x07060302u);
-#pragma unroll
-          for (int h = 0; h < G; ++h) {
-            acc[h][2 * w] = E::dot2(pp[h], lo, acc[h][2 * w]);
-            acc[h][2 * w + 1] = E::dot2(pp[h], hi, acc[h][2 * w + 1]);
+            for (int h = 0; h < G; ++h) s[h][i] = -INFINITY;
           }
         }
       }
-    } else {
+      // ---- online softmax (per lane group; groups merged after the loop) ------
+      bool moved = false;
+      float m_new[G];
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const uint32_t a[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+      for (int h = 0; h < G; ++h) {
+        float tm = s[h][0];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const float v0 = E::lo(a[w]), v1 = E::hi(a[w]);
+        for (int i = 1; i < CH; ++i) tm = fmaxf(tm, s[h][i]);
+        m_new[h] = fmaxf(m[h], tm);
+        moved |= (m_new[h] != m[h]);
+      }
+      if (__any(moved)) {
 #pragma unroll
-          for (int h = 0; h < G; ++h) {
-            acc[h][2 * w] = __builtin_fmaf(pr[h][i], v0, acc[h][2 * w]);
-            acc[h][2 * w + 1] = __builtin_fmaf(pr[h][i], v1, acc[h][2 * w + 1]);
+        for (int h = 0; h < G; ++h) {
+          const float alpha = fast_exp2(m[h] - m_new[h]);
+          m[h] = m_new[h];
+          l[h] *= alpha;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[h][e] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        float ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          s[h][i] = fast_exp2(s[h][i] - m[h]);  // s now holds the probabilities
+          ls += s[h][i];
+        }
+        l[h] += ls;
+      }
+      // ---- PV -------------------------------------------------------------------
+      if constexpr (PACKED_PV && CH >= 2) {
+#pragma unroll
+        for (int i = 0; i < CH; i += 2) {
+          uint32_t pp[G];
+#pragma unroll
+          for (int h = 0; h < G; ++h) pp[h] = E::pack(s[h][i], s[h][i + 1]);
+          const uint32_t a[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+          const uint32_t b[4] = {vr[i + 1].x, vr[i + 1].y, vr[i + 1].z, vr[i + 1].w};
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            // (tok i, tok i+1) pairs for dims 2w and 2w+1
+            const uint32_t lo = __builtin_amdgcn_perm(b[w], a[w], 0x05040100u);
+            const uint32_t hi = __builtin_amdgcn_perm(b[w], a[w], 0x07060302u);
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+              acc[h][2 * w] = E::dot2(pp[h], lo, acc[h][2 * w]);
+              acc[h][2 * w + 1] = E::dot2(pp[h], hi, acc[h][2 * w + 1]);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const uint32_t a[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float v0 = E::lo(a[w]), v1 = E::hi(a[w]);
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+              acc[h][2 * w] = __builtin_fmaf(s[h][i], v0, acc[h][2 * w]);
+              acc[h][2 * w + 1] = __builtin_fmaf(s[h][i], v1, acc[h][2 * w + 1]);
+            }
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      load_v(t_next, c0, vr_in);  // V chunk consumed (vr holds the copy) -> refill it now
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   // ---- main loop: register double buffer, static indexing ----------------
+  // NO branch around any load (hipcc otherwise waits right after issuing them, §5 "Three .s-level
+  // traps" (c) of the programming guide): tile indices are clamped instead, and a tile past the
+  // partition is neutralised by the `limit` mask in compute().
   uint4 kA[NL], vA[NL], kB[NL], vB[NL];
+  const int t_last = t_end - 1;
   load_tile(t_begin, kA, vA);
+  load_tile(min(t_begin + 1, t_last), kB, vB);
+  __builtin_amdgcn_sched_barrier(0);
   for (int t = t_begin; t < t_end; t += 2) {
-    const bool has_b = t + 1 < t_end;
-    if (has_b) load_tile(t + 1, kB, vB);
-    compute(t, kA, vA);
-    if (has_b) {
-      if (t + 2 < t_end) load_tile(t + 2, kA, vA);
-      compute(t + 1, kB, vB);
-    }
+    compute(t, kA, vA, min(t + 2, t_last));
+    compute(t + 1, kB, vB, min(t + 3, t_last));
   }
 
   // ---- merge the NG lane groups of the wave -------------------------------
@@ -394,7 +435,20 @@ extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t
     else break;
   }
   if (best > mi::round_up(max_seq_len, mi::kTile)) best = mi::round_up(max_seq_len, mi::kTile);
-  return best;
+  return best;  // the caller additionally caps it at 64 blocks (mi_paged_attn_decode)
+}
+
+// The partition size a call will really use: `requested` (0 = auto), capped at 64 KV blocks
+// (the kernel keeps a partition's block ids in one 64-lane register) and kept a multiple of 16.
+extern "C" int32_t mi_paged_attn_decode_effective_partition(int32_t num_seqs, int32_t num_kv_heads,
+                                                            int32_t max_seq_len, int32_t block_size,
+                                                            int32_t requested) {
+  if (block_size <= 0) return 0;
+  int32_t ps = requested > 0 ? requested
+                             : mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len);
+  const int32_t cap = 64 * block_size;
+  if (ps > cap) ps = cap;
+  return ps;
 }
 
 extern "C" int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
@@ -438,9 +492,9 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   if (((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) & 15)
     return MI_ERR_INVALID_ARG;
 
-  if (partition_size <= 0)
-    partition_size = mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len);
-  if (partition_size % kTile) return MI_ERR_INVALID_ARG;
+  partition_size = mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len,
+                                                            block_size, partition_size);
+  if (partition_size <= 0 || partition_size % kTile) return MI_ERR_INVALID_ARG;
   const int num_parts = (max_seq_len + partition_size - 1) / partition_size;
   const int64_t need = mi_paged_attn_decode_workspace_bytes(num_seqs, num_q_heads, head_dim,
                                                             max_seq_len, partition_size);

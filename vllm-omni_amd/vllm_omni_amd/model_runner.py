@@ -201,7 +201,8 @@ class GPUARModelRunner:
         for layer, kv in zip(self.model.language_model.model.layers, self.kv_caches):
             layer.self_attn.attn.bind_kv_cache(kv)
         a = self.model.language_model.model.layers[0].self_attn
-        self._decode_part = ops.decode_auto_partition(self.max_num_reqs, a.num_kv_heads, self.max_model_len)
+        self._decode_part = ops.decode_auto_partition(self.max_num_reqs, a.num_kv_heads, self.max_model_len,
+                                                       self.block_size)
         nbytes = ops.decode_workspace_bytes(self.max_num_reqs, a.num_heads, a.head_dim, self.max_model_len,
                                             self._decode_part)
         self._decode_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)

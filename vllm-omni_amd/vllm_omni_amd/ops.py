@@ -113,8 +113,11 @@ def rope_neox_and_cache(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tens
 DECODE_PACKED_PV = False
 
 
-def decode_auto_partition(num_seqs: int, num_kv_heads: int, max_seq_len: int) -> int:
-    return int(lib.mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len))
+def decode_auto_partition(num_seqs: int, num_kv_heads: int, max_seq_len: int, block_size: int = 16,
+                          requested: int = 0) -> int:
+    """Partition size a decode call will really use (``requested`` or auto, capped at 64 blocks)."""
+    return int(lib.mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len, block_size,
+                                                            requested))
 
 
 def decode_workspace_bytes(num_seqs: int, num_q_heads: int, head_dim: int, max_seq_len: int,
@@ -145,8 +148,7 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
     cb, ct, ch = _cache_strides(k_cache, v_cache)
     if s == 0:
         return out
-    if partition_size <= 0:
-        partition_size = decode_auto_partition(s, hkv, max_seq_len)
+    partition_size = decode_auto_partition(s, hkv, max_seq_len, bs, partition_size)
     need = decode_workspace_bytes(s, nq, d, max_seq_len, partition_size)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
