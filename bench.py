@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--ctx", type=int, default=4096)
     ap.add_argument("--config", default="qwen2_5_omni_talker")
     ap.add_argument("--block-size", type=int, default=16)
-    ap.add_argument("--kv-layout", default="NB2")
+    ap.add_argument("--kv-layout", default="NB2_HEAD_MAJOR")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
     ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps for per-launch timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -271,7 +271,7 @@ def main():
                 traffic = pj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "mi::decode_kernel (paged-attention decode)", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "mi::decode_mfma_kernel (paged-attention decode)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 4),
                 "launches_timed": launches,

@@ -106,11 +106,16 @@ int mi_rope_neox_and_cache(void* q, void* k, const void* v, const int64_t* posit
  * on seq_lens[] that sizes the grid, so the launch is graph-replayable while
  * sequences grow.  seq_lens[s] == 0 writes zeros.
  * out_dtype: MI_DTYPE_F32 is accepted for parity measurement.
- * flags: MI_DECODE_PACKED_PV rounds the (unnormalised) probabilities to the cache
- * dtype and contracts P.V two tokens at a time with v_dot2c (what flash-style
- * kernels, incl. the reference's TRITON_ATTN backend, do); without it P stays fp32.
+ * flags: MI_DECODE_PACKED_PV allows the (unnormalised) probabilities to be rounded to
+ * the cache dtype before P.V (what flash-style kernels, incl. the reference's
+ * TRITON_ATTN backend, do).  That selects the matrix-core kernel where it is built
+ * (head_dim 128, block_size >= 16, partition a multiple of 32) and the dot2 form of
+ * the VALU kernel elsewhere; without the flag P stays fp32 (VALU kernel, exact mode).
+ * MI_DECODE_FORCE_VALU keeps the VALU kernel even with PACKED_PV (A/B measurements).
  * ---------------------------------------------------------------------- */
 #define MI_DECODE_PACKED_PV 1
+#define MI_DECODE_FORCE_VALU 2
+#define MI_DECODE_NONTEMPORAL 4 /* nt cache policy on the K/V stream (matrix-core kernel) */
 int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
                                              int32_t head_dim, int32_t max_seq_len,
                                              int32_t partition_size);

@@ -38,7 +38,18 @@ def _mk_case(S, nq, nkv, d, bs, seq_lens, dtype, seed=0, nb_extra=7, layout="nb2
     return kv, kb, vb, table, q, torch.tensor(seq_lens, dtype=torch.int32)
 
 
-def _run(dev, kv, layout, table, q, seq_lens, out_dtype, partition_size=0, max_seq_len=None, packed_pv=False):
+MODES = ["exact", "packed_valu", "fast"]   # fast = MFMA kernel where built, else packed VALU
+
+
+def _tol(mode, dtype):
+    """(rtol, atol) vs the fp32 oracle.  exact: the north_star bar.  packed/fast: P rounded to the cache
+    dtype (2^-9 / 2^-12 relative per term, |out| <= max|V| ~ 4)."""
+    if mode == "exact":
+        return 1e-3, 1e-4
+    return (1e-3, 6e-3) if dtype == torch.bfloat16 else (1e-3, 1e-3)
+
+
+def _run(dev, kv, layout, table, q, seq_lens, out_dtype, partition_size=0, max_seq_len=None, mode="exact"):
     from vllm_omni_amd import ops
 
     kvg = kv.to(dev)
@@ -52,7 +63,8 @@ def _run(dev, kv, layout, table, q, seq_lens, out_dtype, partition_size=0, max_s
     out = torch.full((S, nq * d), float("nan"), dtype=out_dtype, device=dev)
     msl = int(seq_lens.max()) if max_seq_len is None else max_seq_len
     ops.paged_attn_decode(out, q.view(S, nq * d).to(dev), kb, vb, table.to(dev), seq_lens.to(dev),
-                          max(msl, 1), d ** -0.5, partition_size=partition_size, packed_pv=packed_pv)
+                          max(msl, 1), d ** -0.5, partition_size=partition_size, packed_pv=mode != "exact",
+                          force_valu=mode == "packed_valu")
     torch.cuda.synchronize()
     return out.cpu().view(S, nq, d)
 
@@ -77,44 +89,49 @@ def test_decode_matches_oracle(dev, case, dtype):
     S, nq, nkv, d, bs, lens = case
     kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, dtype)
     ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
-    # exact mode (fp32 P): the north_star tolerance, strictly
-    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32)
-    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4)
-    # packed mode: P rounded to the cache dtype (2^-9 / 2^-12 relative per term)
-    gotp = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, packed_pv=True)
-    torch.testing.assert_close(gotp, ref, rtol=1e-3, atol=6e-3 if dtype == torch.bfloat16 else 1e-3)
-    # production output dtype: exactly the rounding of the fp32 result
-    for packed, g32 in ((False, got), (True, gotp)):
-        got16 = _run(dev, kv, "nb2", table, q, seq_lens, dtype, packed_pv=packed)
-        assert torch.equal(got16, g32.to(dtype))
+    for mode in MODES:
+        got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, mode=mode)
+        rtol, atol = _tol(mode, dtype)
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=atol, msg=lambda m: f"[{mode}] {m}")
+        # production output dtype: exactly the rounding of the fp32 result
+        got16 = _run(dev, kv, "nb2", table, q, seq_lens, dtype, mode=mode)
+        assert torch.equal(got16, got.to(dtype)), mode
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("layout", ["nb2", "2nb", "head_major"])
-def test_decode_cache_layouts(dev, layout):
+def test_decode_cache_layouts(dev, layout, mode):
     """The three physical layouts behind the reference's accepted views (kv_utils.py:378-450)."""
     S, nq, nkv, d, bs, lens = 3, 8, 2, 128, 16, [1, 17, 40]
     kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, torch.bfloat16, seed=3, layout=layout)
-    got = _run(dev, kv, layout, table, q, seq_lens, torch.float32)
+    got = _run(dev, kv, layout, table, q, seq_lens, torch.float32, mode=mode)
     ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
-    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+    rtol, atol = _tol(mode, torch.bfloat16)
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("mode", ["exact", "fast"])
 @pytest.mark.parametrize("partition_size", [16, 32, 64, 256, 1024])
-def test_decode_partitions_agree(dev, partition_size):
+def test_decode_partitions_agree(dev, partition_size, mode):
     """Split-context + merge must not change the answer (beyond fp32 reassociation)."""
     S, nq, nkv, d, bs = 3, 28, 4, 128, 16
     lens = [1, 130, 517]
     kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, torch.bfloat16, seed=5)
-    one = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=1024)
-    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=partition_size)
-    torch.testing.assert_close(got, one, rtol=1e-4, atol=1e-4)
+    ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
+    rtol, atol = _tol(mode, torch.bfloat16)
+    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=partition_size, mode=mode)
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+    if mode == "exact":  # fp32 P: partitions only reassociate fp32 sums
+        one = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=1024, mode=mode)
+        torch.testing.assert_close(got, one, rtol=1e-4, atol=1e-4)
     # a launch sized for a longer bound (graph replay while sequences grow) gives the same result
     got2 = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=partition_size,
-                max_seq_len=2048)
-    torch.testing.assert_close(got2, one, rtol=1e-4, atol=1e-4)
+                max_seq_len=2048, mode=mode)
+    assert torch.equal(got2, got)
 
 
-def test_decode_block_table_indexing_bit_exact(dev):
+@pytest.mark.parametrize("mode", MODES)
+def test_decode_block_table_indexing_bit_exact(dev, mode):
     """One-hot attention over integer-valued V: the output IS the row the block table points at."""
     S, nq, nkv, d, bs = 4, 8, 2, 128, 16
     lens = [16, 17, 63, 100]
@@ -129,14 +146,16 @@ def test_decode_block_table_indexing_bit_exact(dev):
             blk, off = int(table[s, t // bs]), t % bs
             vb[blk, off] = torch.randint(-8, 8, (nkv, d), generator=g).to(torch.bfloat16)
             kb[blk, off, :, 0] = 200.0 if t == tgt else -200.0
-    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.bfloat16)
+    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.bfloat16, mode=mode)
     for s, tgt in enumerate(targets):
         blk, off = int(table[s, tgt // bs]), tgt % bs
         exp = vb[blk, off].repeat_interleave(nq // nkv, dim=0)
         assert torch.equal(got[s], exp), f"seq {s}: wrong row gathered"
 
 
-def test_decode_ignores_garbage_past_seq_len(dev):
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("partition_size", [16, 32])
+def test_decode_ignores_garbage_past_seq_len(dev, mode, partition_size):
     """NaN/Inf in cache rows beyond seq_len (same block, or unallocated table entries) must not leak."""
     S, nq, nkv, d, bs = 2, 8, 2, 128, 16
     lens = [5, 37]
@@ -147,28 +166,33 @@ def test_decode_ignores_garbage_past_seq_len(dev):
         kb[blk, n % bs:] = float("nan")
         vb[blk, n % bs:] = float("inf")
     table[0, 1:] = -12345  # never-allocated entries: must not be dereferenced
-    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=16, max_seq_len=64)
+    got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=partition_size, max_seq_len=64,
+               mode=mode)
     assert torch.isfinite(got).all()
-    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+    rtol, atol = _tol(mode, torch.bfloat16)
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=max(atol, 1e-3))
 
 
-def test_decode_empty_and_zero_len(dev):
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_decode_empty_and_zero_len(dev, mode):
     from vllm_omni_amd import ops
 
     S, nq, nkv, d, bs = 3, 8, 2, 128, 16
     kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, [0, 20, 0], torch.bfloat16)
-    for ps in (0, 16):
-        got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=ps, max_seq_len=64)
+    for ps in (0, 16, 32):
+        got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=ps, max_seq_len=64, mode=mode)
         assert torch.equal(got[0], torch.zeros(nq, d)) and torch.equal(got[2], torch.zeros(nq, d))
         ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
-        torch.testing.assert_close(got[1], ref[1], rtol=1e-3, atol=1e-3)
+        rtol, atol = _tol(mode, torch.bfloat16)
+        torch.testing.assert_close(got[1], ref[1], rtol=rtol, atol=max(atol, 1e-3))
     # zero sequences: no launch, no error
     e = torch.empty(0, nq * d, dtype=torch.bfloat16, device=dev)
     ops.paged_attn_decode(e, e, kv.to(dev)[:, 0], kv.to(dev)[:, 1], torch.empty(0, 4, dtype=torch.int32, device=dev),
                           torch.empty(0, dtype=torch.int32, device=dev), 16, 1.0)
 
 
-def test_decode_softmax_extremes(dev):
+@pytest.mark.parametrize("mode", MODES)
+def test_decode_softmax_extremes(dev, mode):
     """Running-max rescale path: a late, much larger score must take over exactly (rule 26)."""
     S, nq, nkv, d, bs = 1, 8, 2, 128, 16
     n = 200
@@ -179,9 +203,10 @@ def test_decode_softmax_extremes(dev):
         kb[blk, off] = (q[0, ::nq // nkv] * 3.0).to(torch.bfloat16)
     ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
     for ps in (16, 64, 1024):
-        got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=ps)
+        got = _run(dev, kv, "nb2", table, q, seq_lens, torch.float32, partition_size=ps, mode=mode)
         assert torch.isfinite(got).all()
-        torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)
+        rtol, atol = _tol(mode, torch.bfloat16)
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=max(atol, 1e-3))
 
 
 def test_decode_rejects_bad_arguments(dev):

@@ -37,7 +37,9 @@ def _setup(dev, cfg_name, ctxs, enforce_eager, mrope):
     cpu_caches = []
     for kv in runner.kv_caches:
         init = torch.randn(nb, 2, bs, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
-        kv.copy_(init.to(dev))
+        kb, vb = normalize_layer_kv(kv)   # whatever physical layout the runner chose
+        kb.copy_(init[:, 0].to(dev))
+        vb.copy_(init[:, 1].to(dev))
         cpu_caches.append((init[:, 0].clone(), init[:, 1].clone()))
     mgr = KVCacheManager(nb, bs)
     scramble = mgr.block_pool.get_new_blocks(nb - 1)

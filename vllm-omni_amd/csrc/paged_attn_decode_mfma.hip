@@ -1,0 +1,402 @@
+// A5 — paged-attention decode, matrix-core variant (gfx950).
+//
+// Why it exists: PMC counters of the VALU kernel (paged_attn_decode.hip) at B=256, ctx=4096 show
+// the waves 10 % waiting on memory, 48 % issuing VALU and 31 % stalled at issue — with G = 7 query
+// rows per KV head the score reductions and the per-lane-redundant softmax make the op
+// VALU-bound (~660 VALU instructions per 16 tokens), not HBM-bound.  Here the two contractions run
+// on MFMA (v_mfma_f32_16x16x32_{bf16,f16}; the G <= 16 query rows are one 16-wide tile, unused
+// columns are zero) and the VALU only does the softmax of a 16x32 score tile (~60 instructions per
+// 32 tokens).  MFMA time is ~4 % of the HBM time of the same bytes, so the padding is free.
+//
+// Data flow per wave = (sequence, query heads of one KV head, context partition), 32 tokens/step:
+//   * K and V rows go HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`): one wave-instruction moves
+//     4 whole 256-B token rows (full 128-B lines), needs no VGPR, and stays in flight across the
+//     math of the previous step.  The LDS image is [32 rows][256 B], XOR-swizzled per 16-B chunk
+//     through the per-lane SOURCE address (the DMA destination is lane-linear).
+//   * swapped QK^T: S^T[tok, head] = K[tok, :] . Q^T[:, head]; A = K rows (`ds_read_b128`), B = Q^T
+//     fragments held in registers.  Each lane then owns ONE head and 8 tokens: the softmax axis is
+//     lane-local plus two cross-row shuffles.
+//   * P^T (bf16/f16) is the B operand of O^T[d, head] += V^T[d, tok] . P^T[tok, head] as it stands
+//     (a k-slot permutation shared by both operands); V^T fragments come from the row-major V
+//     image through `ds_read_b64_tr_b16`.
+//   * O^T accumulates over all tokens of the wave inside the MFMA, so no end-of-wave merge.
+// Numerics: fp32 scores/statistics/accumulators; P is rounded to the cache dtype for the MFMA
+// (as the reference's TRITON_ATTN kernel does before `tl.dot(P, V)`).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "decode_params.h"
+
+namespace mi {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+template <typename Tag>
+__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mfma16<bf16_tag>(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma16<f16_tag>(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int kStep = 32;  // tokens per pipeline step
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// LDS reads are inline asm on purpose: hipcc puts `s_waitcnt vmcnt(0)` in front of any LDS read it
+// can see while an LDS-DMA is outstanding, which would drain the prefetched next stage (programming
+// guide §5 "Pipelining across barriers", §5.7).  Waits are therefore placed by hand: vmcnt(N) counts
+// the DMA instructions issued after the stage being read; the lgkmcnt wait names every destination
+// register as "+v" so no consumer can be scheduled above it.
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+// 8 row reads (two sub-tiles x four k-steps) AND their wait in ONE statement: a compiler-inserted
+// copy of a destination register can then only happen after the data has landed (a copy placed
+// between a bare asm ds_read and a later wait statement reads stale registers — seen on hardware).
+template <int IMM0, int IMM1>
+__device__ __forceinline__ void lds_read_rows8(const uint32_t (&addr)[4], u32x4_t (&r0)[4], u32x4_t (&r1)[4]) {
+  asm volatile(
+      "ds_read_b128 %0, %8 offset:%12\n\t"
+      "ds_read_b128 %4, %8 offset:%13\n\t"
+      "ds_read_b128 %1, %9 offset:%12\n\t"
+      "ds_read_b128 %5, %9 offset:%13\n\t"
+      "ds_read_b128 %2, %10 offset:%12\n\t"
+      "ds_read_b128 %6, %10 offset:%13\n\t"
+      "ds_read_b128 %3, %11 offset:%12\n\t"
+      "ds_read_b128 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0[0]), "=&v"(r0[1]), "=&v"(r0[2]), "=&v"(r0[3]), "=&v"(r1[0]), "=&v"(r1[1]), "=&v"(r1[2]),
+        "=&v"(r1[3])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(IMM0), "i"(IMM1)
+      : "memory");
+}
+// 8 transposed reads (four d-tiles x two sub-tiles) and their wait in one statement.
+template <int IMM0, int IMM1>
+__device__ __forceinline__ void lds_read_tr8(const uint32_t* addr, u32x2_t (&a0)[4], u32x2_t (&a1)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0[0]), "=&v"(a0[1]), "=&v"(a0[2]), "=&v"(a0[3]), "=&v"(a1[0]), "=&v"(a1[1]), "=&v"(a1[2]),
+        "=&v"(a1[3])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(IMM0), "i"(IMM1)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// 16-B chunk swizzle of a [rows][256 B] image that serves row reads (ds_read_b128) and transposed
+// reads (ds_read_b64_tr_b16) alike: programming guide T10 image (b).
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// AUX = cache-policy bits of the DMA loads (0 = default, 2 = nt: K/V bytes are read exactly once).
+template <typename Tag, int AUX>
+__global__ __launch_bounds__(64) void decode_mfma_kernel(const DecodeParams p, const int gh) {
+  using E = Elem<Tag>;
+  constexpr int HD = 128;
+  constexpr int ROWB = HD * 2;        // bytes per token row of one head
+  constexpr int KS = HD / 32;         // k-steps of QK^T
+  constexpr int NT = HD / 16;         // 16-dim tiles of O^T
+  constexpr int RPI = 1024 / ROWB;    // rows per DMA wave-instruction (4)
+  constexpr int IPS = 16 / RPI;       // DMA instructions per 16-row sub-tile (4)
+  constexpr int IMG = kStep * ROWB;   // one K or V image of a stage (8 KiB)
+  constexpr int STAGE = 2 * IMG;      // K image + V image
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+  const int lane = threadIdx.x;
+  const int wave = blockIdx.x;
+  const int part = wave % p.num_parts;
+  const int hw = (wave / p.num_parts) % (p.num_q_heads / gh);
+  const int seq = wave / (p.num_parts * (p.num_q_heads / gh));
+  const int qh0 = hw * gh;
+  const int kvh = qh0 / p.kv_group;
+
+  const int h = lane & 15;   // query head column / token row of a fragment
+  const int g = lane >> 4;   // k-chunk / token group
+
+  const int seq_len = p.seq_lens[seq];
+  const int steps_total = (seq_len + kStep - 1) / kStep;
+  const int part_steps = p.part_tiles / 2;  // part_tiles counts 16-token tiles
+  const int t_begin = part * part_steps;
+  const int t_end = min(t_begin + part_steps, steps_total);
+  const bool direct = p.num_parts == 1;
+  const bool head_ok = h < gh;
+
+  uint16_t* const out16 = reinterpret_cast<uint16_t*>(p.out);
+  float* const out32 = reinterpret_cast<float*>(p.out);
+
+  if (t_begin >= t_end) {
+    if (direct && head_ok) {  // seq_len == 0: zeros
+      const int64_t o = (int64_t)seq * p.out_stride + (int64_t)(qh0 + h) * HD;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (p.out_f32) out32[o + 16 * n + 4 * g + r] = 0.f; else out16[o + 16 * n + 4 * g + r] = 0;
+        }
+    }
+    return;
+  }
+
+  const int32_t* const bt_row = p.block_table + (int64_t)seq * p.block_table_stride;
+  const int bs_mask = (1 << p.bs_log2) - 1;
+  const int last_blk = (seq_len - 1) >> p.bs_log2;
+  const int limit = min(seq_len, t_end * kStep);
+  const int first_blk = (t_begin * kStep) >> p.bs_log2;
+  const int win_ids = bt_row[min(first_blk + lane, last_blk)];  // partition <= 64 blocks (host)
+
+  // ---- Q^T fragments (B operand): lane (head h, dims 32s + 8g ..) ------------------------
+  uint4 qf[KS];
+  {
+    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)seq * p.q_stride +
+                         (int64_t)(qh0 + (head_ok ? h : 0)) * HD + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      qf[s] = head_ok ? *reinterpret_cast<const uint4*>(qb + 32 * s) : make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- per-lane constants -------------------------------------------------------------
+  // DMA source: instruction ii of a sub-tile moves rows 4*ii + (lane>>4); lane position pc = lane&15
+  // of the LDS row holds logical chunk pc ^ swz(row); swz(row) = (((lane>>4)&3)<<2) | (ii&3).
+  uint32_t src_off[IPS];
+#pragma unroll
+  for (int ii = 0; ii < IPS; ++ii) {
+    const int c = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (ii & 3));
+    src_off[ii] = (uint32_t)(((int64_t)(lane >> 4) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
+  }
+  // K row read (A operand of QK^T): row h (+16 j), logical chunk 4s + g
+  const int sw_h = swz(h);
+  uint32_t k_rd[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(h * ROWB + (((4 * s + g) ^ sw_h) * 16));
+  // V transposed read (A operand of PV): group g, lane i = 4q + pp supplies row 4g + q (+16 j),
+  // dims 16n + 4pp .. +3  -> logical chunk 2n + (pp>>1), 8 B half (pp&1)
+  const int q4 = (lane & 15) >> 2, pp = lane & 3;
+  const int v_row = 4 * g + q4;
+  const int sw_v = swz(v_row);
+  uint32_t v_rd[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+    v_rd[n] = (uint32_t)(IMG + v_row * ROWB + (((2 * n + (pp >> 1)) ^ sw_v) * 16) + 8 * (pp & 1));
+
+  const char* const kbase_b = reinterpret_cast<const char*>(p.k_cache);
+  const char* const vbase_b = reinterpret_cast<const char*>(p.v_cache);
+
+  // DMA groups: 8 wave-instructions fill the K image, 8 the V image of stage `st` with the 32
+  // tokens of step t.  They are issued separately so each image is refilled as soon as its reads
+  // have retired (rolling ring: ~3 of a wave's 4 images are in flight at any time).
+  auto issue_k = [&](int t, int st) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tok0 = t * kStep + 16 * j;
+      const int blk = min(tok0 >> p.bs_log2, last_blk);
+      const int phys = __builtin_amdgcn_readlane(win_ids, blk - first_blk);
+      const int64_t base = ((int64_t)phys * p.blk_stride + (int64_t)(tok0 & bs_mask) * p.tok_stride) * 2;
+#pragma unroll
+      for (int ii = 0; ii < IPS; ++ii) {
+        const int64_t rowb = base + (int64_t)(RPI * ii) * p.tok_stride * 2;
+        char* kdst = smem + st * STAGE + (16 * j + RPI * ii) * ROWB;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase_b + rowb + src_off[ii]), (lds_void*)kdst, 16, 0, AUX);
+      }
+    }
+  };
+  auto issue_v = [&](int t, int st) {
+    const bool vtail = (t + 1) * kStep > limit;  // some V rows are past `limit` (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tok0 = t * kStep + 16 * j;
+#pragma unroll
+      for (int ii = 0; ii < IPS; ++ii) {
+        char* vdst = smem + st * STAGE + IMG + (16 * j + RPI * ii) * ROWB;
+        if (!vtail) {
+          const int blk = min(tok0 >> p.bs_log2, last_blk);
+          const int phys = __builtin_amdgcn_readlane(win_ids, blk - first_blk);
+          const int64_t rowb = ((int64_t)phys * p.blk_stride +
+                                (int64_t)((tok0 & bs_mask) + RPI * ii) * p.tok_stride) * 2;
+          __builtin_amdgcn_global_load_lds((gbl_void*)(vbase_b + rowb + src_off[ii]), (lds_void*)vdst, 16, 0, AUX);
+        } else {
+          // rows at or past `limit` take the bytes of row limit-1 instead: their probability is
+          // exactly 0, and 0 * (finite) stays 0 where 0 * (stale NaN/Inf) would not
+          const int tok = min(tok0 + RPI * ii + (lane >> 4), limit - 1);     // per lane
+          const int blk_u = min(tok0 + RPI * ii, limit - 1) >> p.bs_log2;     // wave-uniform
+          const int phys = __builtin_amdgcn_readlane(win_ids, blk_u - first_blk);
+          const int c = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (ii & 3));
+          const int64_t src = ((int64_t)phys * p.blk_stride + (int64_t)(tok & bs_mask) * p.tok_stride +
+                               (int64_t)kvh * p.head_stride) * 2 + c * 16;
+          __builtin_amdgcn_global_load_lds((gbl_void*)(vbase_b + src), (lds_void*)vdst, 16, 0, AUX);
+        }
+      }
+    }
+  };
+  constexpr int kGrp = 2 * IPS;  // DMA wave-instructions per image (8)
+  // vmcnt bookkeeping.  The only vector-memory operations in flight are DMA groups, retired in
+  // issue order:  K0 V0 K1 V1 | K2 (after QK 0)  V2 (after PV 0) | K3 V3 | ...
+  // so "image X has landed" == vmcnt(number of instructions issued after X's group).
+  auto wait_groups = [&](int groups) {  // wave-uniform
+    if (groups >= 3) wait_vmcnt<3 * kGrp>();
+    else if (groups == 2) wait_vmcnt<2 * kGrp>();
+    else if (groups == 1) wait_vmcnt<kGrp>();
+    else wait_vmcnt<0>();
+  };
+
+  float m = -3.0e38f, l = 0.f;
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int t, auto stc) {
+    constexpr int ST = decltype(stc)::value;
+    constexpr int SB = ST * STAGE;
+    const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
+    // K(t) landed?  issued after it: V(t), and K(t+1) V(t+1) when step t+1 exists
+    wait_groups(1 + (has1 ? 2 : 0));
+    // ---- S^T = K . Q^T for the two 16-token sub-tiles -------------------------------------
+    static_assert(KS == 4, "lds_read_rows8 reads four k-steps");
+    u32x4_t k0[KS], k1[KS];
+    lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
+    if (has2) issue_k(t + 2, ST);  // K image of this stage is free again: refill it now
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      s0 = mfma16<Tag>(__builtin_bit_cast(uint4, k0[s]), qf[s], s0);
+      s1 = mfma16<Tag>(__builtin_bit_cast(uint4, k1[s]), qf[s], s1);
+    }
+    // lane: head h, tokens t*32 + 4g + r (s0[r]) and t*32 + 16 + 4g + r (s1[r])
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = s0[r] * p.scale_log2e;
+      v[4 + r] = s1[r] * p.scale_log2e;
+    }
+    if ((t + 1) * kStep > limit) {
+      const int tb = t * kStep + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (tb + r >= limit) v[r] = -INFINITY;
+        if (tb + 16 + r >= limit) v[4 + r] = -INFINITY;
+      }
+    }
+    float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    if (__any(m_new != m)) {
+      const float alpha = fast_exp2(m - m_new);
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] *= alpha;
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = fast_exp2(v[i] - m);
+      ls += v[i];
+    }
+    l += ls;
+    // P^T fragment (B operand): k-slot (g, jj): jj < 4 -> token 4g+jj of sub-tile 0, else sub-tile 1
+    uint4 pb;
+    pb.x = E::pack(v[0], v[1]);
+    pb.y = E::pack(v[2], v[3]);
+    pb.z = E::pack(v[4], v[5]);
+    pb.w = E::pack(v[6], v[7]);
+    // V(t) landed?  issued after it: K(t+1) V(t+1) when step t+1 exists, K(t+2) when step t+2 does
+    wait_groups((has1 ? 2 : 0) + (has2 ? 1 : 0));
+    // ---- O^T[n] += V^T[n] . P^T, four d-tiles (8 transposed reads) per wait -------------------
+#pragma unroll
+    for (int nb = 0; nb < NT; nb += 4) {
+      u32x2_t a0[4], a1[4];
+      lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[nb], a0, a1);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        uint4 vf;
+        vf.x = a0[n][0]; vf.y = a0[n][1]; vf.z = a1[n][0]; vf.w = a1[n][1];
+        acc[nb + n] = mfma16<Tag>(vf, pb, acc[nb + n]);
+      }
+    }
+    if (has2) issue_v(t + 2, ST);  // every read of this stage's V image has retired
+  };
+
+  // ---- pipeline: stage t+1 streams in while stage t is consumed ------------------------------
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  issue_k(t_begin, 0);
+  issue_v(t_begin, 0);
+  if (t_begin + 1 < t_end) {
+    issue_k(t_begin + 1, 1);
+    issue_v(t_begin + 1, 1);
+  }
+  for (int t = t_begin; t < t_end; t += 2) {
+    compute(t, S0{});
+    if (t + 1 < t_end) compute(t + 1, S1{});
+  }
+  // the last step waited with vmcnt(0): no DMA can land in this workgroup's LDS after it exits
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (!head_ok) return;
+  if (direct) {
+    const float inv = 1.f / l;
+    const int64_t o = (int64_t)seq * p.out_stride + (int64_t)(qh0 + h) * HD + 4 * g;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (p.out_f32) {
+        *reinterpret_cast<float4*>(out32 + o + 16 * n) =
+            make_float4(acc[n][0] * inv, acc[n][1] * inv, acc[n][2] * inv, acc[n][3] * inv);
+      } else {
+        uint2 r;
+        r.x = E::pack(acc[n][0] * inv, acc[n][1] * inv);
+        r.y = E::pack(acc[n][2] * inv, acc[n][3] * inv);
+        *reinterpret_cast<uint2*>(out16 + o + 16 * n) = r;
+      }
+    }
+  } else {
+    const int64_t slot = ((int64_t)seq * p.num_q_heads + (qh0 + h)) * p.num_parts + part;
+    float* po = p.part_o + slot * HD + 4 * g;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      *reinterpret_cast<float4*>(po + 16 * n) = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+    if (g == 0) *reinterpret_cast<float2*>(p.part_ml + slot * 2) = make_float2(m, l);
+  }
+}
+
+}  // namespace
+
+// Launch the MFMA decode kernel.  Caller guarantees: head_dim == 128, block_size >= 16,
+// partition a multiple of 32 tokens and <= 64 blocks.
+int launch_decode_mfma(const DecodeParams& p, int gh, int dtype, bool nt, hipStream_t stream) {
+  const int64_t waves = (int64_t)p.num_seqs * (p.num_q_heads / gh) * p.num_parts;
+  if (waves > INT32_MAX) return MI_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)waves), block(64);
+  if (dtype == MI_DTYPE_BF16) {
+    if (nt) hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 2>), grid, block, 0, stream, p, gh);
+    else hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 0>), grid, block, 0, stream, p, gh);
+  } else {
+    if (nt) hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 2>), grid, block, 0, stream, p, gh);
+    else hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 0>), grid, block, 0, stream, p, gh);
+  }
+  return launch_status();
+}
+
+}  // namespace mi

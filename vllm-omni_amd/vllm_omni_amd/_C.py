@@ -17,6 +17,8 @@ MI_ERR_INVALID_ARG, MI_ERR_UNSUPPORTED, MI_ERR_WORKSPACE = -1, -2, -3
 MI_ERR_LAUNCH, MI_ERR_EXHAUSTED, MI_ERR_STATE = -4, -5, -6
 ABI_VERSION = 1
 MI_DECODE_PACKED_PV = 1
+MI_DECODE_FORCE_VALU = 2
+MI_DECODE_NONTEMPORAL = 4
 
 # name -> (restype, argtypes); mirrors include/vllm_omni_amd.h declaration by declaration
 _P = c_void_p

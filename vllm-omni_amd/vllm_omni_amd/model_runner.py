@@ -130,7 +130,7 @@ class ExecuteModelState:
 class GPUARModelRunner:
     def __init__(self, config: TalkerConfig, device: torch.device, dtype: torch.dtype = torch.bfloat16,
                  max_num_reqs: int = 256, max_model_len: int = 4096, max_num_batched_tokens: int = 8192,
-                 block_size: int = 16, kv_layout: str = "NB2", enforce_eager: bool = False,
+                 block_size: int = 16, kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: bool = False,
                  engine_output_type: str = "latent", max_reply_rows: int = 0, seed: Optional[int] = 0):
         from .distributed import get_parallel_state
 

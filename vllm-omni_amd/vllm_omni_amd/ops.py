@@ -109,8 +109,11 @@ def rope_neox_and_cache(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tens
 
 
 # --------------------------------------------------------------------------- A5
-# Default P.V contraction mode of the decode kernel (see include/vllm_omni_amd.h, flags).
-DECODE_PACKED_PV = False
+# Default decode mode (see include/vllm_omni_amd.h, flags): True = P may be rounded to the cache dtype
+# before P.V, as the reference's TRITON_ATTN kernel does -> matrix-core kernel where built (head_dim 128,
+# block >= 16), dot2 VALU kernel elsewhere.  False = exact mode (P kept fp32, VALU kernel).
+DECODE_PACKED_PV = True
+DECODE_NONTEMPORAL = True   # nt cache policy on the K/V stream: +8 % measured (profiles/)
 
 
 def decode_auto_partition(num_seqs: int, num_kv_heads: int, max_seq_len: int, block_size: int = 16,
@@ -129,13 +132,15 @@ def decode_workspace_bytes(num_seqs: int, num_q_heads: int, head_dim: int, max_s
 def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                       block_table: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, scale: float,
                       partition_size: int = 0, workspace: Optional[torch.Tensor] = None,
-                      packed_pv: Optional[bool] = None) -> torch.Tensor:
+                      packed_pv: Optional[bool] = None, force_valu: bool = False,
+                      nontemporal: Optional[bool] = None) -> torch.Tensor:
     """out[s, h] = softmax(q[s,h] . K^T * scale) . V over the paged cache (one query per sequence).
 
     q, out: [S, nq*d] (or [S, nq, d]); block_table int32 [S, max_blocks]; seq_lens int32 [S].
     ``max_seq_len`` is a host-side upper bound of seq_lens (sizes the launch).
-    ``out`` may be fp32 for parity measurement.  ``packed_pv``: round P to the cache dtype and
-    use dot2 for P.V (None = module default ``DECODE_PACKED_PV``).  Returns ``out``.
+    ``out`` may be fp32 for parity measurement.  ``packed_pv`` (None = module default
+    ``DECODE_PACKED_PV``): allow P rounded to the cache dtype (MFMA kernel / dot2 form);
+    ``force_valu`` keeps the VALU kernel.  Returns ``out``.
     """
     _gpu(out, q, k_cache, v_cache, block_table, seq_lens, workspace)
     nb, bs, hkv, d = k_cache.shape
@@ -158,7 +163,10 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
         int(partition_size), _p(workspace),
         workspace.numel() * workspace.element_size() if workspace is not None else 0,
         _dt(q.dtype), _dt(out.dtype),
-        _C.MI_DECODE_PACKED_PV if (DECODE_PACKED_PV if packed_pv is None else packed_pv) else 0, _stream()))
+        (_C.MI_DECODE_PACKED_PV if (DECODE_PACKED_PV if packed_pv is None else packed_pv) else 0)
+        | (_C.MI_DECODE_FORCE_VALU if force_valu else 0)
+        | (_C.MI_DECODE_NONTEMPORAL if (DECODE_NONTEMPORAL if nontemporal is None else nontemporal) else 0),
+        _stream()))
     return out
 
 

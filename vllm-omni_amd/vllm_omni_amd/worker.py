@@ -32,7 +32,7 @@ class WorkerConfig:
     max_num_batched_tokens: int = 32768
     enforce_eager: bool = False
     engine_output_type: str = "latent"
-    kv_layout: str = "NB2"
+    kv_layout: str = "NB2_HEAD_MAJOR"
     device_type: str = "cuda"
     distributed_backend: str = "nccl"
     seed: int = 0
