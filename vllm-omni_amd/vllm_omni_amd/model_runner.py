@@ -182,6 +182,10 @@ class GPUARModelRunner:
 
     # -------------------------------------------------------------------- model
     def load_model(self) -> None:
+        if torch.device(self.device).type == "cuda":
+            from .tuned import enable_tuned_gemms
+
+            self.tuned_gemms = enable_tuned_gemms()
         self.model = Qwen2_5OmniTalkerForConditionalGeneration(self.config, self.dtype, self.device, self.seed)
         if self.max_reply_rows:
             self._reply_pool = torch.zeros(self.max_reply_rows, self.config.embedding_size, dtype=self.dtype,
