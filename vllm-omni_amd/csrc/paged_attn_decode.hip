@@ -420,7 +420,7 @@ extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t
   // Want enough waves to fill 256 CUs x 8-12 resident waves a few times over, but
   // partitions long enough (>= 128 tokens) that the per-wave prologue/merge is noise.
   if (num_seqs <= 0 || num_kv_heads <= 0 || max_seq_len <= 0) return 128;
-  const int64_t target_waves = 8192;
+  const int64_t target_waves = 4096;
   const int64_t pairs = (int64_t)num_seqs * num_kv_heads;
   int32_t best = 128;
   for (int32_t ps = 128; ps <= 16384; ps *= 2) {
