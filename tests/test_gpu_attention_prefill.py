@@ -1,0 +1,109 @@
+"""GPU parity: paged-attention prefill / chunked prefill vs the CPU oracle, through
+the C ABI.  The MFMA kernel rounds P to the cache dtype before P.V (as flash kernels incl. the
+reference's TRITON_ATTN backend do), so the bound vs the fp32 oracle is rtol 1e-3 + atol 6e-3 (bf16) /
+1e-3 (f16) on outputs with |out| <= max|V| ~ 4; the 16-bit output rounding adds 2^-9 / 2^-12 relative.
+"""
+import pytest
+import torch
+
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(dev, nq, nkv, bs, ctxs, chunks, dtype, seed=0, d=128):
+    """ctxs[i] tokens already cached + chunks[i] new query tokens per sequence."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(seed)
+    S = len(ctxs)
+    lens = [c + q for c, q in zip(ctxs, chunks)]
+    max_blocks = max(1, max((n + bs - 1) // bs for n in lens))
+    nb = S * max_blocks + 5
+    kv = torch.randn(nb, 2, bs, nkv, d, generator=g).to(dtype)
+    table = (torch.randperm(nb - 1, generator=g)[: S * max_blocks] + 1).view(S, max_blocks).to(torch.int32)
+    T = sum(chunks)
+    q = torch.randn(T, nq, d, generator=g).to(dtype)
+    qsl = torch.tensor([0] + list(torch.tensor(chunks).cumsum(0)), dtype=torch.int32)
+    seq_lens = torch.tensor(lens, dtype=torch.int32)
+    ref = ref_ops.paged_attention_prefill(q, kv[:, 0], kv[:, 1], table, seq_lens, qsl, d ** -0.5)
+    kvg = kv.to(dev)
+    out = torch.full((T, nq * d), float("nan"), dtype=dtype, device=dev)
+    ops.paged_attn_prefill(out, q.view(T, -1).to(dev), kvg[:, 0], kvg[:, 1], table.to(dev), seq_lens.to(dev),
+                           qsl.to(dev), max(chunks), d ** -0.5)
+    torch.cuda.synchronize()
+    return out.cpu().float().view(T, nq, d), ref
+
+
+CASES = [
+    # nq, nkv, bs, ctxs, chunks
+    (8, 2, 16, [0], [19]),                       # plain prefill, ragged tile
+    (8, 2, 16, [19], [13]),                      # chunked prefill with context (SURVEY §8c iii)
+    (8, 2, 16, [40, 5, 19], [1, 1, 13]),         # two decodes + one prefill chunk in one call
+    (28, 4, 16, [0, 7], [16, 17]),               # S-A head geometry, tile-boundary lengths
+    (7, 1, 16, [100], [33]),                     # S-A at TP=4
+    (4, 4, 32, [3], [70]),                       # MHA, block 32
+    (32, 2, 16, [10], [20]),                     # GQA group 16 -> two workgroups of 8 heads
+    (28, 4, 16, [500], [300]),                   # long context, many steps
+    (12, 2, 16, [0, 0, 0], [1, 15, 64]),         # G = 6, varlen
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CASES)
+def test_prefill_matches_oracle(dev, case, dtype):
+    nq, nkv, bs, ctxs, chunks = case
+    got, ref = _case(dev, nq, nkv, bs, ctxs, chunks, dtype)
+    assert torch.isfinite(got).all()
+    atol = 8e-3 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol)
+
+
+def test_prefill_equals_decode_for_single_token_chunks(dev):
+    """q_len == 1 everywhere: the prefill kernel must agree with the decode kernel (same P rounding)."""
+    from vllm_omni_amd import ops
+
+    nq, nkv, bs, d = 28, 4, 16, 128
+    ctxs, chunks = [31, 64, 200], [1, 1, 1]
+    got, ref = _case(dev, nq, nkv, bs, ctxs, chunks, torch.bfloat16, seed=4)
+    torch.testing.assert_close(got, ref, rtol=4e-3, atol=8e-3)
+
+
+def test_prefill_causality(dev):
+    """Changing K/V rows a query may not see must not change that query's output (bit-exact)."""
+    from vllm_omni_amd import ops
+
+    nq, nkv, bs, d, L = 8, 2, 16, 128, 40
+    g = torch.Generator().manual_seed(7)
+    nb = 8
+    kv = torch.randn(nb, 2, bs, nkv, d, generator=g).to(torch.bfloat16)
+    table = torch.tensor([[3, 1, 5]], dtype=torch.int32)
+    q = torch.randn(L, nq * d, generator=g).to(torch.bfloat16)
+    args = (table.to(dev), torch.tensor([L], dtype=torch.int32, device=dev),
+            torch.tensor([0, L], dtype=torch.int32, device=dev), L, d ** -0.5)
+    outs = []
+    for poison in (False, True):
+        kv2 = kv.clone()
+        if poison:  # rows 24.. of the sequence (block 1 offset 8.., block 5) -> only queries >= 24 may change
+            kv2[1, :, 8:] = 7.0
+            kv2[5] = float("nan")  # beyond L=40 -> rows 40..47 of block 5 and never-read blocks
+            kv2[5, :, :8] = 3.0    # rows 32..39
+        kvg = kv2.to(dev)
+        out = torch.empty(L, nq * d, dtype=torch.bfloat16, device=dev)
+        ops.paged_attn_prefill(out, q.to(dev), kvg[:, 0], kvg[:, 1], *args)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0][:24], outs[1][:24])
+    assert not torch.equal(outs[0][24:], outs[1][24:])
+    assert torch.isfinite(outs[1].float()).all()
+
+
+def test_prefill_rejects_unsupported(dev):
+    from vllm_omni_amd import _C, ops
+
+    kv = torch.zeros(4, 2, 16, 2, 64, dtype=torch.bfloat16, device=dev)
+    q = torch.zeros(5, 8 * 64, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(_C.MIError) as ei:
+        ops.paged_attn_prefill(torch.empty_like(q), q, kv[:, 0], kv[:, 1], torch.zeros(1, 2, dtype=torch.int32, device=dev),
+                               torch.tensor([5], dtype=torch.int32, device=dev),
+                               torch.tensor([0, 5], dtype=torch.int32, device=dev), 5, 1.0)
+    assert ei.value.code == _C.MI_ERR_UNSUPPORTED   # head_dim 64 is not built for the MFMA kernels yet

@@ -1,0 +1,91 @@
+// Shared pieces of the matrix-core attention kernels (decode + prefill): MFMA wrappers, the
+// swizzled [rows][256 B] LDS image, inline-asm LDS reads with their waits, counted vmcnt waits.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace mi {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+template <typename Tag>
+__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mfma16<bf16_tag>(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma16<f16_tag>(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int kStep = 32;  // tokens per pipeline step
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// LDS reads are inline asm on purpose: hipcc puts `s_waitcnt vmcnt(0)` in front of any LDS read it
+// can see while an LDS-DMA is outstanding, which would drain the prefetched next stage (programming
+// guide §5 "Pipelining across barriers", §5.7).  Waits are therefore placed by hand: vmcnt(N) counts
+// the DMA instructions issued after the stage being read; the lgkmcnt wait names every destination
+// register as "+v" so no consumer can be scheduled above it.
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+// 8 row reads (two sub-tiles x four k-steps) AND their wait in ONE statement: a compiler-inserted
+// copy of a destination register can then only happen after the data has landed (a copy placed
+// between a bare asm ds_read and a later wait statement reads stale registers — seen on hardware).
+template <int IMM0, int IMM1>
+__device__ __forceinline__ void lds_read_rows8(const uint32_t (&addr)[4], u32x4_t (&r0)[4], u32x4_t (&r1)[4]) {
+  asm volatile(
+      "ds_read_b128 %0, %8 offset:%12\n\t"
+      "ds_read_b128 %4, %8 offset:%13\n\t"
+      "ds_read_b128 %1, %9 offset:%12\n\t"
+      "ds_read_b128 %5, %9 offset:%13\n\t"
+      "ds_read_b128 %2, %10 offset:%12\n\t"
+      "ds_read_b128 %6, %10 offset:%13\n\t"
+      "ds_read_b128 %3, %11 offset:%12\n\t"
+      "ds_read_b128 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0[0]), "=&v"(r0[1]), "=&v"(r0[2]), "=&v"(r0[3]), "=&v"(r1[0]), "=&v"(r1[1]), "=&v"(r1[2]),
+        "=&v"(r1[3])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(IMM0), "i"(IMM1)
+      : "memory");
+}
+// 8 transposed reads (four d-tiles x two sub-tiles) and their wait in one statement.
+template <int IMM0, int IMM1>
+__device__ __forceinline__ void lds_read_tr8(const uint32_t* addr, u32x2_t (&a0)[4], u32x2_t (&a1)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0[0]), "=&v"(a0[1]), "=&v"(a0[2]), "=&v"(a0[3]), "=&v"(a1[0]), "=&v"(a1[1]), "=&v"(a1[2]),
+        "=&v"(a1[3])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(IMM0), "i"(IMM1)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// 16-B chunk swizzle of a [rows][256 B] image that serves row reads (ds_read_b128) and transposed
+// reads (ds_read_b64_tr_b16) alike: programming guide T10 image (b).
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+
+}  // namespace
+}  // namespace mi
