@@ -154,3 +154,117 @@ def test_finished_requests_are_removed_and_kv_extracted(dev):
     # r1 was not scheduled in that step: it leaves the persistent batch but keeps its cached state
     # (vllm_omni/worker/gpu_model_runner.py:282-301); r0 is gone for good
     assert runner.input_batch.req_ids == [] and "r1" in runner.requests and "r0" not in runner.requests
+
+
+def test_prefill_then_mixed_batch_matches_oracle(dev):
+    """Step 0: two prompts prefilled from embeddings.  Step 1: both decode while a third request
+    prefills (mixed batch: the runner reorders decodes first).  Hidden states of every scheduled
+    token and the greedy ids are compared with the oracle step."""
+    from vllm_omni_amd.kv_cache import KVCacheManager
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, Request, SamplingParams, SchedulerOutput
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_talker")
+    cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.mrope_section = 128, 4, 2, None
+    bs, nb = 16, 32
+    runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=4, max_model_len=128, max_num_batched_tokens=64,
+                              block_size=bs, enforce_eager=True, seed=0)
+    runner.load_model()
+    w = ref_talker.random_weights(cfg, seed=11)
+    runner.model.load_weights({k: v.to(dev) for k, v in w.items()})
+    runner.initialize_kv_cache(nb)
+    cpu_caches = [(torch.zeros(nb, bs, cfg.num_key_value_heads, cfg.head_dim, dtype=torch.bfloat16),
+                   torch.zeros(nb, bs, cfg.num_key_value_heads, cfg.head_dim, dtype=torch.bfloat16))
+                  for _ in range(cfg.num_hidden_layers)]
+    mgr = KVCacheManager(nb, bs)
+    g = torch.Generator().manual_seed(21)
+    csc = ref_ops.build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
+
+    def new_req(rid, n):
+        r = Request(rid, list(range(1, n + 1)), SamplingParams(temperature=0.0),
+                    prompt_embeds=(torch.randn(n, cfg.embedding_size, generator=g) * 0.5).to(torch.bfloat16))
+        assert mgr.allocate_slots(r, n) is not None
+        return r
+
+    def oracle(reqs_in_order, emb_rows, positions, num_sched):
+        B = len(reqs_in_order)
+        table = torch.zeros(B, 8, dtype=torch.int32)
+        for i, r in enumerate(reqs_in_order):
+            ids = mgr.get_block_ids(r.request_id)[0]
+            table[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+        qsl = torch.tensor([0] + list(torch.tensor(num_sched).cumsum(0)), dtype=torch.int32)
+        req_idx = torch.repeat_interleave(torch.arange(B), torch.tensor(num_sched))
+        slots = ref_ops.slot_mapping(table, req_idx, positions, bs)
+        seq_lens = torch.tensor([r.num_computed_tokens + n for r, n in zip(reqs_in_order, num_sched)], dtype=torch.int32)
+        hidden = ref_talker.talker_step(cfg, w, emb_rows, positions, cpu_caches, table, seq_lens, qsl, slots, csc,
+                                        torch.bfloat16)
+        last = hidden[(qsl[1:] - 1).long()]
+        logits, ids = ref_talker.logits_and_greedy(cfg, w, last, None, torch.bfloat16)
+        return hidden, logits, ids, qsl
+
+    # ---- step 0: prefill r0 (20 tokens) and r1 (5 tokens) ----
+    r0, r1 = new_req("r0", 20), new_req("r1", 5)
+    so = SchedulerOutput(scheduled_new_reqs=[
+        NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id), 0,
+                       prompt_embeds=r.prompt_embeds) for r in (r0, r1)],
+        num_scheduled_tokens={"r0": 20, "r1": 5}, total_num_scheduled_tokens=25)
+    assert runner.execute_model(so) is None
+    out = runner.sample_tokens()
+    order = [runner.requests[rid] for rid in out.req_ids]
+    reqs = {"r0": r0, "r1": r1}
+    seq = [reqs[rid] for rid in out.req_ids]
+    ns = [len(r.prompt_token_ids) for r in seq]
+    emb = torch.cat([r.prompt_embeds for r in seq])
+    pos = torch.cat([torch.arange(n) for n in ns])
+    hidden, logits, ids, qsl = oracle(seq, emb, pos, ns)
+    got = torch.cat([out.pooler_output[i]["hidden"] for i in range(len(seq))]).float()
+    torch.testing.assert_close(got, hidden, rtol=3e-2, atol=3e-2)
+    got_ids = torch.tensor([t[0] for t in out.sampled_token_ids])
+    top2 = logits.topk(2, -1).values
+    conf = (top2[:, 0] - top2[:, 1]) > 0.05
+    assert torch.equal(got_ids[conf], ids[conf])
+    for r, n, t in zip(seq, ns, got_ids.tolist()):
+        r.num_computed_tokens = n
+        r.output_token_ids.append(t)
+
+    # ---- step 1: r0, r1 decode; r2 (17 tokens) prefills ----
+    r2 = new_req("r2", 17)
+    reqs["r2"] = r2
+    for r in (r0, r1):
+        assert mgr.allocate_slots(r, 1) is not None
+    so = SchedulerOutput(
+        scheduled_new_reqs=[NewRequestData("r2", r2.prompt_token_ids, r2.sampling_params, mgr.get_block_ids("r2"), 0,
+                                           prompt_embeds=r2.prompt_embeds)],
+        scheduled_cached_reqs=CachedRequestData(req_ids=["r0", "r1"], new_block_ids=[None, None],
+                                                num_computed_tokens=[r0.num_computed_tokens, r1.num_computed_tokens],
+                                                num_output_tokens=[1, 1]),
+        num_scheduled_tokens={"r0": 1, "r1": 1, "r2": 17}, total_num_scheduled_tokens=19)
+    # block tables of r0/r1 may have grown by a block
+    for r in (r0, r1):
+        ids_now = mgr.get_block_ids(r.request_id)[0]
+        row = runner.input_batch.req_id_to_index[r.request_id]
+        have = int(runner.input_batch.block_table[0].num_blocks_per_row[row])
+        if len(ids_now) > have:
+            so.scheduled_cached_reqs.new_block_ids[["r0", "r1"].index(r.request_id)] = (ids_now[have:],)
+    assert runner.execute_model(so) is None
+    out = runner.sample_tokens()
+    seq = [reqs[rid] for rid in out.req_ids]
+    assert [len(reqs[rid].prompt_token_ids) == 17 for rid in out.req_ids] == [False, False, True]  # decodes first
+    ns = [17 if r is r2 else 1 for r in seq]
+    emb_rows, pos_rows = [], []
+    for r, n in zip(seq, ns):
+        if r is r2:
+            emb_rows.append(r.prompt_embeds)
+            pos_rows.append(torch.arange(17))
+        else:
+            emb_rows.append(ref_talker.decode_embeds(w, torch.tensor([r.output_token_ids[-1]]), None, torch.bfloat16))
+            pos_rows.append(torch.tensor([r.num_computed_tokens]))
+    hidden, logits, ids, qsl = oracle(seq, torch.cat(emb_rows).float(), torch.cat(pos_rows), ns)
+    got = torch.cat([out.pooler_output[i]["hidden"] for i in range(len(seq))]).float()
+    assert got.shape == hidden.shape == (19, cfg.hidden_size)
+    torch.testing.assert_close(got, hidden, rtol=3e-2, atol=3e-2)
+    got_ids = torch.tensor([t[0] for t in out.sampled_token_ids])
+    top2 = logits.topk(2, -1).values
+    conf = (top2[:, 0] - top2[:, 1]) > 0.05
+    assert torch.equal(got_ids[conf], ids[conf])
