@@ -201,7 +201,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    dev = torch.device("cuda", local_rank)
+    # rehearsal mode for a 1-GPU box: every rank on cuda:0, collectives over gloo (functional check of
+    # the N>1 code path only; never used by the driver)
+    rehearsal = os.environ.get("MI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        os.environ["VLLM_OMNI_AMD_TP_GRAPH"] = "0"  # gloo collectives are not capturable
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
 
     from vllm_omni_amd import ops
@@ -213,7 +218,8 @@ def main():
     tp, dp, plabel = parallel_plan(world, cfg)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        init_distributed_environment(world, rank, tp, backend="nccl", device=dev)
+        init_distributed_environment(world, rank, tp, backend="gloo" if rehearsal else "nccl",
+                                     device=None if rehearsal else dev)
     if a.batch % dp:
         raise SystemExit("global batch must divide by the data-parallel degree")
     local_batch = a.batch // dp
@@ -284,7 +290,7 @@ def main():
         "dtype": "bf16", "data": "synthetic (random-init weights, N(0,1) KV cache, random non-contiguous block tables, fixed ctx)",
         "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
                    "global_batch": a.batch, "seq_len": a.ctx, "parallelism": plabel,
-                   "hipgraph": bool(not a.eager and tp == 1), "kv_layout": a.kv_layout,
+                   "hipgraph": bool(runner._graphs), "kv_layout": a.kv_layout,
                    "decode_partition": runner._decode_part},
         "roofline": roofline,
     }

@@ -66,7 +66,7 @@ def _worker(rank, world, tp, port, q):
         D.destroy_distributed_environment()
 
 
-@pytest.mark.parametrize("world,tp", [(2, 2), (2, 1)])
+@pytest.mark.parametrize("world,tp", [(2, 2), (2, 1), (4, 2)])
 @pytest.mark.timeout(120)
 def test_tp_sharding_composes_over_gloo(world, tp):
     ctx = mp.get_context("spawn")

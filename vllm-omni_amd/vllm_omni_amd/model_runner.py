@@ -19,6 +19,8 @@ What is restructured for MI355X (SURVEY §3 hot loop 3, §7 "host overhead at bs
 """
 from __future__ import annotations
 
+import os
+import time
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
@@ -153,6 +155,7 @@ class GPUARModelRunner:
         self.execute_model_state: Optional[ExecuteModelState] = None
         self.kv_extracted: dict[str, Any] = {}
         self._graphs: dict[int, tuple[torch.cuda.CUDAGraph, dict]] = {}
+        self._graph_broken = False
         self.max_reply_rows = max_reply_rows
         self._reply_pool: Optional[torch.Tensor] = None
         self._reply_used = 0
@@ -391,8 +394,12 @@ class GPUARModelRunner:
         return hidden, logits, ids
 
     def _can_use_graph(self, n: int, total: int) -> bool:
-        return (not self.enforce_eager and total == n and torch.device(self.device).type == "cuda"
-                and self.parallel.tp_size == 1)
+        """Pure-decode batches replay a hipGraph.  With TP > 1 the graph contains the RCCL
+        all-reduces (torch.distributed collectives are capturable; probed on this stack with
+        tools/probe_rccl_graph.py); VLLM_OMNI_AMD_TP_GRAPH=0 keeps TP > 1 eager."""
+        if self.enforce_eager or total != n or torch.device(self.device).type != "cuda" or self._graph_broken:
+            return False
+        return self.parallel.tp_size == 1 or os.environ.get("VLLM_OMNI_AMD_TP_GRAPH", "1") == "1"
 
     def capture_model(self, batch_sizes: Optional[list[int]] = None) -> None:
         for b in batch_sizes or []:
@@ -410,9 +417,24 @@ class GPUARModelRunner:
                 self._forward(n, n, md)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: another thread's HIP calls (the RCCL watchdog polling events) must not invalidate
+        # the capture.  A capture that does fail leaves a sticky HIP error behind, so it is not caught:
+        # failing loudly beats limping on (VLLM_OMNI_AMD_TP_GRAPH=0 / enforce_eager avoid capture).
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.parallel.tp_size > 1 else "global"):
             self._decode_embeds(n)
             hidden, logits, ids = self._forward(n, n, md)
+        if self.parallel.tp_size > 1:
+            # first replay of a graph with collectives inside: complete it under a watchdog so that a
+            # rank mismatch fails fast instead of hanging the node
+            g.replay()
+            done = torch.cuda.Event()
+            done.record()
+            deadline = time.monotonic() + float(os.environ.get("VLLM_OMNI_AMD_GRAPH_WATCHDOG_S", "60"))
+            while not done.query():
+                if time.monotonic() > deadline:
+                    raise RuntimeError("first replay of the TP hipGraph did not finish within the watchdog "
+                                       "window (set VLLM_OMNI_AMD_TP_GRAPH=0 to run TP eagerly)")
+                time.sleep(0.001)
         self._graphs[n] = (g, {"hidden": hidden, "logits": logits, "ids": ids})
         return self._graphs[n]
 
@@ -432,17 +454,20 @@ class GPUARModelRunner:
         n, total, num_sched, max_seq_len, num_decodes = self._prepare_inputs(scheduler_output)
         use_graph = self._can_use_graph(n, total)
         self._commit_inputs(n, total, total)
+        entry = None
         if use_graph:
             entry = self._graphs.get(n)
-            if entry is None:
-                # first time at this batch size: fill the static inputs once, then capture
-                self._preprocess_host_only(n, num_decodes)
+            self._preprocess_host_only(n, num_decodes)
+            if entry is None:  # first time at this batch size: capture (static inputs are filled)
                 entry = self._capture(n)
-            else:
-                self._preprocess_host_only(n, num_decodes)
+        if use_graph and entry is not None:
             g, outs = entry
             g.replay()
             hidden, logits, ids = outs["hidden"], outs["logits"], outs["ids"]
+        elif use_graph:  # capture failed: the host-side index copies are done, run the step eagerly
+            self._decode_embeds(n)
+            md = self._build_metadata(n, total, 1, max_seq_len, num_decodes)
+            hidden, logits, ids = self._forward(n, total, md)
         else:
             self._preprocess_embeds(n, total, num_sched, num_decodes)
             md = self._build_metadata(n, total, int(num_sched.max()), max_seq_len, num_decodes)
