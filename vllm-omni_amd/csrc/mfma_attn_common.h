@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 template <typename Tag>
 __device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c);
@@ -27,6 +28,22 @@ __device__ __forceinline__ f32x4_t mfma16<f16_tag>(const uint4& a, const uint4& 
                                                 __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
+// K = 16 form: A and B fragments are 4 elements (one 64-bit register pair) per lane, lane l holds
+// k = 4*(l>>4) + j — exactly what one `ds_read_b64_tr_b16` delivers, so a transposed read IS an operand.
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+template <typename Tag>
+__device__ __forceinline__ f32x4_t mfma16_k16(const u32x2_t& a, const u32x2_t& b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mfma16_k16<bf16_tag>(const u32x2_t& a, const u32x2_t& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b),
+                                                   c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma16_k16<f16_tag>(const u32x2_t& a, const u32x2_t& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c,
+                                               0, 0, 0);
+}
+
 constexpr int kStep = 32;  // tokens per pipeline step
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -37,7 +54,6 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // guide §5 "Pipelining across barriers", §5.7).  Waits are therefore placed by hand: vmcnt(N) counts
 // the DMA instructions issued after the stage being read; the lgkmcnt wait names every destination
 // register as "+v" so no consumer can be scheduled above it.
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 // 8 row reads (two sub-tiles x four k-steps) AND their wait in ONE statement: a compiler-inserted
 // copy of a destination register can then only happen after the data has landed (a copy placed

@@ -34,7 +34,7 @@ namespace {
 
 // AUX = cache-policy bits of the DMA loads (0 = default, 2 = nt: K/V bytes are read exactly once).
 template <typename Tag, int AUX>
-__global__ __launch_bounds__(64) void decode_mfma_kernel(const DecodeParams p, const int gh) {
+__global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p, const int gh) {
   using E = Elem<Tag>;
   constexpr int HD = 128;
   constexpr int ROWB = HD * 2;        // bytes per token row of one head
@@ -57,10 +57,17 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const DecodeParams p, c
   const int h = lane & 15;   // query head column / token row of a fragment
   const int g = lane >> 4;   // k-chunk / token group
 
-  const int seq_len = p.seq_lens[seq];
-  const int steps_total = (seq_len + kStep - 1) / kStep;
+  // The block-id window (lane i = i-th block of this partition; the host caps a partition at 64 blocks)
+  // is fetched BEFORE seq_len is known so the two loads overlap: entries past the sequence's last
+  // block are inside the table row (memory-safe) and are never selected (block indices are clamped).
   const int part_steps = p.part_tiles / 2;  // part_tiles counts 16-token tiles
   const int t_begin = part * part_steps;
+  const int first_blk = (t_begin * kStep) >> p.bs_log2;
+  const int32_t* const bt_row = p.block_table + (int64_t)seq * p.block_table_stride;
+  const int win_ids = bt_row[min(first_blk + lane, p.block_table_stride - 1)];
+
+  const int seq_len = p.seq_lens[seq];
+  const int steps_total = (seq_len + kStep - 1) / kStep;
   const int t_end = min(t_begin + part_steps, steps_total);
   const bool direct = p.num_parts == 1;
   const bool head_ok = h < gh;
@@ -81,12 +88,9 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const DecodeParams p, c
     return;
   }
 
-  const int32_t* const bt_row = p.block_table + (int64_t)seq * p.block_table_stride;
   const int bs_mask = (1 << p.bs_log2) - 1;
   const int last_blk = (seq_len - 1) >> p.bs_log2;
   const int limit = min(seq_len, t_end * kStep);
-  const int first_blk = (t_begin * kStep) >> p.bs_log2;
-  const int win_ids = bt_row[min(first_blk + lane, last_blk)];  // partition <= 64 blocks (host)
 
   // ---- Q^T fragments (B operand): lane (head h, dims 32s + 8g ..) ------------------------
   uint4 qf[KS];
@@ -128,45 +132,57 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const DecodeParams p, c
   // DMA groups: 8 wave-instructions fill the K image, 8 the V image of stage `st` with the 32
   // tokens of step t.  They are issued separately so each image is refilled as soon as its reads
   // have retired (rolling ring: ~3 of a wave's 4 images are in flight at any time).
+  // Address arithmetic, kept scalar and minimal: ONE 64-bit multiply per 16-row sub-tile (block base),
+  // then the four DMA instructions of the sub-tile step a uniform pointer by 4 rows.
+  const uint64_t blk_bytes = (uint64_t)p.blk_stride * 2;
+  const uint32_t tok_bytes = (uint32_t)p.tok_stride * 2;
+  const uint32_t grp_bytes = RPI * tok_bytes;
+  auto subtile_base = [&](int tok0) -> uint64_t {  // byte offset of token row tok0 (wave-uniform)
+    const int blk = min(tok0 >> p.bs_log2, last_blk);
+    const uint32_t phys = (uint32_t)__builtin_amdgcn_readlane(win_ids, blk - first_blk);
+    return (uint64_t)phys * blk_bytes + (uint32_t)(tok0 & bs_mask) * tok_bytes;
+  };
   auto issue_k = [&](int t, int st) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int tok0 = t * kStep + 16 * j;
-      const int blk = min(tok0 >> p.bs_log2, last_blk);
-      const int phys = __builtin_amdgcn_readlane(win_ids, blk - first_blk);
-      const int64_t base = ((int64_t)phys * p.blk_stride + (int64_t)(tok0 & bs_mask) * p.tok_stride) * 2;
+      const char* src = kbase_b + subtile_base(t * kStep + 16 * j);
 #pragma unroll
       for (int ii = 0; ii < IPS; ++ii) {
-        const int64_t rowb = base + (int64_t)(RPI * ii) * p.tok_stride * 2;
         char* kdst = smem + st * STAGE + (16 * j + RPI * ii) * ROWB;
-        __builtin_amdgcn_global_load_lds((gbl_void*)(kbase_b + rowb + src_off[ii]), (lds_void*)kdst, 16, 0, AUX);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src + src_off[ii]), (lds_void*)kdst, 16, 0, AUX);
+        src += grp_bytes;
       }
     }
   };
   auto issue_v = [&](int t, int st) {
     const bool vtail = (t + 1) * kStep > limit;  // some V rows are past `limit` (wave-uniform)
+    if (!vtail) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int tok0 = t * kStep + 16 * j;
+      for (int j = 0; j < 2; ++j) {
+        const char* src = vbase_b + subtile_base(t * kStep + 16 * j);
 #pragma unroll
-      for (int ii = 0; ii < IPS; ++ii) {
-        char* vdst = smem + st * STAGE + IMG + (16 * j + RPI * ii) * ROWB;
-        if (!vtail) {
-          const int blk = min(tok0 >> p.bs_log2, last_blk);
-          const int phys = __builtin_amdgcn_readlane(win_ids, blk - first_blk);
-          const int64_t rowb = ((int64_t)phys * p.blk_stride +
-                                (int64_t)((tok0 & bs_mask) + RPI * ii) * p.tok_stride) * 2;
-          __builtin_amdgcn_global_load_lds((gbl_void*)(vbase_b + rowb + src_off[ii]), (lds_void*)vdst, 16, 0, AUX);
-        } else {
-          // rows at or past `limit` take the bytes of row limit-1 instead: their probability is
-          // exactly 0, and 0 * (finite) stays 0 where 0 * (stale NaN/Inf) would not
-          const int tok = min(tok0 + RPI * ii + (lane >> 4), limit - 1);     // per lane
-          const int blk_u = min(tok0 + RPI * ii, limit - 1) >> p.bs_log2;     // wave-uniform
-          const int phys = __builtin_amdgcn_readlane(win_ids, blk_u - first_blk);
+        for (int ii = 0; ii < IPS; ++ii) {
+          char* vdst = smem + st * STAGE + IMG + (16 * j + RPI * ii) * ROWB;
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src + src_off[ii]), (lds_void*)vdst, 16, 0, AUX);
+          src += grp_bytes;
+        }
+      }
+    } else {
+      // rows at or past `limit` take the bytes of row limit-1 instead: their probability is exactly
+      // 0, and 0 * (finite) stays 0 where 0 * (stale NaN/Inf) would not.  Once per partition at most.
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+          char* vdst = smem + st * STAGE + IMG + (16 * j + RPI * ii) * ROWB;
+          const int row0 = t * kStep + 16 * j + RPI * ii;
+          const int tok = min(row0 + (lane >> 4), limit - 1);              // per lane
+          const int blk_u = min(row0, limit - 1) >> p.bs_log2;              // wave-uniform
+          const uint32_t phys = (uint32_t)__builtin_amdgcn_readlane(win_ids, blk_u - first_blk);
           const int c = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (ii & 3));
-          const int64_t src = ((int64_t)phys * p.blk_stride + (int64_t)(tok & bs_mask) * p.tok_stride +
-                               (int64_t)kvh * p.head_stride) * 2 + c * 16;
-          __builtin_amdgcn_global_load_lds((gbl_void*)(vbase_b + src), (lds_void*)vdst, 16, 0, AUX);
+          const uint64_t off = (uint64_t)phys * blk_bytes + (uint64_t)((uint32_t)(tok & bs_mask) * tok_bytes) +
+                               (uint64_t)((int64_t)kvh * p.head_stride * 2) + (uint32_t)(c * 16);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(vbase_b + off), (lds_void*)vdst, 16, 0, AUX);
         }
       }
     }
@@ -237,12 +253,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const DecodeParams p, c
       ls += v[i];
     }
     l += ls;
-    // P^T fragment (B operand): k-slot (g, jj): jj < 4 -> token 4g+jj of sub-tile 0, else sub-tile 1
-    uint4 pb;
-    pb.x = E::pack(v[0], v[1]);
-    pb.y = E::pack(v[2], v[3]);
-    pb.z = E::pack(v[4], v[5]);
-    pb.w = E::pack(v[6], v[7]);
+    // P^T fragments (B operand of the K=16 MFMA): lane (head h, tokens 4g+0..3) of each sub-tile —
+    // exactly the four scores the lane already holds
+    const u32x2_t pb0 = {E::pack(v[0], v[1]), E::pack(v[2], v[3])};
+    const u32x2_t pb1 = {E::pack(v[4], v[5]), E::pack(v[6], v[7])};
     // V(t) landed?  issued after it: K(t+1) V(t+1) when step t+1 exists, K(t+2) when step t+2 does
     wait_groups((has1 ? 2 : 0) + (has2 ? 1 : 0));
     // ---- O^T[n] += V^T[n] . P^T, four d-tiles (8 transposed reads) per wait -------------------
@@ -251,10 +265,9 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(const DecodeParams p, c
       u32x2_t a0[4], a1[4];
       lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[nb], a0, a1);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        uint4 vf;
-        vf.x = a0[n][0]; vf.y = a0[n][1]; vf.z = a1[n][0]; vf.w = a1[n][1];
-        acc[nb + n] = mfma16<Tag>(vf, pb, acc[nb + n]);
+      for (int n = 0; n < 4; ++n) {  // one transposed read == one A operand: no register shuffling
+        acc[nb + n] = mfma16_k16<Tag>(a0[n], pb0, acc[nb + n]);
+        acc[nb + n] = mfma16_k16<Tag>(a1[n], pb1, acc[nb + n]);
       }
     }
     if (has2) issue_v(t + 2, ST);  // every read of this stage's V image has retired
