@@ -80,6 +80,8 @@ CASES = [
     (2, 12, 2, 128, 32, [70, 33]),                     # G = 6, block 32
     (2, 32, 2, 128, 16, [18, 47]),                     # G = 16 -> two waves of 8 heads per KV head
     (2, 5, 1, 64, 8, [3, 41]),                         # G = 5, d = 64, block 8
+    (3, 16, 2, 64, 16, [1, 33, 300]),                  # S-B, long enough for several MFMA steps/partitions
+    (2, 2, 1, 64, 32, [257, 64]),                      # S-B at TP=8 (replicated KV head), block 32
 ]
 
 

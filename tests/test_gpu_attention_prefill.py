@@ -11,7 +11,7 @@ from oracle import ref_ops
 pytestmark = pytest.mark.gpu
 
 
-def _case(dev, nq, nkv, bs, ctxs, chunks, dtype, seed=0, d=128):
+def _case(dev, nq, nkv, bs, ctxs, chunks, dtype, seed=0, d=128):  # noqa: D401
     """ctxs[i] tokens already cached + chunks[i] new query tokens per sequence."""
     from vllm_omni_amd import ops
 
@@ -47,6 +47,12 @@ CASES = [
     (28, 4, 16, [500], [300]),                   # long context, many steps
     (12, 2, 16, [0, 0, 0], [1, 15, 64]),         # G = 6, varlen
 ]
+CASES_D64 = [
+    (16, 2, 16, [0], [19]),                      # S-B head geometry (Qwen3-Omni talker: 16/2 heads, d = 64)
+    (16, 2, 16, [19, 40], [13, 1]),              # chunk with context + a decode row
+    (2, 1, 32, [70], [50]),                      # S-B at TP=8 (KV head replicated), block 32
+    (8, 8, 16, [0, 0], [33, 16]),                # MHA
+]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -54,6 +60,16 @@ CASES = [
 def test_prefill_matches_oracle(dev, case, dtype):
     nq, nkv, bs, ctxs, chunks = case
     got, ref = _case(dev, nq, nkv, bs, ctxs, chunks, dtype)
+    assert torch.isfinite(got).all()
+    atol = 8e-3 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CASES_D64)
+def test_prefill_head_dim_64(dev, case, dtype):
+    nq, nkv, bs, ctxs, chunks = case
+    got, ref = _case(dev, nq, nkv, bs, ctxs, chunks, dtype, d=64)
     assert torch.isfinite(got).all()
     atol = 8e-3 if dtype == torch.bfloat16 else 2e-3
     torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol)
@@ -100,10 +116,10 @@ def test_prefill_causality(dev):
 def test_prefill_rejects_unsupported(dev):
     from vllm_omni_amd import _C, ops
 
-    kv = torch.zeros(4, 2, 16, 2, 64, dtype=torch.bfloat16, device=dev)
-    q = torch.zeros(5, 8 * 64, dtype=torch.bfloat16, device=dev)
+    kv = torch.zeros(4, 2, 16, 2, 32, dtype=torch.bfloat16, device=dev)
+    q = torch.zeros(5, 8 * 32, dtype=torch.bfloat16, device=dev)
     with pytest.raises(_C.MIError) as ei:
         ops.paged_attn_prefill(torch.empty_like(q), q, kv[:, 0], kv[:, 1], torch.zeros(1, 2, dtype=torch.int32, device=dev),
                                torch.tensor([5], dtype=torch.int32, device=dev),
                                torch.tensor([0, 5], dtype=torch.int32, device=dev), 5, 1.0)
-    assert ei.value.code == _C.MI_ERR_UNSUPPORTED   # head_dim 64 is not built for the MFMA kernels yet
+    assert ei.value.code == _C.MI_ERR_UNSUPPORTED   # only head_dim 64 / 128 are built

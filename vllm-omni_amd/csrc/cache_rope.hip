@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_kernel(
     uint16_t* __restrict__ vc, const int64_t* __restrict__ slot_mapping, int num_kv_heads,
     int head_dim, int block_size, int64_t k_tok, int64_t v_tok, int64_t c_blk, int64_t c_tok,
     int64_t c_head) {
+  scalar_cache_acquire();
   const int t = blockIdx.x;
   const int64_t slot = slot_mapping[t];
   if (slot < 0) return;  // padding token
@@ -77,6 +78,7 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 // rotate-half partners [rot/2 + 8j, rot/2 + 8j + 8) of one head.
 template <typename Tag, bool MROPE, bool NORM>
 __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   const int t = blockIdx.x;
   const int HD = p.head_dim;

@@ -100,6 +100,15 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Scalar-cache acquire, first statement of every kernel.  hipcc turns wave-uniform loads of small
+// metadata (seq_lens, block tables, slot mapping, token ids) into SCALAR loads; those buffers are
+// rewritten by host->device copies between launches, and on this stack (gfx950, ROCm 7.x) the scalar
+// data cache was observed to serve stale lines across launches (prefill read a recycled address's
+// old block id: tools/debug_prefill.py).  s_dcache_inv is asynchronous, hence the lgkmcnt wait.
+__device__ __forceinline__ void scalar_cache_acquire() {
+  asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 
 // ---- host-side launch check ---------------------------------------------

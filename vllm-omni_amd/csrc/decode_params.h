@@ -24,7 +24,7 @@ struct DecodeParams {
 };
 
 // paged_attn_decode_mfma.hip
-int launch_decode_mfma(const DecodeParams& p, int heads_per_wave, int dtype, bool nontemporal,
+int launch_decode_mfma(const DecodeParams& p, int heads_per_wave, int head_dim, int dtype, bool nontemporal,
                        hipStream_t stream);
 
 }  // namespace mi

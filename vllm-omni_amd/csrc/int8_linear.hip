@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void dynamic_int8_quant_kernel(int8_t* __restr
                                                                  float* __restrict__ x_scale,
                                                                  const uint16_t* __restrict__ x, int hidden,
                                                                  int64_t x_stride) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   __shared__ float smem[4];
   const int row = blockIdx.x;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void int8_gemm_dequant_kernel(uint16_t* __rest
                                                                 const float* __restrict__ w_scale,
                                                                 const uint16_t* __restrict__ bias, int m, int n,
                                                                 int k, int64_t out_stride) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;

@@ -101,6 +101,29 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 16-B chunk swizzle of a [rows][256 B] image that serves row reads (ds_read_b128) and transposed
 // reads (ds_read_b64_tr_b16) alike: programming guide T10 image (b).
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// Per head_dim: rows of 256 B (16 chunks) use the image above; rows of 128 B (8 chunks, two rows per
+// 256-B bank row) XOR the chunk with the row-pair index, which keeps the 16 row reads of a
+// `ds_read_b128` fragment on distinct 16-B slots.  Any f(row) works for correctness as long as the DMA
+// source and every read apply the same one.
+template <int HD>
+__device__ __forceinline__ int swz_hd(int row) {
+  if constexpr (HD == 128) return swz(row);
+  else return (row >> 1) & 7;
+}
+
+// 4 row reads (two sub-tiles x two k-steps: head_dim 64) and their wait in one statement.
+template <int IMM0, int IMM1>
+__device__ __forceinline__ void lds_read_rows4(const uint32_t (&addr)[2], u32x4_t (&r0)[2], u32x4_t (&r1)[2]) {
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%6\n\t"
+      "ds_read_b128 %2, %4 offset:%7\n\t"
+      "ds_read_b128 %1, %5 offset:%6\n\t"
+      "ds_read_b128 %3, %5 offset:%7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0[0]), "=&v"(r0[1]), "=&v"(r1[0]), "=&v"(r1[1])
+      : "v"(addr[0]), "v"(addr[1]), "i"(IMM0), "i"(IMM1)
+      : "memory");
+}
 
 
 }  // namespace

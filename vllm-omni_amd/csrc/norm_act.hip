@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ ou
                                                        const uint16_t* __restrict__ w, float eps,
                                                        int hidden, int64_t x_stride,
                                                        int64_t out_stride, int64_t r_stride) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   __shared__ float smem[4];
   const int row = blockIdx.x;
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void rms_norm_generic_kernel(uint16_t* out, co
                                                                int hidden, int64_t x_stride,
                                                                int64_t out_stride,
                                                                int64_t r_stride) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   __shared__ float smem[4];
   const int row = blockIdx.x;
@@ -121,6 +123,7 @@ template <typename Tag>
 __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ x, int inter,
                                                        int64_t x_stride, int64_t out_stride) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   const int row = blockIdx.y;
   const uint16_t* g = x + row * x_stride;
@@ -148,6 +151,7 @@ template <typename Tag>
 __global__ __launch_bounds__(256) void silu_mul_scalar_kernel(uint16_t* out, const uint16_t* x,
                                                               int inter, int64_t x_stride,
                                                               int64_t out_stride) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   const int row = blockIdx.y;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < inter; i += gridDim.x * 256) {
@@ -163,6 +167,7 @@ template <int DT>  // MI_DTYPE_*
 __global__ __launch_bounds__(256) void mask_argmax_kernel(void* logits, int64_t* ids, int vocab,
                                                           int64_t row_stride, int lo0, int hi0,
                                                           int lo1, int hi1, int col) {
+  scalar_cache_acquire();
   __shared__ float sv[4];
   __shared__ int si[4];
   const int row = blockIdx.x;
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(256) void talker_embeds_kernel(uint16_t* __restrict
                                                             const int64_t* __restrict__ ridx, int dim,
                                                             int vocab, int64_t nreply,
                                                             int64_t out_stride) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   const int t = blockIdx.x;
   const int64_t id = ids[t];

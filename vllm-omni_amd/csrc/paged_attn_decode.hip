@@ -41,6 +41,7 @@ constexpr float kNegBig = -3.0e38f;
 
 template <typename Tag, int HD, int G, bool PACKED_PV>
 __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   constexpr int LPT = HD / 8;      // lanes per token row
   constexpr int TPL = 64 / LPT;    // token rows per wave-load
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void decode_kernel(const DecodeParams p) {
 // Merge the partitions of one (sequence, q head): one wave per pair.
 template <typename Tag, int HD>
 __global__ __launch_bounds__(64) void decode_reduce_kernel(const DecodeParams p) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
   constexpr int DPL = HD / 64;  // dims per lane
   const int qh = blockIdx.x;
@@ -498,7 +500,7 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   // Kernel choice: with P allowed to be rounded to the cache dtype (MI_DECODE_PACKED_PV) the
   // matrix-core kernel is used wherever it is built; otherwise (or when forced) the VALU kernel.
   const bool use_mfma = (flags & MI_DECODE_PACKED_PV) && !(flags & MI_DECODE_FORCE_VALU) &&
-                        head_dim == 128 && block_size >= 16 && partition_size % 32 == 0;
+                        block_size >= 16 && partition_size % 32 == 0;
   const int G = heads_per_wave(kv_group, use_mfma ? 16 : 8);
 
   DecodeParams p;
@@ -532,7 +534,7 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   const bool packed = (flags & MI_DECODE_PACKED_PV) != 0;
   int rc;
   if (use_mfma) {
-    rc = launch_decode_mfma(p, G, dtype, (flags & MI_DECODE_NONTEMPORAL) != 0, s);
+    rc = launch_decode_mfma(p, G, head_dim, dtype, (flags & MI_DECODE_NONTEMPORAL) != 0, s);
   } else if (dtype == MI_DTYPE_BF16) {
     rc = head_dim == 128 ? dispatch_group<bf16_tag, 128>(p, G, packed, s)
                          : dispatch_group<bf16_tag, 64>(p, G, packed, s);

@@ -33,15 +33,16 @@ namespace mi {
 namespace {
 
 // AUX = cache-policy bits of the DMA loads (0 = default, 2 = nt: K/V bytes are read exactly once).
-template <typename Tag, int AUX>
+template <typename Tag, int HD, int AUX>
 __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p, const int gh) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
-  constexpr int HD = 128;
   constexpr int ROWB = HD * 2;        // bytes per token row of one head
   constexpr int KS = HD / 32;         // k-steps of QK^T
   constexpr int NT = HD / 16;         // 16-dim tiles of O^T
-  constexpr int RPI = 1024 / ROWB;    // rows per DMA wave-instruction (4)
-  constexpr int IPS = 16 / RPI;       // DMA instructions per 16-row sub-tile (4)
+  constexpr int LPR = ROWB / 16;      // lanes (16-B chunks) per row: 16 / 8
+  constexpr int RPI = 64 / LPR;       // rows per DMA wave-instruction: 4 / 8
+  constexpr int IPS = 16 / RPI;       // DMA instructions per 16-row sub-tile: 4 / 2
   constexpr int IMG = kStep * ROWB;   // one K or V image of a stage (8 KiB)
   constexpr int STAGE = 2 * IMG;      // K image + V image
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   uint32_t src_off[IPS];
 #pragma unroll
   for (int ii = 0; ii < IPS; ++ii) {
-    const int c = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (ii & 3));
-    src_off[ii] = (uint32_t)(((int64_t)(lane >> 4) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
+    const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);  // 16*j does not change the swizzle
+    src_off[ii] = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
   }
   // K row read (A operand of QK^T): row h (+16 j), logical chunk 4s + g
-  const int sw_h = swz(h);
+  const int sw_h = swz_hd<HD>(h);
   uint32_t k_rd[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(h * ROWB + (((4 * s + g) ^ sw_h) * 16));
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   // dims 16n + 4pp .. +3  -> logical chunk 2n + (pp>>1), 8 B half (pp&1)
   const int q4 = (lane & 15) >> 2, pp = lane & 3;
   const int v_row = 4 * g + q4;
-  const int sw_v = swz(v_row);
+  const int sw_v = swz_hd<HD>(v_row);
   uint32_t v_rd[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
         for (int ii = 0; ii < IPS; ++ii) {
           char* vdst = smem + st * STAGE + IMG + (16 * j + RPI * ii) * ROWB;
           const int row0 = t * kStep + 16 * j + RPI * ii;
-          const int tok = min(row0 + (lane >> 4), limit - 1);              // per lane
+          const int tok = min(row0 + lane / LPR, limit - 1);              // per lane
           const int blk_u = min(row0, limit - 1) >> p.bs_log2;              // wave-uniform
           const uint32_t phys = (uint32_t)__builtin_amdgcn_readlane(win_ids, blk_u - first_blk);
-          const int c = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (ii & 3));
+          const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);
           const uint64_t off = (uint64_t)phys * blk_bytes + (uint64_t)((uint32_t)(tok & bs_mask) * tok_bytes) +
                                (uint64_t)((int64_t)kvh * p.head_stride * 2) + (uint32_t)(c * 16);
           __builtin_amdgcn_global_load_lds((gbl_void*)(vbase_b + off), (lds_void*)vdst, 16, 0, AUX);
@@ -210,9 +211,9 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
     // K(t) landed?  issued after it: V(t), and K(t+1) V(t+1) when step t+1 exists
     wait_groups(1 + (has1 ? 2 : 0));
     // ---- S^T = K . Q^T for the two 16-token sub-tiles -------------------------------------
-    static_assert(KS == 4, "lds_read_rows8 reads four k-steps");
     u32x4_t k0[KS], k1[KS];
-    lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
+    if constexpr (KS == 4) lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
+    else lds_read_rows4<SB, SB + 16 * ROWB>(k_rd, k0, k1);
     if (has2) issue_k(t + 2, ST);  // K image of this stage is free again: refill it now
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -319,19 +320,23 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 
 }  // namespace
 
-// Launch the MFMA decode kernel.  Caller guarantees: head_dim == 128, block_size >= 16,
+// Launch the MFMA decode kernel.  Caller guarantees: head_dim in {64, 128}, block_size >= 16,
 // partition a multiple of 32 tokens and <= 64 blocks.
-int launch_decode_mfma(const DecodeParams& p, int gh, int dtype, bool nt, hipStream_t stream) {
+int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, bool nt, hipStream_t stream) {
   const int64_t waves = (int64_t)p.num_seqs * (p.num_q_heads / gh) * p.num_parts;
   if (waves > INT32_MAX) return MI_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)waves), block(64);
+#define MI_LAUNCH(TAG, HDIM)                                                                            \
+  do {                                                                                                  \
+    if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2>), grid, block, 0, stream, p, gh);      \
+    else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0>), grid, block, 0, stream, p, gh);         \
+  } while (0)
   if (dtype == MI_DTYPE_BF16) {
-    if (nt) hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 2>), grid, block, 0, stream, p, gh);
-    else hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 0>), grid, block, 0, stream, p, gh);
+    if (head_dim == 128) MI_LAUNCH(bf16_tag, 128); else MI_LAUNCH(bf16_tag, 64);
   } else {
-    if (nt) hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 2>), grid, block, 0, stream, p, gh);
-    else hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 0>), grid, block, 0, stream, p, gh);
+    if (head_dim == 128) MI_LAUNCH(f16_tag, 128); else MI_LAUNCH(f16_tag, 64);
   }
+#undef MI_LAUNCH
   return launch_status();
 }
 

@@ -42,15 +42,16 @@ struct PrefillParams {
 constexpr int kQTile = 16;  // query tokens per workgroup
 
 // G = waves per workgroup = query heads per KV head handled together; NI = waves that issue DMA.
-template <typename Tag, int NI>
+template <typename Tag, int HD, int NI>
 __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p) {
+  scalar_cache_acquire();
   using E = Elem<Tag>;
-  constexpr int HD = 128;
   constexpr int ROWB = HD * 2;
   constexpr int KS = HD / 32;
   constexpr int NT = HD / 16;
-  constexpr int RPI = 1024 / ROWB;   // rows per DMA wave-instruction (4)
-  constexpr int IPS = 16 / RPI;      // DMA instructions per 16-row sub-tile (4)
+  constexpr int LPR = ROWB / 16;     // lanes (16-B chunks) per row: 16 / 8
+  constexpr int RPI = 64 / LPR;      // rows per DMA wave-instruction: 4 / 8
+  constexpr int IPS = 16 / RPI;      // DMA instructions per 16-row sub-tile: 4 / 2
   constexpr int IMG = kStep * ROWB;  // 8 KiB
   constexpr int STAGE = 2 * IMG;
   constexpr int DMA_PER_STAGE = 4 * IPS;        // 16 wave-instructions fill one stage
@@ -102,16 +103,16 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   uint32_t src_off[IPS];
 #pragma unroll
   for (int ii = 0; ii < IPS; ++ii) {
-    const int c = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (ii & 3));
-    src_off[ii] = (uint32_t)(((int64_t)(lane >> 4) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
+    const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);  // 16*j does not change the swizzle
+    src_off[ii] = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
   }
-  const int sw_h = swz(col);
+  const int sw_h = swz_hd<HD>(col);
   uint32_t k_rd[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(col * ROWB + (((4 * s + g) ^ sw_h) * 16));
   const int q4 = (lane & 15) >> 2, pp = lane & 3;
   const int v_row = 4 * g + q4;
-  const int sw_v = swz(v_row);
+  const int sw_v = swz_hd<HD>(v_row);
   uint32_t v_rd[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
@@ -120,18 +121,19 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const char* const kbase_b = reinterpret_cast<const char*>(p.k_cache);
   const char* const vbase_b = reinterpret_cast<const char*>(p.v_cache);
 
-  // DMA instruction `idx` (0..15) of the stage of step t: 0-7 K image, 8-15 V image; inside an
-  // image idx&7 = 4*j + ii (sub-tile j, row group ii).  Rows at or past `limit` of the V image take
+  // DMA instruction `idx` of the stage of step t: [0, 2*IPS) K image, [2*IPS, 4*IPS) V image; inside an
+  // image the index is IPS*j + ii (sub-tile j, row group ii).  Rows at or past `limit` of the V image take
   // the bytes of row limit-1 (their probability is exactly 0; 0 * stale NaN must not appear).
   auto issue_one = [&](int t, int st, int idx) {
     const bool is_v = idx >= 2 * IPS;
-    const int j = (idx >> 2) & 1, ii = idx & 3;
+    const int k = idx % (2 * IPS);
+    const int j = k / IPS, ii = k % IPS;
     const int row0 = t * kStep + 16 * j + RPI * ii;  // first token row of this instruction
     char* dst = smem + st * STAGE + (is_v ? IMG : 0) + (16 * j + RPI * ii) * ROWB;
-    const int tok = min(row0 + (lane >> 4), limit - 1);  // per lane (== row0 + lane>>4 off the tail)
+    const int tok = min(row0 + lane / LPR, limit - 1);  // per lane (== row0 + lane>>4 off the tail)
     const int blk = __builtin_amdgcn_readfirstlane(min(min(row0, limit - 1) >> p.bs_log2, last_blk));
     const int phys = bt_row[blk];
-    const int c = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (ii & 3));
+    const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);
     const int64_t src = ((int64_t)phys * p.blk_stride + (int64_t)(tok & bs_mask) * p.tok_stride +
                          (int64_t)kvh * p.head_stride) * 2 + c * 16;
     __builtin_amdgcn_global_load_lds((gbl_void*)((is_v ? vbase_b : kbase_b) + src), (lds_void*)dst, 16, 0, 0);
@@ -151,9 +153,9 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   auto compute = [&](int t, auto stc) {
     constexpr int ST = decltype(stc)::value;
     constexpr int SB = ST * STAGE;
-    static_assert(KS == 4, "lds_read_rows8 reads four k-steps");
     u32x4_t k0[KS], k1[KS];
-    lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
+    if constexpr (KS == 4) lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
+    else lds_read_rows4<SB, SB + 16 * ROWB>(k_rd, k0, k1);
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -193,20 +195,16 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
       ls += v[i];
     }
     l += ls;
-    uint4 pb;
-    pb.x = E::pack(v[0], v[1]);
-    pb.y = E::pack(v[2], v[3]);
-    pb.z = E::pack(v[4], v[5]);
-    pb.w = E::pack(v[6], v[7]);
+    const u32x2_t pb0 = {E::pack(v[0], v[1]), E::pack(v[2], v[3])};  // P^T fragments of the K=16 MFMA
+    const u32x2_t pb1 = {E::pack(v[4], v[5]), E::pack(v[6], v[7])};
 #pragma unroll
     for (int nb = 0; nb < NT; nb += 4) {
       u32x2_t a0[4], a1[4];
       lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[nb], a0, a1);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        uint4 vf;
-        vf.x = a0[n][0]; vf.y = a0[n][1]; vf.z = a1[n][0]; vf.w = a1[n][1];
-        acc[nb + n] = mfma16<Tag>(vf, pb, acc[nb + n]);
+      for (int n = 0; n < 4; ++n) {  // one transposed read == one A operand
+        acc[nb + n] = mfma16_k16<Tag>(a0[n], pb0, acc[nb + n]);
+        acc[nb + n] = mfma16_k16<Tag>(a1[n], pb1, acc[nb + n]);
       }
     }
   };
@@ -246,14 +244,14 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   }
 }
 
-template <typename Tag>
+template <typename Tag, int HD>
 int launch_prefill(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
   const int waves = p.heads_per_wg;  // one wave per query head
   const dim3 grid((max_query_len + kQTile - 1) / kQTile, p.num_seqs, num_kv_heads * (p.kv_group / waves)),
       block(64 * waves);
-  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, 4>), grid, block, 0, s, p);
-  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, 2>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, 1>), grid, block, 0, s, p);
+  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4>), grid, block, 0, s, p);
+  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1>), grid, block, 0, s, p);
   return launch_status();
 }
 
@@ -276,7 +274,7 @@ extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cac
       block_table_stride <= 0)
     return MI_ERR_INVALID_ARG;
   if (num_q_heads % num_kv_heads) return MI_ERR_INVALID_ARG;
-  if (head_dim != 128) return MI_ERR_UNSUPPORTED;
+  if (head_dim != 128 && head_dim != 64) return MI_ERR_UNSUPPORTED;
   if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
   if (!is_pow2(block_size) || block_size < 16) return MI_ERR_UNSUPPORTED;
   const int kv_group = num_q_heads / num_kv_heads;
@@ -308,6 +306,9 @@ extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cac
   p.tok_stride = cache_token_stride;
   p.head_stride = cache_head_stride;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return dtype == MI_DTYPE_BF16 ? launch_prefill<bf16_tag>(p, num_kv_heads, max_query_len, s)
-                                : launch_prefill<f16_tag>(p, num_kv_heads, max_query_len, s);
+  if (dtype == MI_DTYPE_BF16)
+    return head_dim == 128 ? launch_prefill<bf16_tag, 128>(p, num_kv_heads, max_query_len, s)
+                           : launch_prefill<bf16_tag, 64>(p, num_kv_heads, max_query_len, s);
+  return head_dim == 128 ? launch_prefill<f16_tag, 128>(p, num_kv_heads, max_query_len, s)
+                         : launch_prefill<f16_tag, 64>(p, num_kv_heads, max_query_len, s);
 }
