@@ -71,8 +71,11 @@ def test_argument_validation_without_gpu():
                                     _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, 0, None) == _C.MI_ERR_UNSUPPORTED
     assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 512) == 256 * 28 * 8 * 130 * 4
     assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 4096) == 0
-    part = lib.mi_paged_attn_decode_auto_partition(256, 4, 4096)
-    assert part % 16 == 0 and 128 <= part <= 4096
+    # longest partition <= 1024 leaving >= 512 waves, floor 256, never beyond the (rounded) context
+    auto = lib.mi_paged_attn_decode_auto_partition
+    assert auto(256, 4, 4096) == 1024 and auto(64, 4, 2048) == 1024 and auto(32, 4, 1024) == 256
+    assert auto(1, 4, 8192) == 256 and auto(4, 2, 40) == 64 and auto(256, 1, 4096) == 1024
+    assert lib.mi_paged_attn_decode_effective_partition(256, 4, 4096, 8, 0) == 512     # 64-block cap
 
 
 def test_blockpool_fifo_refcount_and_null_block():

@@ -419,18 +419,19 @@ int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
                                                        int32_t max_seq_len) {
-  // Want enough waves to fill 256 CUs x 8-12 resident waves a few times over, but
-  // partitions long enough (>= 128 tokens) that the per-wave prologue/merge is noise.
-  if (num_seqs <= 0 || num_kv_heads <= 0 || max_seq_len <= 0) return 128;
-  const int64_t target_waves = 4096;
+  // Measured on MI355X (tools/bench_decode_kernel.py, shapes B x ctx = 256x4096, 64x2048, 32x1024,
+  // 8x32768, 1x8192; KV heads 4/2/1): the kernel's per-partition prologue (Q fragments, block-id
+  // window, pipeline fill) and the fp32 partial write + merge cost more than idle CUs do, so take the
+  // LONGEST partition (<= 1024 tokens) that still leaves >= 2 waves per CU, and never go below 256.
+  if (num_seqs <= 0 || num_kv_heads <= 0 || max_seq_len <= 0) return 256;
+  const int64_t target_waves = 512;
   const int64_t pairs = (int64_t)num_seqs * num_kv_heads;
-  int32_t best = 128;
-  for (int32_t ps = 128; ps <= 16384; ps *= 2) {
+  int32_t best = 256;
+  for (int32_t ps = 1024; ps >= 256; ps /= 2) {
     const int64_t parts = (max_seq_len + ps - 1) / ps;
-    if (pairs * parts >= target_waves || ps == 128) best = ps;
-    else break;
+    if (pairs * parts >= target_waves) { best = ps; break; }
   }
-  if (best > mi::round_up(max_seq_len, mi::kTile)) best = mi::round_up(max_seq_len, mi::kTile);
+  if (best > mi::round_up(max_seq_len, 32)) best = mi::round_up(max_seq_len, 32);
   return best;  // the caller additionally caps it at 64 blocks (mi_paged_attn_decode)
 }
 
