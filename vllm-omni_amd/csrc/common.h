@@ -98,6 +98,34 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
   return v;
 }
 
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU:
+// v_permlane{16,32}_swap exchange whole rows between two registers, no LDS round trip
+// (ds_bpermute, which __shfl_xor compiles to, costs an LDS access and an lgkmcnt wait each).
+// Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) treats the two results of
+// the builtin as one value (it dropped the v_max / emitted `v_add v1, v1, v1` after the swap — wrong
+// results on hardware, tools/scratch/plt.hip).  `s_nop 1`: the wait states hipcc itself puts
+// between a VALU write of an operand and the swap.
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {  // a[32..63] <-> b[0..31]
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {  // odd rows of a <-> even rows of b
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rows_allreduce_max(float v) {
+  float a = v, b = v;
+  permlane32_swap(a, b);
+  a = b = fmaxf(a, b);
+  permlane16_swap(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_allreduce_sum(float v) {
+  float a = v, b = v;
+  permlane32_swap(a, b);
+  a = b = a + b;
+  permlane16_swap(a, b);
+  return a + b;
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Scalar-cache acquire, first statement of every kernel.  hipcc turns wave-uniform loads of small

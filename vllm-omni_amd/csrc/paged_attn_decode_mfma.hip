@@ -104,16 +104,17 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   }
 
   // ---- per-lane constants -------------------------------------------------------------
-  // DMA source: instruction ii of a sub-tile moves rows 4*ii + (lane>>4); lane position pc = lane&15
-  // of the LDS row holds logical chunk pc ^ swz(row); swz(row) = (((lane>>4)&3)<<2) | (ii&3).
-  uint32_t src_off[IPS];
+  // DMA source: instruction ii of a sub-tile moves rows RPI*ii + lane/LPR; lane position pc = lane%LPR
+  // of the LDS row holds logical chunk pc ^ f(row), f = swz_k / swz_v (mfma_attn_common.h).
+  uint32_t src_off_k[IPS], src_off_v[IPS];
 #pragma unroll
-  for (int ii = 0; ii < IPS; ++ii) {
-    const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);  // 16*j does not change the swizzle
-    src_off[ii] = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
+  for (int ii = 0; ii < IPS; ++ii) {  // 16*j does not change either swizzle
+    const uint32_t row_b = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2);
+    src_off_k[ii] = row_b + (((lane % LPR) ^ swz_k<HD>(RPI * ii + lane / LPR)) * 16);
+    src_off_v[ii] = row_b + (((lane % LPR) ^ swz_v<HD>(RPI * ii + lane / LPR)) * 16);
   }
   // K row read (A operand of QK^T): row h (+16 j), logical chunk 4s + g
-  const int sw_h = swz_hd<HD>(h);
+  const int sw_h = swz_k<HD>(h);
   uint32_t k_rd[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(h * ROWB + (((4 * s + g) ^ sw_h) * 16));
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   // dims 16n + 4pp .. +3  -> logical chunk 2n + (pp>>1), 8 B half (pp&1)
   const int q4 = (lane & 15) >> 2, pp = lane & 3;
   const int v_row = 4 * g + q4;
-  const int sw_v = swz_hd<HD>(v_row);
+  const int sw_v = swz_v<HD>(v_row);
   uint32_t v_rd[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 #pragma unroll
       for (int ii = 0; ii < IPS; ++ii) {
         char* kdst = smem + st * STAGE + (16 * j + RPI * ii) * ROWB;
-        __builtin_amdgcn_global_load_lds((gbl_void*)(src + src_off[ii]), (lds_void*)kdst, 16, 0, AUX);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src + src_off_k[ii]), (lds_void*)kdst, 16, 0, AUX);
         src += grp_bytes;
       }
     }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 #pragma unroll
         for (int ii = 0; ii < IPS; ++ii) {
           char* vdst = smem + st * STAGE + IMG + (16 * j + RPI * ii) * ROWB;
-          __builtin_amdgcn_global_load_lds((gbl_void*)(src + src_off[ii]), (lds_void*)vdst, 16, 0, AUX);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src + src_off_v[ii]), (lds_void*)vdst, 16, 0, AUX);
           src += grp_bytes;
         }
       }
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
           const int tok = min(row0 + lane / LPR, limit - 1);              // per lane
           const int blk_u = min(row0, limit - 1) >> p.bs_log2;              // wave-uniform
           const uint32_t phys = (uint32_t)__builtin_amdgcn_readlane(win_ids, blk_u - first_blk);
-          const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);
+          const int c = (lane % LPR) ^ swz_v<HD>(RPI * ii + lane / LPR);
           const uint64_t off = (uint64_t)phys * blk_bytes + (uint64_t)((uint32_t)(tok & bs_mask) * tok_bytes) +
                                (uint64_t)((int64_t)kvh * p.head_stride * 2) + (uint32_t)(c * 16);
           __builtin_amdgcn_global_load_lds((gbl_void*)(vbase_b + off), (lds_void*)vdst, 16, 0, AUX);
@@ -237,8 +238,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
       }
     }
     float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows_allreduce_max(mx);
     const float m_new = fmaxf(m, mx);
     if (__any(m_new != m)) {
       const float alpha = fast_exp2(m - m_new);
@@ -290,8 +290,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   // the last step waited with vmcnt(0): no DMA can land in this workgroup's LDS after it exits
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
+  l = rows_allreduce_sum(l);
   if (!head_ok) return;
   if (direct) {
     const float inv = 1.f / l;

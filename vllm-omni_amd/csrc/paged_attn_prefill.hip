@@ -9,15 +9,21 @@
 // swizzled LDS images by LDS-DMA, swapped QK^T (S^T = K . Q^T) so that a lane owns one query
 // COLUMN and the softmax axis is lane-local, P^T as the B operand of O^T += V^T . P^T, V^T through
 // `ds_read_b64_tr_b16`.  What differs:
-//   * a workgroup = the G query heads that share one KV head (one wave per head, G <= 16 waves) x
-//     16 consecutive query tokens; the 16 MFMA columns of a wave are its 16 query TOKENS;
-//   * the K/V stage is shared by the workgroup: DMA issue is split over up to four waves, two raw
-//     `s_barrier`s per step order "stage landed" and "stage consumed" (no __syncthreads: its
-//     implied vmcnt(0) would drain the prefetched stage);
-//   * the causal mask is per lane (column = query token); only steps that touch the diagonal
-//     evaluate it; the context loop stops at the last position any column of the tile may see.
+//   * a workgroup = the G query heads that share one KV head (one wave per head, G <= 8 waves) x
+//     16*NC consecutive query tokens; a wave owns NC column tiles of 16 query TOKENS and uses every
+//     K and V fragment it reads from LDS for all of them (the kernel with one column tile per wave was
+//     bound by LDS reads: 16 KB per wave and step for 24 MFMAs);
+//   * both contractions are K = 32 MFMAs: the two transposed reads of a d-tile (keys 4g.. of either
+//     16-row sub-tile) concatenate into one A operand, the two packed P registers pairs into the B
+//     operand — the k index only has to name the same key on both sides;
+//   * the K/V stages form a ring of three shared by the workgroup: DMA issue is split over up to four
+//     waves, ONE raw `s_barrier` per step orders "stage t landed" and "stage t-1 consumed" before
+//     stage t+2 is issued over it (no __syncthreads: its implied vmcnt(0) would drain the ring);
+//   * the causal mask is per lane (column = query token); only steps that touch a column tile's
+//     diagonal evaluate it; the context loop stops at the last position any column may see; tiles
+//     are dispatched longest first.
 // FLOPs per layer: 2 * S^2 * d * n_q (causal).  MFMA-bound by design; K/V bytes are read once per
-// (16 query tokens x G heads) and served from L2/MALL for any but the first tile of a sequence.
+// (16*NC query tokens x G heads) and served from L2/MALL for any but the first tile of a sequence.
 #include <cstdlib>
 
 #include "common.h"
@@ -39,13 +45,15 @@ struct PrefillParams {
   int64_t q_stride, out_stride, blk_stride, tok_stride, head_stride;
 };
 
-constexpr int kQTile = 16;  // query tokens per workgroup
+constexpr int kColTile = 16;  // query tokens per MFMA column tile
 
-// G = waves per workgroup = query heads per KV head handled together; NI = waves that issue DMA.
-template <typename Tag, int HD, int NI>
+// waves per workgroup = query heads per KV head handled together; NI = waves that issue DMA;
+// NC = column tiles (of 16 query tokens) per wave.
+template <typename Tag, int HD, int NI, int NC>
 __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
+  constexpr int QT = kColTile * NC;  // query tokens per workgroup
   constexpr int ROWB = HD * 2;
   constexpr int KS = HD / 32;
   constexpr int NT = HD / 16;
@@ -54,33 +62,37 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   constexpr int IPS = 16 / RPI;      // DMA instructions per 16-row sub-tile: 4 / 2
   constexpr int IMG = kStep * ROWB;  // 8 KiB
   constexpr int STAGE = 2 * IMG;
+  constexpr int NSTAGE = 3;
   constexpr int DMA_PER_STAGE = 4 * IPS;        // 16 wave-instructions fill one stage
   constexpr int SHARE = DMA_PER_STAGE / NI;      // per issuing wave
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int seq = blockIdx.y;
   // blockIdx.z = (kv head, chunk of heads_per_wg query heads of its GQA group)
-  const int chunks = p.kv_group / p.heads_per_wg;
+  // (the last chunk of a group may be short: its surplus waves keep their DMA share and the barriers
+  // but compute and store nothing)
+  const int chunks = (p.kv_group + p.heads_per_wg - 1) / p.heads_per_wg;
   const int kvh = blockIdx.z / chunks;
-  const int head = kvh * p.kv_group + (blockIdx.z % chunks) * p.heads_per_wg + wid;  // this wave's query head
+  const int hg = (blockIdx.z % chunks) * p.heads_per_wg + wid;
+  const bool active = hg < p.kv_group;                            // wave-uniform
+  const int head = kvh * p.kv_group + min(hg, p.kv_group - 1);    // this wave's query head
 
   const int q0 = p.query_start_loc[seq];
   const int q_len = p.query_start_loc[seq + 1] - q0;
   const int seq_len = p.seq_lens[seq];
-  const int tile0 = blockIdx.x * kQTile;  // first query row of this tile inside the chunk
-  if (tile0 >= q_len) return;             // whole workgroup: uniform
-  const int ctx_off = seq_len - q_len;    // absolute position of query row 0
-  const int rows = min(kQTile, q_len - tile0);
+  // longest (latest) tiles first: the dispatcher hands out blockIdx.x in ascending order
+  const int tile0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;  // first query row of this tile inside the chunk
+  if (tile0 >= q_len) return;              // whole workgroup: uniform
+  const int ctx_off = seq_len - q_len;     // absolute position of query row 0
+  const int rows = min(QT, q_len - tile0);
 
-  const int col = lane & 15;  // query token of the tile
+  const int col = lane & 15;  // query token inside a column tile
   const int g = lane >> 4;
-  const bool col_ok = col < rows;
-  const int qpos = ctx_off + tile0 + col;                  // absolute position of my column
   const int limit = ctx_off + tile0 + rows;                // keys [0, limit) are visible to the tile
   const int t_end = (limit + kStep - 1) / kStep;
-  const int diag_t = (ctx_off + tile0) / kStep;            // first step that can cross the diagonal
+  const int qpos0 = ctx_off + tile0 + col;                 // absolute position of my column in tile 0
 
   // constant address space: the (wave-uniform) block-id fetch becomes a SCALAR load (lgkmcnt), so
   // it never sits in the vmcnt queue the DMA waits are counted on
@@ -89,170 +101,238 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const int bs_mask = (1 << p.bs_log2) - 1;
   const int last_blk = (limit - 1) >> p.bs_log2;
 
-  // ---- Q^T fragments: column = token tile0+col of head `head`, dims 32s + 8g .. -------------
-  uint4 qf[KS];
-  {
+  // ---- Q^T fragments: column = token tile0 + 16c + col of head `head`, dims 32s + 8g .. -------
+  uint4 qf[NC][KS];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool ok = kColTile * c + col < rows;
     const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) +
-                         (int64_t)(q0 + tile0 + (col_ok ? col : 0)) * p.q_stride + (int64_t)head * HD + 8 * g;
+                         (int64_t)(q0 + tile0 + (ok ? kColTile * c + col : 0)) * p.q_stride + (int64_t)head * HD + 8 * g;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      qf[s] = col_ok ? *reinterpret_cast<const uint4*>(qb + 32 * s) : make_uint4(0, 0, 0, 0);
+      qf[c][s] = ok ? *reinterpret_cast<const uint4*>(qb + 32 * s) : make_uint4(0, 0, 0, 0);
   }
 
   // ---- per-lane constants (same images as the decode kernel) ----------------------------------
-  uint32_t src_off[IPS];
-#pragma unroll
-  for (int ii = 0; ii < IPS; ++ii) {
-    const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);  // 16*j does not change the swizzle
-    src_off[ii] = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
-  }
-  const int sw_h = swz_hd<HD>(col);
+  const int sw_h = swz_k<HD>(col);
   uint32_t k_rd[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(col * ROWB + (((4 * s + g) ^ sw_h) * 16));
   const int q4 = (lane & 15) >> 2, pp = lane & 3;
   const int v_row = 4 * g + q4;
-  const int sw_v = swz_hd<HD>(v_row);
+  const int sw_v = swz_v<HD>(v_row);
   uint32_t v_rd[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
     v_rd[n] = (uint32_t)(IMG + v_row * ROWB + (((2 * n + (pp >> 1)) ^ sw_v) * 16) + 8 * (pp & 1));
 
+  // ---- DMA issue.  A stage is four 16-row sub-tiles: K rows 0-15, K rows 16-31, V rows 0-15, V rows
+  // 16-31; issuing wave `wid` owns SUBS consecutive ones.  Address arithmetic is scalar: ONE block-table
+  // load and one 64-bit multiply per sub-tile (a sub-tile never straddles a block: block_size >= 16),
+  // then its IPS DMA instructions step a uniform pointer by RPI rows and add a per-lane 32-bit offset.
+  constexpr int SUBS = 4 / NI;
+  const uint64_t blk_bytes = (uint64_t)p.blk_stride * 2;
+  const uint32_t tok_bytes = (uint32_t)p.tok_stride * 2;
+  const uint32_t grp_bytes = RPI * tok_bytes;
   const char* const kbase_b = reinterpret_cast<const char*>(p.k_cache);
   const char* const vbase_b = reinterpret_cast<const char*>(p.v_cache);
-
-  // DMA instruction `idx` of the stage of step t: [0, 2*IPS) K image, [2*IPS, 4*IPS) V image; inside an
-  // image the index is IPS*j + ii (sub-tile j, row group ii).  Rows at or past `limit` of the V image take
-  // the bytes of row limit-1 (their probability is exactly 0; 0 * stale NaN must not appear).
-  auto issue_one = [&](int t, int st, int idx) {
-    const bool is_v = idx >= 2 * IPS;
-    const int k = idx % (2 * IPS);
-    const int j = k / IPS, ii = k % IPS;
-    const int row0 = t * kStep + 16 * j + RPI * ii;  // first token row of this instruction
-    char* dst = smem + st * STAGE + (is_v ? IMG : 0) + (16 * j + RPI * ii) * ROWB;
-    const int tok = min(row0 + lane / LPR, limit - 1);  // per lane (== row0 + lane>>4 off the tail)
-    const int blk = __builtin_amdgcn_readfirstlane(min(min(row0, limit - 1) >> p.bs_log2, last_blk));
-    const int phys = bt_row[blk];
-    const int c = (lane % LPR) ^ swz_hd<HD>(RPI * ii + lane / LPR);
-    const int64_t src = ((int64_t)phys * p.blk_stride + (int64_t)(tok & bs_mask) * p.tok_stride +
-                         (int64_t)kvh * p.head_stride) * 2 + c * 16;
-    __builtin_amdgcn_global_load_lds((gbl_void*)((is_v ? vbase_b : kbase_b) + src), (lds_void*)dst, 16, 0, 0);
-  };
-  auto issue = [&](int t, int st) {  // my share of the stage (waves >= NI issue nothing)
-    if (wid < NI) {
+  uint32_t my_off[SUBS][IPS];  // per-lane source offset inside a sub-tile: row, head, swizzled chunk
 #pragma unroll
-      for (int k = 0; k < SHARE; ++k) issue_one(t, st, wid * SHARE + k);
+  for (int u = 0; u < SUBS; ++u) {
+    const bool is_v = wid * SUBS + u >= 2;
+#pragma unroll
+    for (int ii = 0; ii < IPS; ++ii) {
+      const int r = RPI * ii + lane / LPR;
+      const int c = (lane % LPR) ^ (is_v ? swz_v<HD>(r) : swz_k<HD>(r));
+      my_off[u][ii] = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
+    }
+  }
+  auto issue = [&](int t, int st) {  // my share of the stage (waves >= NI issue nothing)
+    if (wid >= NI) return;
+    const bool tail = (t + 1) * kStep > limit;  // wave-uniform: some rows of the step are past `limit`
+#pragma unroll
+    for (int u = 0; u < SUBS; ++u) {
+      const int sub = wid * SUBS + u;
+      const bool is_v = sub >= 2;
+      const int j = sub & 1;
+      char* dst = smem + st * STAGE + (is_v ? IMG : 0) + 16 * j * ROWB;
+      const char* const img = is_v ? vbase_b : kbase_b;
+      const int tok0 = t * kStep + 16 * j;
+      if (!(tail && is_v)) {
+        // K rows past `limit` may hold anything: their scores are replaced by -inf, never multiplied
+        const int blk = min(tok0 >> p.bs_log2, last_blk);
+        const char* src = img + (uint64_t)(uint32_t)bt_row[blk] * blk_bytes + (uint32_t)(tok0 & bs_mask) * tok_bytes;
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src + my_off[u][ii]), (lds_void*)(dst + RPI * ii * ROWB), 16, 0, 0);
+          src += grp_bytes;
+        }
+      } else {
+        // V rows at or past `limit` take the bytes of row limit-1: their probability is exactly 0, and
+        // 0 * (finite) stays 0 where 0 * (stale NaN/Inf) would not.  Last step of a tile only.
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+          const int row0 = tok0 + RPI * ii;
+          const int tok = min(row0 + lane / LPR, limit - 1);  // per lane
+          const int blk = __builtin_amdgcn_readfirstlane(min(row0, limit - 1) >> p.bs_log2);
+          const int c = (lane % LPR) ^ swz_v<HD>(RPI * ii + lane / LPR);
+          const uint64_t off = (uint64_t)(uint32_t)bt_row[blk] * blk_bytes + (uint64_t)((uint32_t)(tok & bs_mask) * tok_bytes) +
+                               (uint64_t)((int64_t)kvh * p.head_stride * 2) + (uint32_t)(c * 16);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(img + off), (lds_void*)(dst + RPI * ii * ROWB), 16, 0, 0);
+        }
+      }
     }
   };
 
-  float m = -3.0e38f, l = 0.f;
-  f32x4_t acc[NT];
+  float m[NC], l[NC];
+  f32x4_t acc[NC][NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < NC; ++c) {
+    m[c] = -3.0e38f;
+    l[c] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[c][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
+  // One 32-key step.  Order chosen for overlap inside the wave: all QK^T MFMAs are issued first, the V
+  // reads are issued (and land) behind them, the softmax VALU of column tile 0 runs while the MFMAs of
+  // tile 1 still occupy the matrix pipe, the PV MFMAs follow back to back.
   auto compute = [&](int t, auto stc) {
     constexpr int ST = decltype(stc)::value;
     constexpr int SB = ST * STAGE;
+    if (!active) return;
     u32x4_t k0[KS], k1[KS];
     if constexpr (KS == 4) lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
     else lds_read_rows4<SB, SB + 16 * ROWB>(k_rd, k0, k1);
-    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t s0[NC], s1[NC];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      s0 = mfma16<Tag>(__builtin_bit_cast(uint4, k0[s]), qf[s], s0);
-      s1 = mfma16<Tag>(__builtin_bit_cast(uint4, k1[s]), qf[s], s1);
-    }
-    // lane: query column `col`, keys t*32 + 4g + r (s0[r]) and t*32 + 16 + 4g + r (s1[r])
-    float v[8];
+    for (int c = 0; c < NC; ++c) {
+      s0[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      s1[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = s0[r] * p.scale_log2e;
-      v[4 + r] = s1[r] * p.scale_log2e;
-    }
-    if (t >= diag_t) {  // causal mask, per column: key position <= query position
-      const int kb = t * kStep + 4 * g;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (kb + r > qpos) v[r] = -INFINITY;
-        if (kb + 16 + r > qpos) v[4 + r] = -INFINITY;
+      for (int s = 0; s < KS; ++s) {
+        s0[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k0[s]), qf[c][s], s0[c]);
+        s1[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k1[s]), qf[c][s], s1[c]);
       }
     }
-    float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    if (__any(m_new != m)) {
-      const float alpha = fast_exp2(m - m_new);
-      m = m_new;
-      l *= alpha;
+    u32x2_t a0[NT / 4][4], a1[NT / 4][4];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] *= alpha;
+    for (int nb = 0; nb < NT / 4; ++nb) lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[4 * nb], a0[nb], a1[nb]);
+
+    uint4 pb[NC];  // P^T operand per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      // lane: query column `col` of tile c, keys t*32 + 4g + r (s0[r]) and t*32 + 16 + 4g + r (s1[r])
+      f32x2_t v[4] = {{s0[c][0], s0[c][1]}, {s0[c][2], s0[c][3]}, {s1[c][0], s1[c][1]}, {s1[c][2], s1[c][3]}};
+      const int qpos = qpos0 + kColTile * c;
+      if ((t + 1) * kStep > ctx_off + tile0 + kColTile * c + 1) {  // the step reaches past the tile's first diagonal key
+        const int kb = t * kStep + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kb + r > qpos) v[r >> 1][r & 1] = -INFINITY;
+          if (kb + 16 + r > qpos) v[2 + (r >> 1)][r & 1] = -INFINITY;
+        }
+      }
+      float mx = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1])),
+                       fmaxf(fmaxf(v[2][0], v[2][1]), fmaxf(v[3][0], v[3][1])));
+      mx = rows_allreduce_max(mx);
+      const float m_new = fmaxf(m[c], mx * p.scale_log2e);  // scale > 0: max commutes with it
+      if (__any(m_new != m[c])) {
+        const float alpha = fast_exp2(m[c] - m_new);
+        m[c] = m_new;
+        l[c] *= alpha;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[c][n] *= alpha;
+      }
+      const f32x2_t sc = {p.scale_log2e, p.scale_log2e}, nm = {-m[c], -m[c]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // packed fma (v_pk_fma_f32), then the quarter-rate exp per element
+        v[i] = __builtin_elementwise_fma(v[i], sc, nm);
+        v[i][0] = fast_exp2(v[i][0]);
+        v[i][1] = fast_exp2(v[i][1]);
+      }
+      const f32x2_t ls = (v[0] + v[1]) + (v[2] + v[3]);
+      l[c] += ls[0] + ls[1];
+      pb[c] = make_uint4(E::pack(v[0][0], v[0][1]), E::pack(v[1][0], v[1][1]), E::pack(v[2][0], v[2][1]),
+                         E::pack(v[3][0], v[3][1]));
     }
-    float ls = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v[i] = fast_exp2(v[i] - m);
-      ls += v[i];
-    }
-    l += ls;
-    const u32x2_t pb0 = {E::pack(v[0], v[1]), E::pack(v[2], v[3])};  // P^T fragments of the K=16 MFMA
-    const u32x2_t pb1 = {E::pack(v[4], v[5]), E::pack(v[6], v[7])};
+    for (int nb = 0; nb < NT / 4; ++nb) {
 #pragma unroll
-    for (int nb = 0; nb < NT; nb += 4) {
-      u32x2_t a0[4], a1[4];
-      lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[nb], a0, a1);
+      for (int n = 0; n < 4; ++n) {  // two transposed reads == one K = 32 A operand
+        const uint4 a = make_uint4(a0[nb][n][0], a0[nb][n][1], a1[nb][n][0], a1[nb][n][1]);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {  // one transposed read == one A operand
-        acc[nb + n] = mfma16_k16<Tag>(a0[n], pb0, acc[nb + n]);
-        acc[nb + n] = mfma16_k16<Tag>(a1[n], pb1, acc[nb + n]);
+        for (int c = 0; c < NC; ++c) acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
       }
     }
   };
 
-  // ---- pipeline.  Per step: [issue stage t+1] [my DMAs of stage t landed] barrier [compute t]
-  //      barrier (stage t may be overwritten by the issue of step t+2).  The issuing waves' only
-  //      vector-memory operations are their SHARE DMA instructions per stage, retired in order.
+  // ---- pipeline: ring of three stages, one barrier per step.  Per step t:
+  //      [my DMAs of stage t landed] barrier (=> stage t complete, stage t-1 consumed by every wave)
+  //      [issue stage t+2 over stage t-1] [compute t].  The issuing waves' only vector-memory
+  //      operations are their SHARE DMA instructions per stage, retired in order.
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  auto step = [&](int t, auto stc) {
+    constexpr int ST = decltype(stc)::value;
+    if (t + 1 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < t_end) issue(t + 2, (ST + 2) % NSTAGE);
+    compute(t, stc);
+  };
   issue(0, 0);
-  for (int t = 0; t < t_end; t += 2) {
-    if (t + 1 < t_end) { issue(t + 1, 1); wait_vmcnt<SHARE>(); } else { wait_vmcnt<0>(); }
-    __builtin_amdgcn_s_barrier();
-    compute(t, S0{});
-    __builtin_amdgcn_s_barrier();
-    if (t + 1 < t_end) {
-      if (t + 2 < t_end) { issue(t + 2, 0); wait_vmcnt<SHARE>(); } else { wait_vmcnt<0>(); }
-      __builtin_amdgcn_s_barrier();
-      compute(t + 1, S1{});
-      __builtin_amdgcn_s_barrier();
-    }
+  if (1 < t_end) issue(1, 1);
+  for (int t = 0; t < t_end; t += 3) {
+    step(t, S0{});
+    if (t + 1 < t_end) step(t + 1, S1{});
+    if (t + 2 < t_end) step(t + 2, S2{});
   }
 
   // ---- epilogue: O^T -> out[token][head][dim] -----------------------------------------------------
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  if (!col_ok) return;
-  const float inv = 1.f / l;
-  uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + col) * p.out_stride +
-                (int64_t)head * HD + 4 * g;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    uint2 r;
-    r.x = E::pack(acc[n][0] * inv, acc[n][1] * inv);
-    r.y = E::pack(acc[n][2] * inv, acc[n][3] * inv);
-    *reinterpret_cast<uint2*>(o + 16 * n) = r;
+  for (int c = 0; c < NC; ++c) {
+    float lc = l[c];
+    lc = rows_allreduce_sum(lc);
+    if (active && kColTile * c + col < rows) {
+      const float inv = 1.f / lc;
+      uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + kColTile * c + col) * p.out_stride +
+                    (int64_t)head * HD + 4 * g;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        uint2 r;
+        r.x = E::pack(acc[c][n][0] * inv, acc[c][n][1] * inv);
+        r.y = E::pack(acc[c][n][2] * inv, acc[c][n][3] * inv);
+        *reinterpret_cast<uint2*>(o + 16 * n) = r;
+      }
+    }
   }
 }
 
+template <typename Tag, int HD, int NC>
+int launch_prefill_nc(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
+  const int waves = p.heads_per_wg;  // one wave per query head
+  constexpr int QT = kColTile * NC;
+  const dim3 grid((max_query_len + QT - 1) / QT, p.num_seqs, num_kv_heads * ((p.kv_group + waves - 1) / waves)),
+      block(64 * waves);
+  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4, NC>), grid, block, 0, s, p);
+  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2, NC>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1, NC>), grid, block, 0, s, p);
+  return launch_status();
+}
+
+// Column tiles per wave: 2 (32 query tokens per workgroup) once the chunk is long enough to use them;
+// a short chunk (decode-like mixed batches, tails) keeps 16-token tiles so that rows are not wasted.
+// MI_PREFILL_NC=1|2 overrides (tools/bench_prefill_kernel.py).
 template <typename Tag, int HD>
 int launch_prefill(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
-  const int waves = p.heads_per_wg;  // one wave per query head
-  const dim3 grid((max_query_len + kQTile - 1) / kQTile, p.num_seqs, num_kv_heads * (p.kv_group / waves)),
-      block(64 * waves);
-  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4>), grid, block, 0, s, p);
-  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1>), grid, block, 0, s, p);
-  return launch_status();
+  static const int forced = [] {
+    const char* e = getenv("MI_PREFILL_NC");
+    return e ? atoi(e) : 0;
+  }();
+  const int nc = forced ? forced : (max_query_len > kColTile ? 2 : 1);
+  return nc >= 2 ? launch_prefill_nc<Tag, HD, 2>(p, num_kv_heads, max_query_len, s)
+                 : launch_prefill_nc<Tag, HD, 1>(p, num_kv_heads, max_query_len, s);
 }
 
 }  // namespace
@@ -278,9 +358,17 @@ extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cac
   if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
   if (!is_pow2(block_size) || block_size < 16) return MI_ERR_UNSUPPORTED;
   const int kv_group = num_q_heads / num_kv_heads;
-  int heads_per_wg = 1;  // largest divisor of the GQA group that fits 8 waves (256-VGPR budget)
-  for (int w = 8; w >= 1; --w)
-    if (kv_group % w == 0) { heads_per_wg = w; break; }
+  // Query heads (= waves) per workgroup: the whole GQA group when it fits 8 waves (256-VGPR budget), else
+  // chunks of 8 (the last one may be short).  Measured (8k prompt, 28/4 heads): one 7-wave workgroup per CU
+  // 563 TFLOP/s, two independent 4-wave workgroups 476 — the second K/V stream costs more than the
+  // phase interleaving gains.  MI_PREFILL_HPW overrides (tools/bench_prefill_kernel.py).
+  static const int forced_hpw = [] {
+    const char* e = getenv("MI_PREFILL_HPW");
+    return e ? atoi(e) : 0;
+  }();
+  int heads_per_wg = kv_group <= 8 ? kv_group : 8;
+  if (forced_hpw > 0) heads_per_wg = forced_hpw < kv_group ? forced_hpw : kv_group;
+  if (heads_per_wg > 8) heads_per_wg = 8;
   if (q_token_stride % 8 || out_token_stride % 8 || cache_block_stride % 8 || cache_token_stride % 8 ||
       cache_head_stride % 8)
     return MI_ERR_INVALID_ARG;
