@@ -1,9 +1,12 @@
+// Standalone check of mi::rows_allreduce_{max,sum} (v_permlane{32,16}_swap) against a host loop.
+//   hipcc -O3 --offload-arch=gfx950 tools/scratch/permlane_swap_check.hip -o /tmp/plc && /tmp/plc   -> "bad=0"
+// Written when the __builtin_amdgcn_permlane*_swap form was found to be miscompiled (see common.h).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../vllm-omni_amd/csrc/common.h"
 __global__ void k(float* o, const float* in) {
   float v = in[threadIdx.x];
-  o[threadIdx.x] = mi::rows_allreduce_max(v);
+  o[threadIdx.x] = mi::rows_allreduce_max(v + 0.f);
   o[64 + threadIdx.x] = mi::rows_allreduce_sum(v);
 }
 int main() {

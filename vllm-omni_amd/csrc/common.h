@@ -101,6 +101,8 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 // Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU:
 // v_permlane{16,32}_swap exchange whole rows between two registers, no LDS round trip
 // (ds_bpermute, which __shfl_xor compiles to, costs an LDS access and an lgkmcnt wait each).
+// `volatile`: a cross-lane exchange must not be sunk past a divergent branch or early return (a
+// non-volatile form was, and read lanes that had already exited — run-to-run differences in the tests).
 // Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) treats the two results of
 // the builtin as one value (it dropped the v_max / emitted `v_add v1, v1, v1` after the swap — wrong
 // results on hardware, tools/scratch/plt.hip).  `s_nop 1`: the wait states hipcc itself puts
@@ -111,12 +113,27 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {  // a[32..
 __device__ __forceinline__ void permlane16_swap(float& a, float& b) {  // odd rows of a <-> even rows of b
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+// max without the canonicalising `v_max x, x` hipcc puts in front of every fmaxf whose operand it
+// cannot prove quiet (three VALU instructions per max in the softmax).  v_med3_f32 through its builtin:
+// med3(a, b, +inf) == max(a, b) for non-NaN operands, one instruction, and — unlike inline asm — an
+// instruction the compiler's hazard recogniser knows, so the wait states between an MFMA writing a
+// score and the VALU reading it are still inserted (an inline-asm v_max3 fed straight from MFMA
+// results read them early: run-to-run differences in tests/test_gpu_attention_decode.py).
+__device__ __forceinline__ float max2f(float a, float b) {
+  return __builtin_amdgcn_fmed3f(a, b, __builtin_inff());
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return max2f(max2f(a, b), c); }
+// (one asm statement: swap, max, swap, max — its input comes from compiler-generated VALU code, never
+// straight from an MFMA; `s_nop 0` = the wait state between a swap and the VALU reading its result)
 __device__ __forceinline__ float rows_allreduce_max(float v) {
   float a = v, b = v;
-  permlane32_swap(a, b);
-  a = b = fmaxf(a, b);
-  permlane16_swap(a, b);
-  return fmaxf(a, b);
+  asm volatile(
+      "s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\t"
+      "v_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0\n\t"
+      "v_max_f32 %0, %0, %1"
+      : "+v"(a), "+v"(b));
+  return a;
 }
 __device__ __forceinline__ float rows_allreduce_sum(float v) {
   float a = v, b = v;

@@ -223,23 +223,20 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
       s1 = mfma16<Tag>(__builtin_bit_cast(uint4, k1[s]), qf[s], s1);
     }
     // lane: head h, tokens t*32 + 4g + r (s0[r]) and t*32 + 16 + 4g + r (s1[r])
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = s0[r] * p.scale_log2e;
-      v[4 + r] = s1[r] * p.scale_log2e;
-    }
+    // VALU budget matters here (the kernel is only just HBM-bound): raw scores are kept, the scale rides
+    // in the exp2 argument's fma; max via v_max3 without canonicalising copies; packed fp32 math.
+    f32x2_t v[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
     if ((t + 1) * kStep > limit) {
       const int tb = t * kStep + 4 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (tb + r >= limit) v[r] = -INFINITY;
-        if (tb + 16 + r >= limit) v[4 + r] = -INFINITY;
+        if (tb + r >= limit) v[r >> 1][r & 1] = -INFINITY;
+        if (tb + 16 + r >= limit) v[2 + (r >> 1)][r & 1] = -INFINITY;
       }
     }
-    float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+    float mx = max3f(max3f(v[0][0], v[0][1], v[1][0]), max3f(v[1][1], v[2][0], v[2][1]), max2f(v[3][0], v[3][1]));
     mx = rows_allreduce_max(mx);
-    const float m_new = fmaxf(m, mx);
+    const float m_new = max2f(m, mx * p.scale_log2e);  // scale > 0: max commutes with it
     if (__any(m_new != m)) {
       const float alpha = fast_exp2(m - m_new);
       m = m_new;
@@ -247,17 +244,19 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] *= alpha;
     }
-    float ls = 0.f;
+    const f32x2_t sc = {p.scale_log2e, p.scale_log2e}, nm = {-m, -m};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v[i] = fast_exp2(v[i] - m);
-      ls += v[i];
+    for (int i = 0; i < 4; ++i) {
+      v[i] = __builtin_elementwise_fma(v[i], sc, nm);
+      v[i][0] = fast_exp2(v[i][0]);
+      v[i][1] = fast_exp2(v[i][1]);
     }
-    l += ls;
+    const f32x2_t ls = (v[0] + v[1]) + (v[2] + v[3]);
+    l += ls[0] + ls[1];
     // P^T fragments (B operand of the K=16 MFMA): lane (head h, tokens 4g+0..3) of each sub-tile —
     // exactly the four scores the lane already holds
-    const u32x2_t pb0 = {E::pack(v[0], v[1]), E::pack(v[2], v[3])};
-    const u32x2_t pb1 = {E::pack(v[4], v[5]), E::pack(v[6], v[7])};
+    const u32x2_t pb0 = {E::pack(v[0][0], v[0][1]), E::pack(v[1][0], v[1][1])};
+    const u32x2_t pb1 = {E::pack(v[2][0], v[2][1]), E::pack(v[3][0], v[3][1])};
     // V(t) landed?  issued after it: K(t+1) V(t+1) when step t+1 exists, K(t+2) when step t+2 does
     wait_groups((has1 ? 2 : 0) + (has2 ? 1 : 0));
     // ---- O^T[n] += V^T[n] . P^T, four d-tiles (8 transposed reads) per wait -------------------

@@ -233,10 +233,9 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
           if (kb + 16 + r > qpos) v[2 + (r >> 1)][r & 1] = -INFINITY;
         }
       }
-      float mx = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1])),
-                       fmaxf(fmaxf(v[2][0], v[2][1]), fmaxf(v[3][0], v[3][1])));
+      float mx = max3f(max3f(v[0][0], v[0][1], v[1][0]), max3f(v[1][1], v[2][0], v[2][1]), max2f(v[3][0], v[3][1]));
       mx = rows_allreduce_max(mx);
-      const float m_new = fmaxf(m[c], mx * p.scale_log2e);  // scale > 0: max commutes with it
+      const float m_new = max2f(m[c], mx * p.scale_log2e);  // scale > 0: max commutes with it
       if (__any(m_new != m[c])) {
         const float alpha = fast_exp2(m[c] - m_new);
         m[c] = m_new;
