@@ -1,8 +1,8 @@
 """Per-phase timing of the prefill kernel from the timing build (`make -C vllm-omni_amd/csrc dbg`).
 
-The kernel accumulates s_memtime deltas (100 MHz ticks) per wave of workgroup (0,0,0) — the LONGEST tile
-(tiles are dispatched longest first) — for the phases: 7 vmcnt wait, 0 barrier, 1 DMA issue, 2 K reads, 3 QK^T MFMA
-issue, 4 V reads, 5 softmax, 6 PV MFMA issue.
+The kernel accumulates s_memrealtime deltas (100 MHz ticks) per wave of workgroup (0,0,0) — the LONGEST
+tile (tiles are dispatched longest first): vmcnt wait (my DMA share of the stage landed), barrier, DMA
+issue, compute (K reads, QK^T, V reads, softmax, PV).  Reported as mean ns per 32-key step.
 """
 import ctypes
 import os
@@ -44,16 +44,16 @@ def main():
     run()
     e1.record()
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 160)()
+    buf = (ctypes.c_ulonglong * 128)()
     assert lib.mi_debug_prefill_ticks(buf) == 0
     print(f"kernel {e0.elapsed_time(e1) * 1e3:.1f} us")
-    names = ["barrier", "dma issue", "Kread+QK||softmax", "Vread+PV", "loop tail", "vmcnt wait", "-", "-"]
+    names = ["vmcnt wait", "barrier", "dma issue", "compute"]
     for w in range(8):
-        row = [buf[w * 10 + i] for i in range(10)]
-        steps = row[9]
+        row = [buf[w * 8 + i] for i in range(8)]
+        steps = row[7]
         if not steps:
             continue
-        tot = sum(row[:8])
+        tot = sum(row[:4])
         print(f"wave {w}: steps={steps} total={tot * 10 / 1e3:.1f} us | " +
               " ".join(f"{n}={row[i] * 10 / steps:.0f}ns" for i, n in enumerate(names)))
 

@@ -47,6 +47,24 @@ struct PrefillParams {
 
 constexpr int kColTile = 16;  // query tokens per MFMA column tile
 
+// Phase timing for tools/debug_prefill_timing.py: compiled only with -DMI_PREFILL_TIMING (`make dbg`
+// builds a separate library), never in the product library.  Workgroup (0,0,0) — the longest tile —
+// accumulates s_memrealtime deltas (100 MHz) per wave: 0 vmcnt wait, 1 barrier, 2 DMA issue, 3 compute.
+// A sample costs ~50 ns and orders only against instruction ISSUE (an MFMA still in the pipe is not waited for).
+#ifdef MI_PREFILL_TIMING
+}  // namespace
+__device__ unsigned long long mi_prefill_ticks[16][8];
+namespace {
+#define MI_TICK(i)                                                       \
+  do {                                                                   \
+    const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();    \
+    tacc[i] += now_ - tprev;                                             \
+    tprev = now_;                                                        \
+  } while (0)
+#else
+#define MI_TICK(i) do { } while (0)
+#endif
+
 // waves per workgroup = query heads per KV head handled together; NI = waves that issue DMA;
 // NC = column tiles (of 16 query tokens) per wave.
 template <typename Tag, int HD, int NI, int NC>
@@ -273,12 +291,20 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
+#ifdef MI_PREFILL_TIMING
+  unsigned long long tacc[4] = {0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
+#endif
   auto step = [&](int t, auto stc) {
     constexpr int ST = decltype(stc)::value;
     if (t + 1 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
+    MI_TICK(0);
     __builtin_amdgcn_s_barrier();
+    MI_TICK(1);
     if (t + 2 < t_end) issue(t + 2, (ST + 2) % NSTAGE);
+    MI_TICK(2);
     compute(t, stc);
+    MI_TICK(3);
   };
   issue(0, 0);
   if (1 < t_end) issue(1, 1);
@@ -288,6 +314,13 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     if (t + 2 < t_end) step(t + 2, S2{});
   }
 
+#ifdef MI_PREFILL_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mi_prefill_ticks[wid][i] = tacc[i];
+    mi_prefill_ticks[wid][7] = (unsigned long long)t_end;
+  }
+#endif
   // ---- epilogue: O^T -> out[token][head][dim] -----------------------------------------------------
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -336,6 +369,12 @@ int launch_prefill(const PrefillParams& p, int num_kv_heads, int max_query_len, 
 
 }  // namespace
 }  // namespace mi
+
+#ifdef MI_PREFILL_TIMING
+extern "C" int mi_debug_prefill_ticks(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mi::mi_prefill_ticks), sizeof(unsigned long long) * 16 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
                                      const int32_t* block_table, const int32_t* seq_lens,
