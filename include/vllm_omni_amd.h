@@ -195,6 +195,31 @@ int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_
                           void* stream);
 
 /* ------------------------------------------------------------------------
+ * N2 — device-side sampler.  Replaces the sampler call of
+ * vllm_omni/worker/gpu_ar_model_runner.py:626-657 (upstream vLLM v0.19
+ * `Sampler`: penalties -> temperature -> top-k/top-p -> random_sample) for
+ * the talker loop; shipped stage config: T 0.9, top_p 0.8, top_k 40,
+ * repetition_penalty 1.05 (platforms/rocm/stage_configs/qwen2_5_omni.yaml:51-59).
+ * One launch, one workgroup per row, row in LDS (vocab <= 16368):
+ *   v = logits[r, :]; seen tokens: v = v > 0 ? v / rep : v * rep; v /= T
+ *   top-k: keep v >= k-th largest (ties kept);  p = softmax(v)
+ *   top-p: keep an element while the mass of strictly larger p is < top_p
+ *          (elements tied with the last kept value are all kept)
+ *   ids[r] = argmax_i p_i / -ln(u_i), u_i = (Philox4x32-10(ctr = {i, 0,
+ *            offset_lo, offset_hi}, key = seed)[0] >> 8 + 0.5) / 2^24
+ *   T == 0: ids[r] = first index of the maximum of the penalised logits.
+ * Per-row arrays are device pointers; top_k / top_p / rep_penalty / seen_* may
+ * be NULL (off).  seen_bitmap[seen_row[r]] is the request's prompt+output
+ * token set (bit i of word i/32); update_seen != 0 sets the drawn id's bit.
+ * logits are not modified.  ids int64.
+ * ---------------------------------------------------------------------- */
+int mi_sample_tokens(int64_t* ids, const void* logits, int32_t num_rows, int32_t vocab,
+                     int64_t row_stride, int logits_dtype, const float* temperature,
+                     const int32_t* top_k, const float* top_p, const float* rep_penalty,
+                     uint32_t* seen_bitmap, const int32_t* seen_row, int32_t bitmap_words_per_row,
+                     int32_t update_seen, const uint64_t* seed, const uint64_t* offset, void* stream);
+
+/* ------------------------------------------------------------------------
  * A11 — talker per-step input embedding, batched:
  *   out[t] = embed_table[token_ids[t]] (+ reply_rows[reply_idx[t]] when reply_idx[t] >= 0)
  * i.e. `thinker_reply_part[0:1] + embed_input_ids(last token)` of

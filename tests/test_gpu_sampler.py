@@ -1,0 +1,125 @@
+"""GPU parity: device sampler (mi_sample_tokens) vs oracle/ref_sampler.py through the C ABI.
+
+Integer result (a token id): compared exactly, except on rows the float64 oracle itself flags as a coin flip
+in the last ulp — a top-p decision within 1e-5 (relative) of the threshold or an exponential race whose two
+best scores are within 1e-4 of each other (the kernel uses fp32 `__expf` / `__logf`).  Such rows must still
+land on a token the oracle keeps, and there must be few of them.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_sampler
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, logits, temperature, top_k, top_p, rep, bitmap, seen_row, seed, offset, update=True):
+    from vllm_omni_amd import ops
+
+    t = lambda a, dt: None if a is None else torch.as_tensor(np.asarray(a), dtype=dt).to(dev)  # noqa: E731
+    bm = None if bitmap is None else torch.as_tensor(bitmap.astype(np.int64).astype(np.uint32).view(np.int32)).to(dev)
+    ids = ops.sample_tokens(logits.to(dev), t(temperature, torch.float32), t(seed, torch.int64), t(offset, torch.int64),
+                            top_k=t(top_k, torch.int32), top_p=t(top_p, torch.float32), rep_penalty=t(rep, torch.float32),
+                            seen_bitmap=bm, seen_row=t(seen_row, torch.int32), update_seen=update)
+    torch.cuda.synchronize()
+    return ids.cpu().numpy(), (None if bm is None else bm.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("vocab", [8448, 3072, 1000])
+def test_sampler_matches_oracle(dev, vocab, dtype):
+    rng = np.random.default_rng(vocab)
+    n = 96
+    logits = torch.from_numpy((rng.standard_normal((n, vocab)) * 3).astype(np.float32)).to(dtype)
+    logits[:, 5:9] = -1e9 if dtype != torch.float16 else float("-inf")       # bad-word mask already applied upstream
+    lf = logits.float().numpy()
+    temperature = rng.choice([0.0, 0.5, 0.9, 1.3], size=n).astype(np.float32)
+    top_k = rng.choice([0, 1, 5, 40, vocab + 3], size=n).astype(np.int32)
+    top_p = rng.choice([1.0, 0.95, 0.8, 0.3], size=n).astype(np.float32)
+    rep = rng.choice([1.0, 1.05, 1.5], size=n).astype(np.float32)
+    words = (vocab + 31) // 32
+    bitmap = rng.integers(0, 2**32, size=(n + 3, words), dtype=np.uint64).astype(np.uint32)
+    bitmap &= rng.integers(0, 2**32, size=bitmap.shape, dtype=np.uint64).astype(np.uint32)  # ~25 % of tokens seen
+    seen_row = rng.permutation(n + 3)[:n].astype(np.int32)
+    seed = rng.integers(0, 2**63, size=n, dtype=np.int64)
+    offset = rng.integers(0, 2**40, size=n, dtype=np.int64)
+    got, bm_after = _run(dev, logits, temperature, top_k, top_p, rep, bitmap, seen_row, seed, offset)
+    ref, margins = ref_sampler.sample(lf, temperature, top_k, top_p, rep, bitmap, seen_row, seed, offset)
+    flips = 0
+    for r in range(n):
+        if got[r] == ref[r]:
+            continue
+        m = margins[r]
+        assert m["topp_gap"] < 1e-5 or m["race_ratio"] < 1 + 1e-4, (r, int(got[r]), int(ref[r]), m, float(temperature[r]),
+                                                                      int(top_k[r]), float(top_p[r]))
+        flips += 1
+    assert flips <= 2, flips
+    # the drawn token is recorded in the request's seen set, nothing else changes
+    expect = bitmap.copy()
+    for r in range(n):
+        expect[seen_row[r], got[r] >> 5] |= np.uint32(1 << (int(got[r]) & 31))
+    assert np.array_equal(bm_after, expect)
+
+
+def test_sampler_draw_frequencies_follow_the_kept_distribution(dev):
+    """Size-independent property: over many draw offsets the empirical frequencies of the exponential race
+    equal the renormalised top-k/top-p distribution (chi-square, 5 sigma)."""
+    vocab, n = 3072, 4096
+    rng = np.random.default_rng(7)
+    row = (rng.standard_normal(vocab) * 2.5).astype(np.float32)
+    logits = torch.from_numpy(np.tile(row, (n, 1)))
+    temperature = np.full(n, 0.9, np.float32)
+    top_k = np.full(n, 40, np.int32)
+    top_p = np.full(n, 0.8, np.float32)
+    seed = np.full(n, 1234, np.int64)
+    offset = np.arange(n, dtype=np.int64)
+    got, _ = _run(dev, logits, temperature, top_k, top_p, None, None, None, seed, offset)
+    v = row.astype(np.float64) / 0.9
+    kth = np.sort(v)[-40]
+    v[v < kth] = -np.inf
+    p = np.exp(v - v.max())
+    p /= p.sum()
+    order = np.argsort(-p)
+    before = np.cumsum(p[order]) - p[order]
+    kept = order[before < 0.8]
+    q = p[kept] / p[kept].sum()
+    assert set(np.unique(got)) <= set(kept.tolist())
+    counts = np.array([(got == i).sum() for i in kept])
+    chi2 = ((counts - n * q) ** 2 / (n * q)).sum()
+    dof = len(kept) - 1
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+
+
+def test_sampler_reproducible_and_edge_cases(dev):
+    from vllm_omni_amd import _C, ops
+
+    vocab, n = 1000, 8
+    rng = np.random.default_rng(3)
+    logits = torch.from_numpy(rng.standard_normal((n, vocab)).astype(np.float32))
+    temperature = np.full(n, 1.0, np.float32)
+    seed = np.arange(n, dtype=np.int64)
+    offset = np.zeros(n, np.int64)
+    a, _ = _run(dev, logits, temperature, None, None, None, None, None, seed, offset)
+    b, _ = _run(dev, logits, temperature, None, None, None, None, None, seed, offset)
+    c, _ = _run(dev, logits, temperature, None, None, None, None, None, seed, offset + 1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)            # same (seed, offset) -> same draw
+    # top_k = 1 and top_p -> 0 are greedy whatever the noise; T = 0 ignores top-k/top-p
+    g = logits.argmax(-1).numpy()
+    k1, _ = _run(dev, logits, temperature, np.ones(n, np.int32), None, None, None, None, seed, offset)
+    p0, _ = _run(dev, logits, temperature, None, np.full(n, 1e-6, np.float32), None, None, None, seed, offset)
+    t0, _ = _run(dev, logits, np.zeros(n, np.float32), np.full(n, 5, np.int32), np.full(n, 0.5, np.float32), None, None,
+                 None, seed, offset)
+    assert np.array_equal(k1, g) and np.array_equal(p0, g) and np.array_equal(t0, g)
+    # zero rows: no launch; oversize vocabulary and CPU tensors are refused, nothing falls back
+    empty = ops.sample_tokens(torch.empty(0, vocab, device=dev), torch.empty(0, device=dev),
+                              torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.int64, device=dev))
+    assert empty.numel() == 0
+    big = torch.zeros(1, 20000, device=dev)
+    one = lambda dt: torch.zeros(1, dtype=dt, device=dev)  # noqa: E731
+    with pytest.raises(_C.MIError) as ei:
+        ops.sample_tokens(big, one(torch.float32), one(torch.int64), one(torch.int64))
+    assert ei.value.code == _C.MI_ERR_UNSUPPORTED
+    with pytest.raises(RuntimeError):
+        ops.sample_tokens(torch.zeros(1, 10), torch.zeros(1), torch.zeros(1, dtype=torch.int64),
+                          torch.zeros(1, dtype=torch.int64))

@@ -268,3 +268,70 @@ def test_prefill_then_mixed_batch_matches_oracle(dev):
     top2 = logits.topk(2, -1).values
     conf = (top2[:, 0] - top2[:, 1]) > 0.05
     assert torch.equal(got_ids[conf], ids[conf])
+
+
+def test_runner_samples_on_device_like_the_oracle(dev):
+    """N2 through the runner: per-request temperature / top-k / top-p / repetition penalty / seed; the drawn ids
+    equal the sampler oracle applied to the step's masked logits, draw counter = tokens generated so far, the
+    seen set = prompt + generated tokens."""
+    import numpy as np
+
+    from oracle import ref_sampler
+    from vllm_omni_amd.kv_cache import KVCacheManager
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, Request, SamplingParams, SchedulerOutput
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_talker")
+    bs, nb = 16, 32
+    runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=4, max_model_len=128, max_num_batched_tokens=64,
+                              block_size=bs, enforce_eager=True, seed=0)
+    runner.load_model()
+    runner.initialize_kv_cache(nb)
+    mgr = KVCacheManager(nb, bs)
+    sps = [SamplingParams(temperature=0.9, top_k=40, top_p=0.8, repetition_penalty=1.05, seed=123),
+           SamplingParams(temperature=0.0),
+           SamplingParams(temperature=1.2, repetition_penalty=1.3)]          # seed derived from the request id
+    reqs = [Request(f"s{i}", list(range(3 + i, 12 + 2 * i)), sp) for i, sp in enumerate(sps)]
+    outs = {r.request_id: [] for r in reqs}
+    for step in range(4):
+        sched = {}
+        for r in reqs:
+            n = len(r.prompt_token_ids) if step == 0 else 1
+            assert mgr.allocate_slots(r, n) is not None
+            sched[r.request_id] = n
+        if step == 0:
+            so = SchedulerOutput(scheduled_new_reqs=[NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params,
+                                                                    mgr.get_block_ids(r.request_id), 0) for r in reqs],
+                                 num_scheduled_tokens=sched, total_num_scheduled_tokens=sum(sched.values()))
+        else:
+            cached = CachedRequestData(req_ids=[r.request_id for r in reqs], new_token_ids=[],
+                                       new_block_ids=[mgr.get_block_ids(r.request_id) if False else None for r in reqs],
+                                       num_computed_tokens=[r.num_computed_tokens for r in reqs],
+                                       num_output_tokens=[len(outs[r.request_id]) for r in reqs])
+            so = SchedulerOutput(scheduled_cached_reqs=cached, num_scheduled_tokens=sched,
+                                 total_num_scheduled_tokens=len(reqs))
+        runner.execute_model(so)
+        n = len(reqs)
+        logits = runner.execute_model_state.logits[:n].float().cpu().numpy()
+        order = list(runner.input_batch.req_ids[:n])
+        out = runner.sample_tokens()
+        for row, rid in enumerate(order):
+            r = next(q for q in reqs if q.request_id == rid)
+            sp = r.sampling_params
+            seen = np.zeros(cfg.vocab_size, dtype=bool)
+            seen[np.asarray(r.prompt_token_ids + outs[rid])] = True
+            seed = sp.seed if sp.seed is not None else runner.requests[rid].sample_seed
+            want, m = ref_sampler.sample_row(logits[row], sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty,
+                                             seen if sp.repetition_penalty != 1.0 else None, seed, len(outs[rid]))
+            got = out.sampled_token_ids[out.req_id_to_index[rid]][0]
+            assert got == want or m["topp_gap"] < 1e-5 or m["race_ratio"] < 1 + 1e-4, (step, rid, got, want, m)
+            outs[rid].append(got)
+        for r in reqs:
+            r.num_computed_tokens += sched[r.request_id]
+    # sampled rows differ from greedy ones at least once; the bitmap holds prompt + outputs of penalised requests
+    st0 = runner.requests["s0"]
+    words = runner.sampling_state.bitmap[st0.seen_slot].cpu().numpy().view(np.uint32)
+    have = {i for i in range(cfg.vocab_size) if (words[i >> 5] >> (i & 31)) & 1}
+    assert have == set(reqs[0].prompt_token_ids) | set(outs["s0"])
+    assert runner.requests["s1"].seen_slot == -1

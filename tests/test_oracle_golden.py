@@ -14,7 +14,7 @@ from types import SimpleNamespace
 import pytest
 import torch
 
-from oracle import ref_ops, ref_talker
+from oracle import ref_ops, ref_sampler, ref_talker
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -190,3 +190,43 @@ def test_int8_scheme_saturation_and_scales():
     # error bound: each of the K products is off by at most (|x| dw + |w| dx), dx = sx/2, dw = sw/2
     bound = (x.abs() @ (ws.view(-1, 1) / 2).expand_as(w).t()) + ((s.view(-1, 1) / 2).expand_as(x) @ w.abs().t())
     assert ((y - x @ w.t()).abs() <= bound * 1.01 + 1e-6).all()
+
+
+# ------------------------------------------------------------------ sampler oracle (N2)
+def test_philox4x32_10_known_answer_vectors():
+    """Random123's kat_vectors for philox4x32-10 (Salmon et al. 2011): zero, all-ones, digits of pi."""
+    import numpy as np
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+            (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for ctr, key, want in kat:
+        got = ref_sampler.philox4x32_10(ctr, key)
+        assert tuple(int(x) for x in got) == want
+    u = ref_sampler.uniform_noise(4096, seed=11, offset=2**40 + 5)
+    assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.03 and len(np.unique(u)) > 4000
+
+
+def test_sampler_oracle_semantics():
+    """The rules upstream's `apply_penalties` / `apply_top_k_top_p` / `random_sample` state, one case each."""
+    import numpy as np
+
+    lg = np.array([2.0, 1.0, 1.0, -1.0, 0.5], dtype=np.float32)
+    assert ref_sampler.sample_row(lg, 0.0)[0] == 0                                   # greedy, first maximum
+    assert ref_sampler.sample_row(np.array([1.0, 3.0, 3.0], np.float32), 0.0)[0] == 1
+    seen = np.array([True, False, False, True, False])
+    # repetition penalty: positive logits divided, negative multiplied, unseen untouched -> 1.0 wins over 2/4
+    assert ref_sampler.sample_row(lg, 0.0, rep_penalty=4.0, seen=seen)[0] == 1
+    # top-k keeps ties with the k-th value: k = 2 keeps {0, 1, 2}; draws never leave that set
+    ids = {ref_sampler.sample_row(lg, 1.0, top_k=2, seed=1, offset=o)[0] for o in range(400)}
+    assert ids == {0, 1, 2}
+    # top-p keeps an element while the mass ranked before it is < p, at least one
+    assert {ref_sampler.sample_row(lg, 1.0, top_p=1e-9, seed=1, offset=o)[0] for o in range(50)} == {0}
+    p = np.exp(lg.astype(np.float64)); p /= p.sum()
+    ids = {ref_sampler.sample_row(lg, 1.0, top_p=float(p[0]) + 1e-6, seed=2, offset=o)[0] for o in range(600)}
+    assert ids == {0, 1, 2}                                                            # the tied pair enters together
+    # the exponential race is an exact sampler: frequencies follow p
+    draws = np.array([ref_sampler.sample_row(lg, 1.0, seed=5, offset=o)[0] for o in range(4000)])
+    freq = np.bincount(draws, minlength=5) / 4000
+    assert np.abs(freq - p).max() < 0.03

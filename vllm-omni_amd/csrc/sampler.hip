@@ -1,0 +1,226 @@
+// N2 — device-side sampler for the talker loop: repetition penalty, temperature, top-k,
+// top-p and the random draw in ONE launch, one 256-thread workgroup per logits row held in LDS as fp32.
+//
+// Replaces the sampler call of the reference's runner, `self.sampler(logits=..., sampling_metadata=...)`
+// at vllm_omni/worker/gpu_ar_model_runner.py:626-657 — upstream vLLM v0.19 `Sampler`: penalties
+// (`apply_penalties`: logit > 0 ? logit / r : logit * r for tokens seen in prompt or output) -> temperature
+// -> `apply_top_k_top_p` (top-k keeps every value >= the k-th largest; top-p keeps an element while the
+// probability mass ranked before it is < p, always at least one) -> `random_sample` (probs / Exp(1) noise,
+// argmax).  The shipped talker stage samples with T = 0.9, top_p = 0.8, top_k = 40, repetition_penalty =
+// 1.05 (vllm_omni/platforms/rocm/stage_configs/qwen2_5_omni.yaml:51-59).
+//
+// No sort: both cut-offs are found by bisection over the order-preserving integer key of the fp32 values
+// (32 block-wide counts each), which is exact for top-k (ties with the k-th value are kept, as upstream's
+// `logits_sort < kth` mask does) and, for top-p, keeps every element tied with the last kept VALUE (upstream
+// breaks such ties by sort position, i.e. arbitrarily).  The draw is the exponential race upstream uses:
+// id = argmax_i p_i / q_i, q_i = -ln(u_i), with u_i from Philox4x32-10 keyed by the request's seed and
+// counted by (column, draw offset) — reproducible, independent of launch shape, restated bit for bit by
+// oracle/ref_sampler.py.  Rows with temperature == 0 take the first index of the maximum (greedy).
+#include "common.h"
+
+namespace mi {
+namespace {
+
+struct SamplerParams {
+  int64_t* ids;
+  const void* logits;
+  int64_t row_stride;
+  int32_t vocab;
+  const float* temperature;   // [rows]
+  const int32_t* top_k;       // [rows] or null; <= 0 or >= vocab: off
+  const float* top_p;         // [rows] or null; >= 1: off
+  const float* rep_penalty;   // [rows] or null; 1: off
+  uint32_t* seen;             // [state rows][words_per_row] bitmap of prompt + output tokens, or null
+  const int32_t* seen_row;    // [rows] state row of each logits row, or null (= row)
+  int32_t words_per_row;
+  int32_t update_seen;
+  const uint64_t* seed;       // [rows]
+  const uint64_t* offset;     // [rows] draw counter of the request
+};
+
+// order-preserving map fp32 -> uint32 (larger float <=> larger key; -0 < +0)
+__device__ __forceinline__ uint32_t fkey(float f) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+// Philox4x32-10 (Salmon et al., SC'11), first output word
+__device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
+struct BlockReduce {
+  float* fbuf;     // [4]
+  uint32_t* ubuf;  // [4]
+  __device__ __forceinline__ float sum(float v) {
+    v = wave_allreduce_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) fbuf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (fbuf[0] + fbuf[1]) + (fbuf[2] + fbuf[3]);
+  }
+  __device__ __forceinline__ float max(float v) {
+    v = wave_allreduce_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) fbuf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(fbuf[0], fbuf[1]), fmaxf(fbuf[2], fbuf[3]));
+  }
+  __device__ __forceinline__ uint32_t count(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ubuf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ubuf[0] + ubuf[1] + ubuf[2] + ubuf[3];
+  }
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
+  scalar_cache_acquire();
+  extern __shared__ float vals[];  // [vocab] then 4 floats + 4 uints + 2 ints
+  float* fbuf = vals + p.vocab;
+  uint32_t* ubuf = reinterpret_cast<uint32_t*>(fbuf + 4);
+  int* ibuf = reinterpret_cast<int*>(ubuf + 4);
+  BlockReduce red{fbuf, ubuf};
+  const int row = blockIdx.x, tid = threadIdx.x, V = p.vocab;
+  const float T = p.temperature[row];
+  const float pen = p.rep_penalty ? p.rep_penalty[row] : 1.f;
+  const int srow = p.seen_row ? p.seen_row[row] : row;
+  uint32_t* seen = p.seen ? p.seen + (int64_t)srow * p.words_per_row : nullptr;
+  const float invT = T > 0.f ? 1.f / T : 1.f;
+
+  // 1. load -> penalty -> temperature, fp32 in LDS
+  for (int i = tid; i < V; i += 256) {
+    float v;
+    if constexpr (DT == MI_DTYPE_F32) v = reinterpret_cast<const float*>(p.logits)[row * p.row_stride + i];
+    else if constexpr (DT == MI_DTYPE_BF16)
+      v = Elem<bf16_tag>::from_bits(reinterpret_cast<const uint16_t*>(p.logits)[row * p.row_stride + i]);
+    else v = Elem<f16_tag>::from_bits(reinterpret_cast<const uint16_t*>(p.logits)[row * p.row_stride + i]);
+    if (seen && pen != 1.f && ((seen[i >> 5] >> (i & 31)) & 1u)) v = v > 0.f ? v / pen : v * pen;
+    vals[i] = v * invT;
+  }
+  __syncthreads();
+
+  int best_i = 0x7fffffff;
+  float best_s = -INFINITY;
+  if (T > 0.f) {
+    // 2. top-k: key of the k-th largest value, built bit by bit (largest tau with count(key >= tau) >= k)
+    const int k = p.top_k ? p.top_k[row] : 0;
+    if (k > 0 && k < V) {
+      uint32_t tau = 0;
+      for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = tau | (1u << b);
+        uint32_t c = 0;
+        for (int i = tid; i < V; i += 256) c += fkey(vals[i]) >= cand;
+        if (red.count(c) >= (uint32_t)k) tau = cand;
+      }
+      for (int i = tid; i < V; i += 256)
+        if (fkey(vals[i]) < tau) vals[i] = -INFINITY;
+      __syncthreads();
+    }
+    // 3. softmax (probabilities replace the logits in LDS)
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, vals[i]);
+    mx = red.max(mx);
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) {
+      const float e = __expf(vals[i] - mx);
+      vals[i] = e;
+      s += e;
+    }
+    s = red.sum(s);
+    const float inv = 1.f / s;
+    // 4. top-p: smallest key c with mass(prob key > c) < top_p; keep prob keys >= c (binary search)
+    const float tp = p.top_p ? p.top_p[row] : 1.f;
+    uint32_t cut = 0;
+    if (tp < 1.f) {
+      uint32_t lo = 0, hi = 0xffffffffu;
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        float m = 0.f;
+        for (int i = tid; i < V; i += 256) {
+          const float pr = vals[i] * inv;
+          if (fkey(pr) > mid) m += pr;
+        }
+        if (red.sum(m) < tp) hi = mid; else lo = mid + 1;
+      }
+      cut = lo;
+    }
+    // 5. exponential race over the survivors
+    const uint64_t sd = p.seed[row], off = p.offset[row];
+    for (int i = tid; i < V; i += 256) {
+      const float pr = vals[i] * inv;
+      if (pr > 0.f && fkey(pr) >= cut) {
+        const uint32_t x = philox_first((uint32_t)i, 0u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)sd,
+                                        (uint32_t)(sd >> 32));
+        const float u = ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1), 24 bits
+        const float sc = pr / -__logf(u);
+        if (sc > best_s || (sc == best_s && i < best_i)) { best_s = sc; best_i = i; }
+      }
+    }
+  } else {
+    for (int i = tid; i < V; i += 256) {
+      const float v = vals[i];
+      if (v > best_s || (v == best_s && i < best_i)) { best_s = v; best_i = i; }
+    }
+  }
+  // block argmax, first index on ties
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float os = __shfl_xor(best_s, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    if (os > best_s || (os == best_s && oi < best_i)) { best_s = os; best_i = oi; }
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { fbuf[tid >> 6] = best_s; ibuf[tid >> 6] = best_i; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (fbuf[w] > best_s || (fbuf[w] == best_s && ibuf[w] < best_i)) { best_s = fbuf[w]; best_i = ibuf[w]; }
+    if (best_i == 0x7fffffff) best_i = 0;  // a row of NaNs
+    p.ids[row] = best_i;
+    if (seen && p.update_seen) atomicOr(&seen[best_i >> 5], 1u << (best_i & 31));
+  }
+}
+
+}  // namespace
+}  // namespace mi
+
+extern "C" int mi_sample_tokens(int64_t* ids, const void* logits, int32_t num_rows, int32_t vocab,
+                                int64_t row_stride, int logits_dtype, const float* temperature,
+                                const int32_t* top_k, const float* top_p, const float* rep_penalty,
+                                uint32_t* seen_bitmap, const int32_t* seen_row, int32_t bitmap_words_per_row,
+                                int32_t update_seen, const uint64_t* seed, const uint64_t* offset, void* stream) {
+  using namespace mi;
+  if (num_rows == 0) return MI_OK;
+  if (!ids || !logits || !temperature || !seed || !offset || num_rows < 0 || vocab <= 0 || row_stride < vocab)
+    return MI_ERR_INVALID_ARG;
+  if (vocab > 16368) return MI_ERR_UNSUPPORTED;  // the fp32 row lives in 64 KB of LDS (talker vocabularies: 3072 / 8448)
+  if (seen_bitmap && bitmap_words_per_row * 32 < vocab) return MI_ERR_INVALID_ARG;
+  SamplerParams p{ids, logits, row_stride, vocab, temperature, top_k, top_p, rep_penalty, seen_bitmap, seen_row,
+                  bitmap_words_per_row, update_seen, seed, offset};
+  const size_t lds = (size_t)vocab * 4 + 64;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(num_rows), block(256);
+  switch (logits_dtype) {
+    case MI_DTYPE_F32: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_F32>), grid, block, lds, s, p); break;
+    case MI_DTYPE_BF16: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_BF16>), grid, block, lds, s, p); break;
+    case MI_DTYPE_F16: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_F16>), grid, block, lds, s, p); break;
+    default: return MI_ERR_UNSUPPORTED;
+  }
+  return launch_status();
+}

@@ -46,10 +46,76 @@ class CachedRequestState:
     output_token_ids: list[int] = field(default_factory=list)
     prompt_embeds: Optional[torch.Tensor] = None          # [prompt_len, E] talker prefill embeddings
     additional_information: Optional[dict] = None
+    sample_seed: int = 0                                  # Philox key of the request's draws
+    seen_slot: int = -1                                   # row of the device seen-token bitmap, -1 = none
 
     @property
     def num_tokens(self) -> int:
         return len(self.prompt_token_ids) + len(self.output_token_ids)
+
+
+class SamplingState:
+    """Per-request state of the device sampler (ops.sample_tokens): the Philox key, the draw
+    counter (= number of tokens drawn so far) and, for requests with a repetition penalty, a row of the
+    device bitmap of prompt + output tokens (the sampler sets the drawn token's bit itself).  Mirrors what
+    upstream keeps in `SamplingMetadata` (`prompt_token_ids`, `output_token_ids`, per-request generators) for
+    the sampler call at vllm_omni/worker/gpu_ar_model_runner.py:626-657."""
+
+    def __init__(self, max_num_reqs: int, vocab: int, device, base_seed: int):
+        from .block_table import CpuGpuBuffer
+
+        self.vocab, self.words = vocab, (vocab + 31) // 32
+        self.base_seed = int(base_seed or 0)
+        self.free_slots = list(range(max_num_reqs - 1, -1, -1))
+        self.scratch_slot = max_num_reqs                      # rows without a penalty record their draws here
+        self.bitmap = torch.zeros(max_num_reqs + 1, self.words, dtype=torch.int32, device=device)
+        mk = lambda dt: CpuGpuBuffer(max_num_reqs, dtype=dt, device=device)  # noqa: E731
+        self.temperature, self.top_p, self.rep = mk(torch.float32), mk(torch.float32), mk(torch.float32)
+        self.top_k, self.seen_row = mk(torch.int32), mk(torch.int32)
+        self.seed, self.offset = mk(torch.int64), mk(torch.int64)
+
+    def add(self, st: CachedRequestState) -> None:
+        sp = st.sampling_params
+        if sp.seed is not None:
+            st.sample_seed = int(sp.seed) & (2**63 - 1)
+        else:  # stable across runs and processes (str hash is salted): FNV-1a of the request id
+            h = 0xCBF29CE484222325 ^ self.base_seed
+            for ch in st.req_id.encode():
+                h = ((h ^ ch) * 0x100000001B3) & (2**64 - 1)
+            st.sample_seed = h & (2**63 - 1)
+        if sp.repetition_penalty != 1.0 and st.seen_slot < 0 and self.free_slots:
+            st.seen_slot = self.free_slots.pop()
+            row = np.zeros(self.words, dtype=np.uint32)
+            toks = np.asarray(list(st.prompt_token_ids) + list(st.output_token_ids), dtype=np.int64)
+            toks = toks[(toks >= 0) & (toks < self.vocab)]
+            np.bitwise_or.at(row, toks >> 5, (np.uint32(1) << (toks & 31).astype(np.uint32)))
+            self.bitmap[st.seen_slot].copy_(torch.from_numpy(row.view(np.int32)))
+
+    def remove(self, st: Optional[CachedRequestState]) -> None:
+        if st is not None and st.seen_slot >= 0:
+            self.free_slots.append(st.seen_slot)
+            st.seen_slot = -1
+
+    @staticmethod
+    def needed(params: list[SamplingParams]) -> bool:
+        return any(p.temperature > 0 or p.repetition_penalty != 1.0 for p in params)
+
+    def sample(self, logits: torch.Tensor, states: list[CachedRequestState], ids: torch.Tensor) -> torch.Tensor:
+        n = len(states)
+        for i, st in enumerate(states):
+            sp = st.sampling_params
+            self.temperature.np[i] = max(sp.temperature, 0.0)
+            self.top_p.np[i] = sp.top_p
+            self.rep.np[i] = sp.repetition_penalty if st.seen_slot >= 0 else 1.0
+            self.top_k.np[i] = sp.top_k
+            self.seen_row.np[i] = st.seen_slot if st.seen_slot >= 0 else self.scratch_slot
+            self.seed.np[i] = st.sample_seed
+            self.offset.np[i] = len(st.output_token_ids)
+        return ops.sample_tokens(logits[:n], self.temperature.copy_to_gpu(n), self.seed.copy_to_gpu(n),
+                                 self.offset.copy_to_gpu(n), top_k=self.top_k.copy_to_gpu(n),
+                                 top_p=self.top_p.copy_to_gpu(n), rep_penalty=self.rep.copy_to_gpu(n),
+                                 seen_bitmap=self.bitmap, seen_row=self.seen_row.copy_to_gpu(n), update_seen=True,
+                                 ids=ids[:n])
 
 
 class InputBatch:
@@ -182,6 +248,7 @@ class GPUARModelRunner:
         self.copy_done = torch.cuda.Event() if on_gpu else None
         self._decode_ws: Optional[torch.Tensor] = None
         self._decode_part = 0
+        self.sampling_state: Optional[SamplingState] = None   # built with the model (needs the vocabulary size)
 
     # -------------------------------------------------------------------- model
     def load_model(self) -> None:
@@ -190,6 +257,8 @@ class GPUARModelRunner:
 
             self.tuned_gemms = enable_tuned_gemms()
         self.model = Qwen2_5OmniTalkerForConditionalGeneration(self.config, self.dtype, self.device, self.seed)
+        if torch.device(self.device).type == "cuda" and self.config.vocab_size <= 16368:
+            self.sampling_state = SamplingState(self.max_num_reqs, self.config.vocab_size, self.device, self.seed or 0)
         if self.max_reply_rows:
             self._reply_pool = torch.zeros(self.max_reply_rows, self.config.embedding_size, dtype=self.dtype,
                                            device=self.device)
@@ -226,7 +295,9 @@ class GPUARModelRunner:
     def _update_states(self, so: SchedulerOutput) -> None:
         ib = self.input_batch
         for rid in so.finished_req_ids:
-            self.requests.pop(rid, None)
+            st = self.requests.pop(rid, None)
+            if self.sampling_state is not None:
+                self.sampling_state.remove(st)
             ib.remove_request(rid)
         if so.new_block_ids_to_zero:
             self._zero_block_ids(so.new_block_ids_to_zero)
@@ -242,6 +313,8 @@ class GPUARModelRunner:
                                     tuple(list(b) for b in nr.block_ids), nr.num_computed_tokens,
                                     prompt_embeds=nr.prompt_embeds, additional_information=nr.additional_information)
             self.requests[nr.req_id] = st
+            if self.sampling_state is not None:
+                self.sampling_state.add(st)
             to_add.append(st)
 
         for i, rid in enumerate(cached.req_ids):
@@ -496,10 +569,14 @@ class GPUARModelRunner:
         ib = self.input_batch
         n = st.num_reqs
         ids = st.sampled_ids
-        # non-greedy requests: temperature / top-k / top-p on the masked logits
-        params = [self.requests[r].sampling_params for r in ib.req_ids[:n]]
-        if any(p.temperature > 0 for p in params):
-            ids = self._sample_random(st.logits, params, ids)
+        # non-greedy requests (or a repetition penalty): one launch of the device sampler on the masked
+        # logits — penalty, temperature, top-k, top-p and the draw; greedy rows of the batch go through it too
+        states = [self.requests[r] for r in ib.req_ids[:n]]
+        if SamplingState.needed([s_.sampling_params for s_ in states]):
+            if self.sampling_state is None:
+                raise RuntimeError("non-greedy sampling needs the device sampler (GPU, vocabulary <= 16368): "
+                                   "there is no host fallback")
+            ids = self.sampling_state.sample(st.logits, states, self.sampled_ids_gpu)
         # D2H on the side stream through pinned buffers (ids + hidden states)
         cur = torch.cuda.current_stream() if self.copy_stream is not None else None
         want_hidden = self.engine_output_type != "text"
@@ -530,28 +607,6 @@ class GPUARModelRunner:
             pooler = [None] * n
         return OmniModelRunnerOutput(list(ib.req_ids[:n]), dict(ib.req_id_to_index), sampled, pooler,
                                      kv_extracted_req_ids=st.kv_extracted_req_ids)
-
-    def _sample_random(self, logits: torch.Tensor, params: list[SamplingParams], greedy_ids: torch.Tensor):
-        """Temperature / top-k / top-p sampling for rows that ask for it (host-side mirror of the
-        sampler the shipped talker config uses: T=0.9, top_p=0.8, top_k=40)."""
-        n = logits.shape[0]
-        lf = logits[:n].float()
-        temp = torch.tensor([p.temperature if p.temperature > 0 else 1.0 for p in params], device=lf.device)
-        lf = lf / temp.unsqueeze(-1)
-        top_k = max((p.top_k for p in params), default=0)
-        if top_k > 0:
-            kth = torch.topk(lf, min(top_k, lf.shape[-1]), dim=-1).values[:, -1:]
-            lf = lf.masked_fill(lf < kth, float("-inf"))
-        probs = torch.softmax(lf, dim=-1)
-        top_p = min((p.top_p for p in params), default=1.0)
-        if top_p < 1.0:
-            sp, si = torch.sort(probs, dim=-1, descending=True)
-            keep = (sp.cumsum(-1) - sp) < top_p
-            probs = torch.zeros_like(probs).scatter_(-1, si, sp * keep)
-            probs = probs / probs.sum(-1, keepdim=True)
-        drawn = torch.multinomial(probs, 1).squeeze(-1)
-        is_greedy = torch.tensor([p.temperature <= 0 for p in params], device=lf.device)
-        return torch.where(is_greedy, greedy_ids[:n], drawn)
 
     # ---------------------------------------------------------------- KV hand-off
     def _extract_finished_kv(self, finished: dict[str, dict]) -> list[str]:

@@ -242,6 +242,33 @@ def mask_logits_argmax(logits: torch.Tensor, ranges: Sequence[tuple[int, int]] =
     return ids
 
 
+def sample_tokens(logits: torch.Tensor, temperature: torch.Tensor, seed: torch.Tensor, offset: torch.Tensor,
+                  top_k: Optional[torch.Tensor] = None, top_p: Optional[torch.Tensor] = None,
+                  rep_penalty: Optional[torch.Tensor] = None, seen_bitmap: Optional[torch.Tensor] = None,
+                  seen_row: Optional[torch.Tensor] = None, update_seen: bool = True,
+                  ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Penalty -> temperature -> top-k -> top-p -> exponential-race draw, one launch (N2).
+
+    temperature/top_p/rep_penalty fp32 [rows]; top_k/seen_row int32 [rows]; seed/offset int64 [rows] (bit
+    patterns of the uint64 Philox key and draw counter); seen_bitmap int32 [state rows, words]."""
+    _gpu(logits, temperature, seed, offset, top_k, top_p, rep_penalty, seen_bitmap, seen_row, ids)
+    t, v = logits.shape
+    if temperature.dtype != torch.float32 or seed.dtype != torch.int64 or offset.dtype != torch.int64:
+        raise TypeError("temperature must be float32, seed/offset int64")
+    for name, x, dt in (("top_k", top_k, torch.int32), ("top_p", top_p, torch.float32),
+                        ("rep_penalty", rep_penalty, torch.float32), ("seen_bitmap", seen_bitmap, torch.int32),
+                        ("seen_row", seen_row, torch.int32)):
+        if x is not None and x.dtype != dt:
+            raise TypeError(f"{name} must be {dt}")
+    if ids is None:
+        ids = torch.empty(t, dtype=torch.int64, device=logits.device)
+    check("mi_sample_tokens", lib.mi_sample_tokens(
+        _p(ids), _p(logits), t, v, logits.stride(0), _dt(logits.dtype), _p(temperature), _p(top_k), _p(top_p),
+        _p(rep_penalty), _p(seen_bitmap), _p(seen_row), seen_bitmap.shape[1] if seen_bitmap is not None else 0,
+        1 if update_seen else 0, _p(seed), _p(offset), _stream()))
+    return ids
+
+
 def talker_decode_embeds(out: torch.Tensor, embed_table: torch.Tensor, token_ids: torch.Tensor,
                          reply_rows: Optional[torch.Tensor] = None, reply_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[t] = embed_table[token_ids[t]] (+ reply_rows[reply_idx[t]] where reply_idx[t] >= 0)."""
