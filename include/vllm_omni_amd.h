@@ -195,6 +195,28 @@ int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_
                           void* stream);
 
 /* ------------------------------------------------------------------------
+ * N3 — KV extract for the stage hand-off, fused.  Replaces,
+ * for raw-data connectors, `_extract_kv_cache` -> `_slice_transfer_data_for_
+ * target` -> `KVCacheTransferData.to_gpu_tensor`
+ * (vllm_omni/distributed/omni_connectors/kv_transfer_manager.py:786-862,
+ * 498-519, 144-157; utils/kv_utils.py:230-273): for every layer, K then V
+ * rows [0, rows) of the request — row r lives in block block_ids[r /
+ * block_size] at slot r % block_size — restricted to KV heads [head_lo,
+ * head_lo + head_cnt), are written contiguously ([rows, head_cnt, head_dim])
+ * at dst + k_offsets[layer] / dst + v_offsets[layer].
+ * k_layers / v_layers: device arrays of device addresses of each layer's
+ * [num_blocks, block_size, kv_heads, head_dim] views (0 = layer absent, its
+ * offsets are ignored); all layers share the strides (in elements).
+ * block_ids must already be validated (0 <= id < num_blocks); dst 16-byte
+ * aligned; head_dim * elem_size a multiple of 16.
+ * ---------------------------------------------------------------------- */
+int mi_kv_pack(void* dst, const uint64_t* k_layers, const uint64_t* v_layers, const int64_t* k_offsets,
+               const int64_t* v_offsets, int32_t num_layers, const int32_t* block_ids,
+               int32_t num_block_ids, int32_t rows, int32_t block_size, int32_t head_lo, int32_t head_cnt,
+               int32_t head_dim, int32_t elem_size, int64_t cache_block_stride,
+               int64_t cache_token_stride, int64_t cache_head_stride, void* stream);
+
+/* ------------------------------------------------------------------------
  * N2 — device-side sampler.  Replaces the sampler call of
  * vllm_omni/worker/gpu_ar_model_runner.py:626-657 (upstream vLLM v0.19
  * `Sampler`: penalties -> temperature -> top-k/top-p -> random_sample) for

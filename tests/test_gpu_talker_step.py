@@ -151,6 +151,11 @@ def test_finished_requests_are_removed_and_kv_extracted(dev):
     exp = ref_ops.extract_kv(cpu_caches[0][0], cpu_caches[0][1], blocks, 21)
     # rows 0..19 were pre-filled identically on both sides (row 20 was written by the step on the GPU only)
     assert torch.equal(got["key_cache"][0][:20].cpu(), exp[0][:20])
+    assert got["metadata"]["seq_len"] == 21 and got["block_ids"] == blocks
+    # the packed wire payload of the same request decodes to the same tensors (kv_transfer.pack_request_kv)
+    from vllm_omni_amd.kv_transfer import KVCacheTransferData
+    dec = KVCacheTransferData.from_bytes(runner.kv_payloads["r0"].cpu().numpy().tobytes())
+    assert dec["request_id"] == "r0" and torch.equal(dec["layer_blocks"]["value_cache"][1], got["value_cache"][1].cpu())
     # r1 was not scheduled in that step: it leaves the persistent batch but keeps its cached state
     # (vllm_omni/worker/gpu_model_runner.py:282-301); r0 is gone for good
     assert runner.input_batch.req_ids == [] and "r1" in runner.requests and "r0" not in runner.requests

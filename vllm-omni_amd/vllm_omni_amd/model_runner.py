@@ -220,6 +220,7 @@ class GPUARModelRunner:
         self.input_batch = InputBatch(max_num_reqs, max_model_len, self.max_num_batched_tokens, block_size, device)
         self.execute_model_state: Optional[ExecuteModelState] = None
         self.kv_extracted: dict[str, Any] = {}
+        self.kv_payloads: dict[str, torch.Tensor] = {}     # packed wire payloads (1-D uint8, device)
         self._graphs: dict[int, tuple[torch.cuda.CUDAGraph, dict]] = {}
         self._graph_broken = False
         self.max_reply_rows = max_reply_rows
@@ -611,12 +612,28 @@ class GPUARModelRunner:
     # ---------------------------------------------------------------- KV hand-off
     def _extract_finished_kv(self, finished: dict[str, dict]) -> list[str]:
         """Gather finished requests' K/V before their blocks are reused (A2 consumer;
-        kv_transfer_manager.py:721-862).  Results are kept in ``self.kv_extracted``."""
+        kv_transfer_manager.py:721-862).  On the GPU each request becomes ONE packed payload — extraction,
+        (optional) sender-side head slice and serialisation in one kernel launch (kv_transfer.pack_request_kv,
+        the `to_gpu_tensor` wire format) — kept in ``self.kv_payloads[rid]``; ``self.kv_extracted[rid]`` is the
+        decoded view of it (key_cache / value_cache lists, block_ids, metadata)."""
+        from .kv_transfer import KVCacheTransferData, pack_request_kv
+
         done = []
+        on_gpu = torch.device(self.device).type == "cuda"
         for rid, info in finished.items():
-            keys, vals = extract_request_kv(self.kv_caches, info.get("block_ids", []), int(info.get("seq_len", 0)))
-            self.kv_extracted[rid] = {"key_cache": keys, "value_cache": vals, "block_ids": info.get("block_ids", []),
-                                      "metadata": {"block_size": self.block_size, "num_layers": len(self.kv_caches),
-                                                   "dtype": str(self.dtype), "seq_len": int(info.get("seq_len", 0))}}
+            block_ids, seq_len = list(info.get("block_ids", [])), int(info.get("seq_len", 0))
+            if on_gpu:
+                payload = pack_request_kv(self.kv_caches, rid, block_ids, seq_len, self.block_size, str(self.dtype))
+                if payload is not None:
+                    self.kv_payloads[rid] = payload
+                    dec = KVCacheTransferData.from_bytes_gpu(payload)
+                    self.kv_extracted[rid] = {"key_cache": dec["layer_blocks"]["key_cache"],
+                                              "value_cache": dec["layer_blocks"]["value_cache"],
+                                              "block_ids": dec["block_ids"], "metadata": dec["metadata"]}
+            else:  # host-logic unit tests: the cache is a host tensor, indexing only
+                keys, vals = extract_request_kv(self.kv_caches, block_ids, seq_len)
+                self.kv_extracted[rid] = {"key_cache": keys, "value_cache": vals, "block_ids": block_ids,
+                                          "metadata": {"block_size": self.block_size, "num_layers": len(self.kv_caches),
+                                                       "dtype": str(self.dtype), "seq_len": seq_len}}
             done.append(rid)
         return done
