@@ -268,6 +268,12 @@ int mi_dynamic_int8_quant(int8_t* xq, float* x_scale, const void* x, int32_t num
 int mi_int8_gemm_dequant(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq,
                          const float* w_scale, const void* bias, int32_t m, int32_t n,
                          int32_t k, int64_t out_row_stride, int dtype, void* stream);
+/* Dequant epilogue alone, for an int32 accumulator produced by a library int8 GEMM (hipBLASLt through
+ * torch._int_mm): out[m, n] = acc[m, n] * x_scale[m] * w_scale[n] (+ bias[n]).  n % 4 == 0. */
+int mi_int8_dequant(void* out, const int32_t* acc, const float* x_scale, const float* w_scale,
+                    const void* bias, int32_t m, int32_t n, int64_t acc_row_stride,
+                    int64_t out_row_stride, int dtype, void* stream);
+
 
 /* ------------------------------------------------------------------------
  * A1 — KV block pool (host side, no GPU).  The allocator underneath the

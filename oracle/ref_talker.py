@@ -36,7 +36,7 @@ def decode_embeds(weights: dict, last_token_ids: torch.Tensor, step_vec: Optiona
 def talker_step(cfg, weights: dict, inputs_embeds: torch.Tensor, positions: torch.Tensor, kv_caches: Sequence,
                 block_table: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
                 slot_map: torch.Tensor, cos_sin_cache: torch.Tensor, round_to: Optional[torch.dtype] = None,
-                num_layers: Optional[int] = None):
+                num_layers: Optional[int] = None, quant: Optional[str] = None):
     """Run the stack on ``inputs_embeds`` [T, E] (all requests' scheduled tokens, varlen).
 
     kv_caches: per layer (key_blocks, value_blocks) CPU views, UPDATED IN PLACE at ``slot_map``.
@@ -45,15 +45,26 @@ def talker_step(cfg, weights: dict, inputs_embeds: torch.Tensor, positions: torc
     rt = round_to
     h = _lin(inputs_embeds.to(F32), weights["thinker_to_talker_proj.weight"], weights["thinker_to_talker_proj.bias"], rt)
     return decoder_stack(cfg, weights, h, positions, kv_caches, block_table, seq_lens, query_start_loc, slot_map,
-                         cos_sin_cache, round_to, num_layers)
+                         cos_sin_cache, round_to, num_layers, quant)
 
 
 def decoder_stack(cfg, weights: dict, h: torch.Tensor, positions: torch.Tensor, kv_caches: Sequence,
                   block_table: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
                   slot_map: torch.Tensor, cos_sin_cache: torch.Tensor, round_to: Optional[torch.dtype] = None,
-                  num_layers: Optional[int] = None):
-    """``Qwen2Model.forward`` on already-projected embeddings ``h`` [T, H] (qwen2_old.py:300-326)."""
+                  num_layers: Optional[int] = None, quant: Optional[str] = None):
+    """``Qwen2Model.forward`` on already-projected embeddings ``h`` [T, H] (qwen2_old.py:300-326).
+
+    quant="int8": the four linears of every block run the reference's W8A8 scheme (int8_config.py:180-212,
+    323-342: per-output-channel weight scale, dynamic per-token activation scale, int32 accumulation)."""
     rt = round_to
+    if quant == "int8":
+        def _lin(x, w, b, rt_):  # noqa: F811 — shadows the module-level fp32 linear inside this call
+            wq, ws = R.int8_weight_quant(w.to(F32))
+            return R._rt(R.int8_linear(x, wq, ws, b), rt_)
+    elif quant is not None:
+        raise ValueError(quant)
+    else:
+        _lin = globals()["_lin"]
     d, nq, nkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
     t = h.shape[0]
     h = h.to(F32)

@@ -70,3 +70,25 @@ def test_int8_rejects_unsupported_k(dev):
                               torch.zeros(8, 100, dtype=torch.int8, device=dev), torch.ones(8, device=dev), None,
                               torch.bfloat16)
     assert ei.value.code == _C.MI_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(64, 256, 512, True), (512, 1024, 384, False), (17, 96, 64, True), (3, 64, 128, True)])
+def test_int8_linear_library_and_mfma_paths_agree_exactly(dev, M, N, K, bias):
+    """ops.int8_linear: hand-written quantisation -> int8 contraction (library for M > 16, MFMA kernel otherwise) ->
+    hand-written dequant.  Integer sums are exact, so it equals the all-MFMA path bit for bit and the oracle to
+    one 16-bit rounding."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16) if bias else None
+    wq, ws = ops.dynamic_int8_quant(w.to(dev))
+    got = ops.int8_linear(x.to(dev), wq, ws, b.to(dev) if bias else None)
+    xq, xs = ops.dynamic_int8_quant(x.to(dev))
+    mfma = ops.int8_gemm_dequant(xq, xs, wq, ws, b.to(dev) if bias else None, torch.bfloat16)
+    assert torch.equal(got, mfma)
+    eq, es = ref_ops.int8_weight_quant(w.float())
+    assert torch.equal(wq.cpu(), eq) and torch.equal(ws.cpu(), es)
+    exp = ref_ops.int8_linear(x.float(), eq, es, b)
+    torch.testing.assert_close(got.cpu().float(), exp, rtol=1e-2, atol=1e-2)

@@ -94,8 +94,58 @@ __global__ __launch_bounds__(256) void int8_gemm_dequant_kernel(uint16_t* __rest
   store(c11, row0 + 16, col0 + 16);
 }
 
+// Dequant epilogue for an int32 accumulator tile produced by a library int8 GEMM:
+// out[m, n] = acc[m, n] * x_scale[m] * w_scale[n] (+ bias[n]).  4 columns per lane (16-B reads, 8-B writes).
+template <typename Tag>
+__global__ __launch_bounds__(256) void int8_dequant_kernel(uint16_t* __restrict__ out, const int32_t* __restrict__ acc,
+                                                           const float* __restrict__ x_scale,
+                                                           const float* __restrict__ w_scale,
+                                                           const uint16_t* __restrict__ bias, int n,
+                                                           int64_t acc_stride, int64_t out_stride) {
+  scalar_cache_acquire();
+  using E = Elem<Tag>;
+  const int row = blockIdx.y;
+  const float xs = x_scale[row];
+  for (int c = (blockIdx.x * 256 + threadIdx.x) * 4; c < n; c += gridDim.x * 1024) {
+    const int4 a = *reinterpret_cast<const int4*>(acc + row * acc_stride + c);
+    const float4 ws = *reinterpret_cast<const float4*>(w_scale + c);
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (bias) {
+      const uint2 bb = *reinterpret_cast<const uint2*>(bias + c);
+      b0 = E::lo(bb.x); b1 = E::hi(bb.x); b2 = E::lo(bb.y); b3 = E::hi(bb.y);
+    }
+    uint2 r;
+    r.x = E::pack((float)a.x * xs * ws.x + b0, (float)a.y * xs * ws.y + b1);
+    r.y = E::pack((float)a.z * xs * ws.z + b2, (float)a.w * xs * ws.w + b3);
+    *reinterpret_cast<uint2*>(out + row * out_stride + c) = r;
+  }
+}
+
 }  // namespace
 }  // namespace mi
+
+extern "C" int mi_int8_dequant(void* out, const int32_t* acc, const float* x_scale, const float* w_scale,
+                               const void* bias, int32_t m, int32_t n, int64_t acc_row_stride,
+                               int64_t out_row_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (m == 0 || n == 0) return MI_OK;
+  if (!out || !acc || !x_scale || !w_scale || m < 0 || n < 0) return MI_ERR_INVALID_ARG;
+  if (n % 4 || acc_row_stride % 4 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)acc | (uintptr_t)w_scale) & 15 || ((uintptr_t)out | (uintptr_t)bias) & 7) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int gx = (n / 4 + 255) / 256;
+  if (gx > 64) gx = 64;
+  const dim3 grid(gx, m), block(256);
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto b = reinterpret_cast<const uint16_t*>(bias);
+  if (dtype == MI_DTYPE_BF16)
+    hipLaunchKernelGGL((int8_dequant_kernel<bf16_tag>), grid, block, 0, s, o, acc, x_scale, w_scale, b, n, acc_row_stride, out_row_stride);
+  else if (dtype == MI_DTYPE_F16)
+    hipLaunchKernelGGL((int8_dequant_kernel<f16_tag>), grid, block, 0, s, o, acc, x_scale, w_scale, b, n, acc_row_stride, out_row_stride);
+  else
+    return MI_ERR_UNSUPPORTED;
+  return launch_status();
+}
 
 extern "C" int mi_dynamic_int8_quant(int8_t* xq, float* x_scale, const void* x, int32_t num_tokens,
                                      int32_t hidden, int64_t x_token_stride, int dtype, void* stream) {

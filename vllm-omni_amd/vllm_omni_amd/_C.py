@@ -47,6 +47,7 @@ SIGNATURES = {
     "mi_silu_and_mul": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_mask_logits_argmax": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int, _P]),
+    "mi_int8_dequant": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_kv_pack": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                            c_int64, c_int64, c_int64, _P]),
     "mi_sample_tokens": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P]),

@@ -247,6 +247,23 @@ def _init_weight(out_f: int, in_f: int, dtype, device, generator=None, std: floa
     return w.to(dtype)
 
 
+def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """bf16 library GEMM, or the W8A8 path once ``quantize_int8_`` has run on the layer."""
+    if getattr(layer, "qweight", None) is not None:
+        return ops.int8_linear(x, layer.qweight, layer.weight_scale, bias)
+    return F.linear(x, layer.weight, bias)
+
+
+def quantize_int8_(layer) -> None:
+    """Online W8A8 quantisation of one linear layer after its weights are loaded — the reference's
+    ``Int8OnlineLinearMethod.process_weights_after_loading`` (vllm_omni/quantization/int8_config.py:391-418:
+    ``ops.scaled_int8_quant(weight, scale=None)``): int8 weight [N, K] and an fp32 scale per output channel; the
+    16-bit weight is dropped.  Activations are quantised per token at run time."""
+    w = layer.weight
+    layer.qweight, layer.weight_scale = ops.dynamic_int8_quant(w)   # a row of [N, K] is an output channel
+    layer.weight = None
+
+
 class ColumnParallelLinear:
     """y = x W^T (+ b), output features sharded over TP ranks (no communication)."""
 
@@ -263,7 +280,7 @@ class ColumnParallelLinear:
         self.bias = torch.zeros(self.output_size_per_partition, dtype=dtype, device=device) if bias else None
 
     def __call__(self, x: torch.Tensor):
-        y = F.linear(x, self.weight, self.bias)
+        y = _apply_linear(self, x, self.bias)
         if self.gather_output:
             y = tensor_model_parallel_all_gather(y)
         return y, None
@@ -317,7 +334,7 @@ class RowParallelLinear:
 
     def __call__(self, x: torch.Tensor):
         # bias is added once (rank 0) so the all-reduced sum carries it exactly once
-        y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        y = _apply_linear(self, x, self.bias if self.tp_rank == 0 else None)
         if self.reduce_results:
             y = tensor_model_parallel_all_reduce(y)
         return y, None

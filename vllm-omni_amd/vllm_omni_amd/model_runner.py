@@ -199,7 +199,8 @@ class GPUARModelRunner:
     def __init__(self, config: TalkerConfig, device: torch.device, dtype: torch.dtype = torch.bfloat16,
                  max_num_reqs: int = 256, max_model_len: int = 4096, max_num_batched_tokens: int = 8192,
                  block_size: int = 16, kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: bool = False,
-                 engine_output_type: str = "latent", max_reply_rows: int = 0, seed: Optional[int] = 0):
+                 engine_output_type: str = "latent", max_reply_rows: int = 0, seed: Optional[int] = 0,
+                 quantization: Optional[str] = None):
         from .distributed import get_parallel_state
 
         self.config = config
@@ -213,6 +214,9 @@ class GPUARModelRunner:
         self.enforce_eager = enforce_eager
         self.engine_output_type = engine_output_type
         self.seed = seed
+        if quantization not in (None, "int8"):
+            raise ValueError(f"unsupported quantization {quantization!r} (None or 'int8')")
+        self.quantization = quantization
         self.parallel = get_parallel_state()
         self.model: Optional[Qwen2_5OmniTalkerForConditionalGeneration] = None
         self.kv_caches: list = []
@@ -258,6 +262,8 @@ class GPUARModelRunner:
 
             self.tuned_gemms = enable_tuned_gemms()
         self.model = Qwen2_5OmniTalkerForConditionalGeneration(self.config, self.dtype, self.device, self.seed)
+        if self.quantization == "int8":   # online W8A8 of the decoder linears (int8_config.py:391-418)
+            self.model.quantize_int8()
         if torch.device(self.device).type == "cuda" and self.config.vocab_size <= 16368:
             self.sampling_state = SamplingState(self.max_num_reqs, self.config.vocab_size, self.device, self.seed or 0)
         if self.max_reply_rows:

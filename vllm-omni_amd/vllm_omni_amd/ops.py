@@ -304,3 +304,36 @@ def int8_gemm_dequant(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor,
         _p(out), _p(xq), _p(x_scale), _p(wq), _p(w_scale), _p(bias), m, n, k, out.stride(0),
         _dt(out_dtype), _stream()))
     return out
+
+
+def int8_dequant(acc: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor],
+                 out_dtype: torch.dtype) -> torch.Tensor:
+    _gpu(acc, x_scale, w_scale, bias)
+    m, n = acc.shape
+    out = torch.empty(m, n, dtype=out_dtype, device=acc.device)
+    check("mi_int8_dequant", lib.mi_int8_dequant(_p(out), _p(acc), _p(x_scale), _p(w_scale), _p(bias), m, n,
+                                                  acc.stride(0), out.stride(0), _dt(out_dtype), _stream()))
+    return out
+
+
+# Library int8 GEMM (hipBLASLt behind torch._int_mm) needs M > 16 and K, N multiples of 8; everything else
+# goes through the hand-written MFMA kernel.  VLLM_OMNI_AMD_INT8_GEMM=mfma forces the latter.
+_INT8_FORCE_MFMA = __import__("os").environ.get("VLLM_OMNI_AMD_INT8_GEMM", "") == "mfma"
+
+
+def int8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W8A8 linear of the reference's scheme (vllm_omni/quantization/int8_config.py:323-342: dynamic symmetric
+    per-token activation scale, per-output-channel weight scale): hand-written per-token quantisation kernel ->
+    int8 x int8 -> int32 contraction -> hand-written dequant epilogue.  The contraction is a plain GEMM and uses
+    the library (measured M = 512: 62-102 us against 286-484 us for the MFMA kernel of csrc/int8_linear.hip,
+    tools/bench_misc_kernels.py); the integer sums are exact either way, so both paths give identical results."""
+    x2 = x.reshape(-1, x.shape[-1])
+    xq, xs = dynamic_int8_quant(x2)
+    m, k = xq.shape
+    n = wq.shape[0]
+    if not _INT8_FORCE_MFMA and m > 16 and k % 8 == 0 and n % 8 == 0:
+        acc = torch._int_mm(xq, wq.t())
+        y = int8_dequant(acc, xs, w_scale, bias, x.dtype)
+    else:
+        y = int8_gemm_dequant(xq, xs, wq, w_scale, bias, x.dtype)
+    return y.view(*x.shape[:-1], n)

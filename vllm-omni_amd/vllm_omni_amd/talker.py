@@ -293,13 +293,39 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
             yield p + "input_layernorm.weight", layer.input_layernorm.weight
             yield p + "post_attention_layernorm.weight", layer.post_attention_layernorm.weight
 
+    # ---- W8A8 ------------------------------------------------------
+    def linear_layers(self):
+        """(weight name, layer) of the decoder linears the reference's int8 config quantises — every linear of the
+        transformer blocks (DiffusionInt8Config applies to `LinearBase` layers, int8_config.py:136-164); the
+        embedding, lm_head and the thinker→talker projection stay 16-bit."""
+        for i, layer in enumerate(self.language_model.model.layers):
+            p = f"language_model.model.layers.{i}."
+            yield p + "self_attn.qkv_proj.weight", layer.self_attn.qkv_proj
+            yield p + "self_attn.o_proj.weight", layer.self_attn.o_proj
+            yield p + "mlp.gate_up_proj.weight", layer.mlp.gate_up_proj
+            yield p + "mlp.down_proj.weight", layer.mlp.down_proj
+
+    def quantize_int8(self) -> None:
+        from .layers import quantize_int8_
+
+        for _, lin in self.linear_layers():
+            if getattr(lin, "qweight", None) is None:
+                quantize_int8_(lin)
+        self.quantization = "int8"
+
     def load_weights(self, full: dict[str, torch.Tensor]) -> set[str]:
-        """Copy UNSHARDED weights (fused names as in ``named_weights``) into this rank's shards."""
+        """Copy UNSHARDED weights (fused names as in ``named_weights``) into this rank's shards.  On a quantised
+        model the 16-bit shard of a linear is rebuilt, loaded and quantised again (online quantisation)."""
         cfg = self.config
         tp, r = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
         loaded = set()
+        quantised = {n: lin for n, lin in self.linear_layers() if getattr(lin, "qweight", None) is not None}
+        for n, lin in quantised.items():
+            if n in full:
+                lin.weight = torch.empty(lin.qweight.shape, dtype=self.dtype, device=lin.qweight.device)
+                lin.qweight = lin.weight_scale = None
         for name, dst in self.named_weights():
-            if name not in full:
+            if name not in full or dst is None:
                 continue
             w = full[name]
             if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
@@ -312,7 +338,13 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
                 w = shard_column(w, tp, r)
             dst.copy_(w.to(dst.dtype))
             loaded.add(name)
+        if quantised:
+            self.quantize_int8()
         return loaded
 
     def weight_bytes(self) -> int:
-        return sum(w.numel() * w.element_size() for _, w in self.named_weights())
+        n = sum(w.numel() * w.element_size() for _, w in self.named_weights() if w is not None)
+        for _, lin in self.linear_layers():
+            if getattr(lin, "qweight", None) is not None:
+                n += lin.qweight.numel() + lin.weight_scale.numel() * 4
+        return n
