@@ -14,9 +14,13 @@ non-contiguous block tables, every sequence at exactly ``ctx`` tokens and NOT gr
 timed region, so bytes/step are constant.  Inputs are resident in HBM when the
 timed region starts.
 
-Parallelism by N: 1 -> tp1, 2 -> tp2, 4 -> tp4, 8 -> dp2 x tp4 (28 query heads do not divide by 8:
-vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:91); the global batch is fixed (strong
-scaling).  Rank 0 prints ONE JSON line.
+Parallelism for N > 1 (`choose_plan`): the global batch is fixed (strong scaling) and decode sequences are
+independent, so every split of N into data-parallel replicas x tensor-parallel ranks is valid (TP <= 4: 28 query
+heads do not divide by 8, vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:91).  At start-up the bench
+times the RCCL all-reduce of each candidate TP size on the node and takes the plan with the smallest
+per-rank-compute (measured table) + 2 x layers x all-reduce estimate; data parallelism has no data-path
+collective.  MI_BENCH_PLAN=tpmax|dp|tpT forces a plan; the chosen plan and the probe results are in the JSON.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -48,6 +52,9 @@ def parse_args():
     ap.add_argument("--block-size", type=int, default=16)
     ap.add_argument("--kv-layout", default="NB2_HEAD_MAJOR")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
+    ap.add_argument("--simulate-shard", default=None, metavar="TP,DP",
+                    help="ONE GPU runs rank 0 of a (tp, dp) plan with the collectives stubbed: per-rank compute time of "
+                         "that plan, i.e. its step time without communication.  A sizing estimate, flagged in the JSON")
     ap.add_argument("--quantization", default=None, choices=[None, "int8"],
                     help="W8A8 decoder linears (BASELINE config #5 family; NOT the headline: the default line is bf16)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps for per-launch timing")
@@ -58,13 +65,84 @@ def parse_args():
 
 
 def parallel_plan(n_gpus: int, cfg) -> tuple[int, int, str]:
-    """(tp, dp, label).  TP must divide the query heads; what is left becomes data parallel."""
+    """(tp, dp, label) of the widest tensor-parallel plan: TP must divide the query heads; what is left
+    becomes data parallel."""
     tp = n_gpus
     while tp > 1 and (cfg.num_attention_heads % tp or (cfg.num_key_value_heads < tp and tp % cfg.num_key_value_heads)
                       or (cfg.num_key_value_heads >= tp and cfg.num_key_value_heads % tp)):
         tp //= 2
     dp = n_gpus // tp
-    return tp, dp, (f"tp{tp}" if dp == 1 else f"dp{dp}xtp{tp}")
+    return tp, dp, plan_label(tp, dp)
+
+
+def plan_label(tp: int, dp: int) -> str:
+    return f"tp{tp}" if dp == 1 else (f"dp{dp}" if tp == 1 else f"dp{dp}xtp{tp}")
+
+
+# Per-rank step time (ms) of every (tp, dp) plan at the headline shape, measured on ONE MI355X with the
+# collectives stubbed (`bench.py --simulate-shard TP,DP`, profiles/r01_scaling_estimate.md).  Decode sequences are
+# independent, so data parallelism needs no collective; tensor parallelism adds 2 all-reduces per layer.
+COMPUTE_MS = {(1, 1): 16.75, (2, 1): 9.87, (1, 2): 10.84, (4, 1): 6.59, (2, 2): 7.03, (1, 4): 7.58,
+              (4, 2): 4.58, (2, 4): 4.92, (1, 8): 5.63}
+
+
+def choose_plan(world: int, rank: int, cfg, a, dev, probe: bool = True, backend: str = "nccl"):
+    """Pick (tp, dp) for N > 1 at the headline shape from MEASURED all-reduce latency on this node:
+    estimate(plan) = per-rank compute (table above) + 2 * layers * all-reduce(batch/dp x hidden, tp ranks).
+    MI_BENCH_PLAN=tpmax | dp | tpT forces a plan.  Returns (tp, dp, label, info)."""
+    tp_max, _, _ = parallel_plan(world, cfg)
+    forced = os.environ.get("MI_BENCH_PLAN", "")
+    if forced == "probe":   # rehearsal of the probing path itself
+        forced, probe = "", True
+    headline = (a.config, a.batch, a.ctx, a.quantization) == ("qwen2_5_omni_talker", 256, 4096, None)
+    if forced == "tpmax" or (not forced and (not headline or not probe)):
+        return tp_max, world // tp_max, plan_label(tp_max, world // tp_max), {"rule": "widest tensor-parallel plan"}
+    if forced == "dp":
+        return 1, world, plan_label(1, world), {"rule": "forced data parallel"}
+    if forced.startswith("tp"):
+        t = int(forced[2:])
+        return t, world // t, plan_label(t, world // t), {"rule": f"forced {forced}"}
+    cands = [(t, world // t) for t in (1, 2, 4, 8) if t <= tp_max and world % t == 0 and (t, world // t) in COMPUTE_MS
+             and a.batch % (world // t) == 0]
+    ar_us: dict[int, float] = {}
+    for t, d in cands:
+        if t == 1:
+            continue
+        try:
+            grp = None
+            for g in range(d):                      # every rank creates every group, in the same order
+                ranks = list(range(g * t, (g + 1) * t))
+                gg = dist.new_group(ranks=ranks, backend=backend)
+                if rank in ranks:
+                    grp = gg
+            x = torch.zeros(a.batch // d, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
+            for _ in range(5):
+                dist.all_reduce(x, group=grp)
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dist.all_reduce(x, group=grp)
+            e1.record()
+            torch.cuda.synchronize()
+            tt = torch.tensor([e0.elapsed_time(e1) / 20 * 1e3], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ar_us[t] = float(tt.item())
+        except Exception as e:  # noqa: BLE001 — a plan whose collective cannot even be timed is not a candidate
+            ar_us[t] = float("inf")
+            if rank == 0:
+                print(f"[bench] all-reduce probe for tp={t} failed: {e!r}", file=sys.stderr)
+    est = {(t, d): COMPUTE_MS[(t, d)] + (2 * cfg.num_hidden_layers * ar_us[t] / 1e3 if t > 1 else 0.0) for t, d in cands}
+    # every rank must take the same decision: rank 0's estimate table decides
+    best = min(est, key=est.get)
+    pick = torch.tensor(list(best), device=dev)
+    dist.broadcast(pick, src=0)
+    tp, dp = int(pick[0]), int(pick[1])
+    info = {"rule": "min over plans of measured-compute table + 2*layers*measured all-reduce",
+            "allreduce_us": {f"tp{t}": round(v, 1) for t, v in ar_us.items()},
+            "estimate_ms": {plan_label(t, d): round(v, 2) for (t, d), v in est.items()}}
+    return tp, dp, plan_label(tp, dp), info
 
 
 class SyntheticScheduler:
@@ -218,8 +296,25 @@ def main():
 
     cfg = TalkerConfig.from_json(a.config)
     tp, dp, plabel = parallel_plan(world, cfg)
+    plan_info = None
+    if a.simulate_shard:
+        if world > 1:
+            raise SystemExit("--simulate-shard runs on one GPU")
+        from vllm_omni_amd.distributed import simulate_tensor_parallel_rank
+
+        tp, dp = (int(x) for x in a.simulate_shard.split(","))
+        plabel = f"SIMULATED rank 0 of dp{dp}xtp{tp}, collectives stubbed"
+        if tp > 1:
+            simulate_tensor_parallel_rank(tp)
+        a.no_cpu_baseline = True
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not rehearsal:
+            dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        elif not dist.is_initialized():
+            dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+        tp, dp, plabel, plan_info = choose_plan(world, rank, cfg, a, dev, probe=not rehearsal,
+                                                backend="gloo" if rehearsal else "nccl")
         init_distributed_environment(world, rank, tp, backend="gloo" if rehearsal else "nccl",
                                      device=None if rehearsal else dev)
     if a.batch % dp:
@@ -285,7 +380,10 @@ def main():
                 "launches_timed": launches,
                 "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
 
+    if a.simulate_shard:   # the whole plan would decode the global batch in this rank's step time
+        tokens_per_s = a.batch / (ms_per_step / 1e3)
     out = {
+        "simulated": bool(a.simulate_shard),
         "metric": ("decode tokens/s, Qwen-Omni-7B talker, bs=256 ctx=4k"
                    if (a.config, a.batch, a.ctx, a.quantization) == ("qwen2_5_omni_talker", 256, 4096, None)
                    else f"decode tokens/s, {cfg.name}{' int8' if a.quantization else ''}, bs={a.batch} ctx={a.ctx} (not the headline shape)"),
@@ -297,7 +395,7 @@ def main():
         "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
                    "global_batch": a.batch, "seq_len": a.ctx, "parallelism": plabel,
                    "hipgraph": bool(runner._graphs), "kv_layout": a.kv_layout,
-                   "decode_partition": runner._decode_part},
+                   "decode_partition": runner._decode_part, **({"plan_choice": plan_info} if plan_info else {})},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

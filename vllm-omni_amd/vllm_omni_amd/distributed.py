@@ -30,6 +30,7 @@ class ParallelState:
     dp_size: int = 1
     dp_rank: int = 0
     tp_group: Optional["dist.ProcessGroup"] = None
+    simulated: bool = False   # one rank of a TP plan run alone, collectives stubbed (sizing estimates only)
 
 
 _STATE = ParallelState()
@@ -77,6 +78,15 @@ def init_distributed_environment(world_size: int, rank: int, tp_size: int, backe
     return _STATE
 
 
+def simulate_tensor_parallel_rank(tp_size: int, tp_rank: int = 0) -> ParallelState:
+    """ONE rank of a ``tp_size`` plan without its peers: shapes, shards and kernels are those of the real rank,
+    the all-reduce is skipped and the all-gather repeats the local shard.  Results are meaningless; the step TIME
+    is the per-rank compute of that plan (bench.py --simulate-shard).  Never used by the product path."""
+    global _STATE
+    _STATE = ParallelState(world_size=tp_size, rank=tp_rank, tp_size=tp_size, tp_rank=tp_rank, simulated=True)
+    return _STATE
+
+
 def destroy_distributed_environment() -> None:
     global _STATE
     _STATE = ParallelState()
@@ -87,7 +97,7 @@ def destroy_distributed_environment() -> None:
 def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group (no-op at tp=1).  2 per decoder layer: after o_proj and
     after down_proj; message [T, H] in the model dtype (1.8 MB at the bench shape)."""
-    if _STATE.tp_size > 1:
+    if _STATE.tp_size > 1 and not _STATE.simulated:
         dist.all_reduce(x, group=_STATE.tp_group)
     return x
 
@@ -96,6 +106,8 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
     """Concatenate the TP shards along ``dim`` (vocab-parallel logits)."""
     if _STATE.tp_size == 1:
         return x
+    if _STATE.simulated:
+        return torch.cat([x] * _STATE.tp_size, dim=dim)
     parts = [torch.empty_like(x) for _ in range(_STATE.tp_size)]
     dist.all_gather(parts, x.contiguous(), group=_STATE.tp_group)
     return torch.cat(parts, dim=dim)
