@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--block-size", type=int, default=16)
     ap.add_argument("--kv-layout", default="NB2_HEAD_MAJOR")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay")
+    ap.add_argument("--sync-output", action="store_true",
+                    help="wait for every step's ids + hidden states on the host before launching the next step (the "
+                         "default pipelines them one step behind: sample_tokens(async_output=True))")
     ap.add_argument("--simulate-shard", default=None, metavar="TP,DP",
                     help="ONE GPU runs rank 0 of a (tp, dp) plan with the collectives stubbed: per-rank compute time of "
                          "that plan, i.e. its step time without communication.  A sizing estimate, flagged in the JSON")
@@ -339,16 +342,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        runner.execute_model(sched.schedule())
-        return runner.sample_tokens()
+    def run_steps(k: int) -> None:
+        """k engine steps; every step's output (ids + hidden states) is on the host when this returns.  Pipelined
+        mode retrieves step i's output after step i+1 has been launched (upstream's async scheduling)."""
+        pending = None
+        for _ in range(k):
+            runner.execute_model(sched.schedule())
+            out = runner.sample_tokens(async_output=not a.sync_output)
+            if pending is not None:
+                pending.get_output()
+            pending = None if a.sync_output else out
+        if pending is not None:
+            pending.get_output()
 
-    for _ in range(a.warmup):
-        step()
+    run_steps(a.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    run_steps(a.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -395,6 +405,7 @@ def main():
         "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
                    "global_batch": a.batch, "seq_len": a.ctx, "parallelism": plabel,
                    "hipgraph": bool(runner._graphs), "kv_layout": a.kv_layout,
+                   "output": "sync" if a.sync_output else "pipelined one step behind (all outputs on the host inside the timed region)",
                    "decode_partition": runner._decode_part, **({"plan_choice": plan_info} if plan_info else {})},
         "roofline": roofline,
     }

@@ -347,3 +347,69 @@ def test_runner_samples_on_device_like_the_oracle(dev):
     have = {i for i in range(cfg.vocab_size) if (words[i >> 5] >> (i & 31)) & 1}
     assert have == set(reqs[0].prompt_token_ids) | set(outs["s0"])
     assert runner.requests["s1"].seen_slot == -1
+
+
+@pytest.mark.parametrize("enforce_eager", [True, False])
+def test_async_output_pipeline_equals_sync(dev, enforce_eager):
+    """N1: sample_tokens(async_output=True) — the next step is launched before the previous step's ids and hidden
+    states are read back; drawn ids feed the next embedding lookup on the device.  Tokens and hidden states must be
+    identical to the synchronous loop, through a steady decode phase, a request that finishes mid-way (the pending
+    output is drained before the batch changes) and sampled requests (draw counter ahead of the host token list)."""
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SamplingParams, SchedulerOutput
+
+    def run(async_mode):
+        cfg, runner, w, cpu_caches, mgr, reqs = _setup(dev, "mini_talker", [5, 16, 40, 1], enforce_eager, False)
+        reqs[1].sampling_params = SamplingParams(temperature=0.8, top_k=20, top_p=0.9, repetition_penalty=1.1, seed=7)
+        reqs[3].sampling_params = SamplingParams(temperature=1.0, seed=11)
+        live = list(reqs)
+        tokens = {r.request_id: [] for r in reqs}
+        hiddens = {r.request_id: [] for r in reqs}
+        pending = None
+
+        def take(out):
+            for rid, j in out.req_id_to_index.items():
+                if rid in out.req_ids:
+                    tokens[rid].append(out.sampled_token_ids[j][0])
+                    hiddens[rid].append(out.pooler_output[j]["hidden"][0].clone())
+
+        for step in range(7):
+            finished = set()
+            if step == 4:                      # r2 finishes: composition change -> the runner drains by itself
+                finished = {"r2"}
+                live = [r for r in live if r.request_id != "r2"]
+            sched = {r.request_id: 1 for r in live}
+            if step == 0:
+                so = SchedulerOutput(scheduled_new_reqs=[
+                    NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id),
+                                   r.num_computed_tokens, additional_information=r.additional_information) for r in live],
+                    num_scheduled_tokens=sched, total_num_scheduled_tokens=len(live))
+            else:
+                new_blocks = []
+                for r in live:
+                    nb_ = mgr.allocate_slots(r, 1)
+                    new_blocks.append(nb_.get_block_ids() if nb_.blocks[0] else None)
+                so = SchedulerOutput(scheduled_cached_reqs=CachedRequestData(
+                    req_ids=[r.request_id for r in live], new_block_ids=new_blocks,
+                    num_computed_tokens=[r.num_computed_tokens for r in live], num_output_tokens=[step] * len(live)),
+                    num_scheduled_tokens=sched, total_num_scheduled_tokens=len(live), finished_req_ids=finished)
+            runner.execute_model(so)
+            out = runner.sample_tokens(async_output=async_mode)
+            if async_mode:
+                if pending is not None:
+                    take(pending.get_output())
+                pending = out
+            else:
+                take(out)
+            for r in live:
+                r.num_computed_tokens += 1
+        if pending is not None:
+            take(pending.get_output())
+        return tokens, hiddens, {rid: list(st.output_token_ids) for rid, st in runner.requests.items()}
+
+    t_sync, h_sync, o_sync = run(False)
+    t_async, h_async, o_async = run(True)
+    assert t_sync == t_async and o_sync == o_async
+    assert [len(v) for v in t_sync.values()] == [7, 7, 4, 7]
+    for rid in h_sync:
+        for a_, b_ in zip(h_sync[rid], h_async[rid]):
+            assert torch.equal(a_, b_)

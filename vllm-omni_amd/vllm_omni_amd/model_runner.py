@@ -100,7 +100,10 @@ class SamplingState:
     def needed(params: list[SamplingParams]) -> bool:
         return any(p.temperature > 0 or p.repetition_penalty != 1.0 for p in params)
 
-    def sample(self, logits: torch.Tensor, states: list[CachedRequestState], ids: torch.Tensor) -> torch.Tensor:
+    def sample(self, logits: torch.Tensor, states: list[CachedRequestState], ids: torch.Tensor,
+               drawn_ahead: int = 0) -> torch.Tensor:
+        """``drawn_ahead``: draws already made for these requests whose tokens are not yet in ``output_token_ids``
+        (an async output still pending on the host)."""
         n = len(states)
         for i, st in enumerate(states):
             sp = st.sampling_params
@@ -110,7 +113,7 @@ class SamplingState:
             self.top_k.np[i] = sp.top_k
             self.seen_row.np[i] = st.seen_slot if st.seen_slot >= 0 else self.scratch_slot
             self.seed.np[i] = st.sample_seed
-            self.offset.np[i] = len(st.output_token_ids)
+            self.offset.np[i] = len(st.output_token_ids) + drawn_ahead
         return ops.sample_tokens(logits[:n], self.temperature.copy_to_gpu(n), self.seed.copy_to_gpu(n),
                                  self.offset.copy_to_gpu(n), top_k=self.top_k.copy_to_gpu(n),
                                  top_p=self.top_p.copy_to_gpu(n), rep_penalty=self.rep.copy_to_gpu(n),
@@ -195,7 +198,35 @@ class ExecuteModelState:
     kv_extracted_req_ids: Optional[list[str]]
 
 
+class AsyncOmniModelRunnerOutput:
+    """What ``sample_tokens(async_output=True)`` returns (upstream's ``AsyncGPUModelRunnerOutput`` idea applied to
+    the reference's hidden-state hand-back, gpu_ar_model_runner.py:835,868-912): the device->host copy of the step's
+    ids and hidden states is in flight on a side stream; ``get_output()`` waits for it, then does the host
+    bookkeeping (token lists, pooler payloads) and returns the ordinary ``OmniModelRunnerOutput``.  Outputs finish
+    in step order."""
+
+    def __init__(self, runner: "GPUARModelRunner", st: "ExecuteModelState", slot: int, req_ids: list, req_index: dict,
+                 prev: Optional["AsyncOmniModelRunnerOutput"]):
+        self.runner, self.st, self.slot = runner, st, slot
+        self.req_ids, self.req_index, self.prev = req_ids, req_index, prev
+        self._out: Optional[OmniModelRunnerOutput] = None
+
+    @property
+    def done(self) -> bool:
+        return self._out is not None
+
+    def get_output(self) -> OmniModelRunnerOutput:
+        if self._out is None:
+            if self.prev is not None:
+                self.prev.get_output()
+                self.prev = None
+            self._out = self.runner._finish_output(self)
+        return self._out
+
+
 class GPUARModelRunner:
+    OUT_SLOTS = 4   # ring of pinned output buffers: a step's hidden-state views live for OUT_SLOTS - 1 more steps
+
     def __init__(self, config: TalkerConfig, device: torch.device, dtype: torch.dtype = torch.bfloat16,
                  max_num_reqs: int = 256, max_model_len: int = 4096, max_num_batched_tokens: int = 8192,
                  block_size: int = 16, kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: bool = False,
@@ -247,10 +278,26 @@ class GPUARModelRunner:
         e = self.config.embedding_size
         self.inputs_embeds = torch.zeros(t, e, dtype=self.dtype, device=dev)
         self.sampled_ids_gpu = torch.zeros(n, dtype=torch.int64, device=dev)
-        self.sampled_ids_cpu = torch.zeros(n, dtype=torch.int64, pin_memory=on_gpu)
-        self.hidden_cpu = torch.zeros(t, self.config.hidden_size, dtype=self.dtype, pin_memory=on_gpu)
+        # step outputs go device -> staging (same stream, ~2 us) -> pinned host on a side stream, through a ring of
+        # OUT_SLOTS buffers so that the copy of step N can still be in flight while step N+1 runs
+        # (sample_tokens(async_output=True)).  The hidden-state tensors handed out are VIEWS of the pinned ring: they
+        # stay valid until OUT_SLOTS - 1 further steps have been sampled.  (Cloning them into fresh host tensors
+        # every step was measured to stall the GPU ~48 ms every third step: the 1.8 MB malloc/free churn unmaps
+        # pages, and the MMU notifier that follows blocks the device queues.)
+        hs = self.config.hidden_size
+        k = self.OUT_SLOTS
+        self._out_ids_cpu = [torch.zeros(n, dtype=torch.int64, pin_memory=on_gpu) for _ in range(k)]
+        self._out_hidden_cpu = [torch.zeros(t, hs, dtype=self.dtype, pin_memory=on_gpu) for _ in range(k)]
+        self._out_ids_stage = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(k)] if on_gpu else None
+        self._out_hidden_stage = [torch.zeros(t, hs, dtype=self.dtype, device=dev) for _ in range(k)] if on_gpu else None
         self.copy_stream = torch.cuda.Stream(device=dev) if on_gpu else None
-        self.copy_done = torch.cuda.Event() if on_gpu else None
+        self._out_done = [torch.cuda.Event() for _ in range(k)] if on_gpu else None
+        self._out_inflight: list[Optional["AsyncOmniModelRunnerOutput"]] = [None] * k
+        self._out_slot = 0
+        self._last_output: Optional["AsyncOmniModelRunnerOutput"] = None   # newest output whose host part is pending
+        self._ids_on_device_for: Optional[tuple] = None   # batch rows whose last token id already sits in last_token_ids.gpu
+        self._h2d_done = torch.cuda.Event() if on_gpu else None
+        self._h2d_pending = False
         self._decode_ws: Optional[torch.Tensor] = None
         self._decode_part = 0
         self.sampling_state: Optional[SamplingState] = None   # built with the model (needs the vocabulary size)
@@ -437,12 +484,13 @@ class GPUARModelRunner:
         ib = self.input_batch
         if num_decodes:
             nd = num_decodes
-            self.last_token_ids.np[:nd] = ib.last_token_ids_cpu[:nd]
             off = ib.reply_offset[:nd]
             has = (off >= 0) & (off < ib.reply_end[:nd])
             self.reply_idx.np[:nd] = np.where(has, off, -1)
             ib.reply_offset[:nd] = np.where(has, off + 1, off)   # consume one reply row per step
-            self.last_token_ids.copy_to_gpu(nd)
+            if not (nd == n and self._ids_on_device_for == tuple(ib.req_ids[:n])):
+                self.last_token_ids.np[:nd] = ib.last_token_ids_cpu[:nd]
+                self.last_token_ids.copy_to_gpu(nd)
             self.reply_idx.copy_to_gpu(nd)
             self._decode_embeds(nd)
         # prefill rows: per-request prompt embeddings (thinker hidden states) or token embeddings
@@ -523,6 +571,10 @@ class GPUARModelRunner:
     def execute_model(self, scheduler_output: SchedulerOutput, intermediate_tensors=None):
         if self.execute_model_state is not None:
             raise RuntimeError("State error: sample_tokens() must be called after execute_model() returns None.")
+        # an output whose host part is still pending may stay pending only across a pure steady-state decode step
+        # (same requests, same rows, one token each): everything else reads the host-side token state
+        if self._last_output is not None and not self._last_output.done and not self._steady_decode(scheduler_output):
+            self._last_output.get_output()
         kv_done = None
         if scheduler_output.finished_requests_needing_kv_transfer:
             kv_done = self._extract_finished_kv(scheduler_output.finished_requests_needing_kv_transfer)
@@ -531,6 +583,9 @@ class GPUARModelRunner:
             if kv_done:
                 return OmniModelRunnerOutput([], {}, [], [], kv_extracted_req_ids=kv_done)
             return EMPTY_MODEL_RUNNER_OUTPUT
+        if self._h2d_pending:   # the previous step's host->device index copies read the pinned buffers written below
+            self._h2d_done.synchronize()
+            self._h2d_pending = False
         n, total, num_sched, max_seq_len, num_decodes = self._prepare_inputs(scheduler_output)
         use_graph = self._can_use_graph(n, total)
         self._commit_inputs(n, total, total)
@@ -540,6 +595,9 @@ class GPUARModelRunner:
             self._preprocess_host_only(n, num_decodes)
             if entry is None:  # first time at this batch size: capture (static inputs are filled)
                 entry = self._capture(n)
+        if self._h2d_done is not None and use_graph:
+            self._h2d_done.record()
+            self._h2d_pending = True
         if use_graph and entry is not None:
             g, outs = entry
             g.replay()
@@ -550,25 +608,44 @@ class GPUARModelRunner:
             hidden, logits, ids = self._forward(n, total, md)
         else:
             self._preprocess_embeds(n, total, num_sched, num_decodes)
+            if self._h2d_done is not None:
+                self._h2d_done.record()
+                self._h2d_pending = True
             md = self._build_metadata(n, total, int(num_sched.max()), max_seq_len, num_decodes)
             hidden, logits, ids = self._forward(n, total, md)
         self.execute_model_state = ExecuteModelState(scheduler_output, logits, ids, hidden, n, total,
                                                      self.query_start_loc.np[:n + 1].copy(), kv_done)
         return None
 
+    def _steady_decode(self, so: SchedulerOutput) -> bool:
+        ib = self.input_batch
+        if so.scheduled_new_reqs or so.finished_req_ids or so.finished_requests_needing_kv_transfer:
+            return False
+        if so.scheduled_cached_reqs.resumed_req_ids or so.total_num_scheduled_tokens != ib.num_reqs:
+            return False
+        if self._ids_on_device_for != tuple(ib.req_ids) or len(so.num_scheduled_tokens) != ib.num_reqs:
+            return False
+        return all(so.num_scheduled_tokens.get(r) == 1 for r in ib.req_ids)
+
     def _preprocess_host_only(self, n: int, num_decodes: int) -> None:
         """Graph path: only the host->device index copies; the gather-add itself is in the graph."""
         ib = self.input_batch
-        self.last_token_ids.np[:n] = ib.last_token_ids_cpu[:n]
         off = ib.reply_offset[:n]
         has = (off >= 0) & (off < ib.reply_end[:n])
         self.reply_idx.np[:n] = np.where(has, off, -1)
         ib.reply_offset[:n] = np.where(has, off + 1, off)
-        self.last_token_ids.copy_to_gpu(n)
+        if self._ids_on_device_for != tuple(ib.req_ids[:n]):   # else the last sample_tokens left them on the device
+            self.last_token_ids.np[:n] = ib.last_token_ids_cpu[:n]
+            self.last_token_ids.copy_to_gpu(n)
         self.reply_idx.copy_to_gpu(n)
 
     @torch.inference_mode()
-    def sample_tokens(self, grammar_output=None) -> OmniModelRunnerOutput:
+    def sample_tokens(self, grammar_output=None, async_output: bool = False):
+        """Second phase of the step (gpu_ar_model_runner.py:626-953): sample, hand ids + hidden states back.
+
+        ``async_output=True`` returns an ``AsyncOmniModelRunnerOutput`` right after the device->host copy is
+        enqueued: the caller may run ``execute_model`` of the next step before ``get_output()`` — the drawn ids
+        stay on the device for the next step's embedding lookup, the host bookkeeping happens in ``get_output()``."""
         st = self.execute_model_state
         if st is None:
             raise RuntimeError("State error: sample_tokens() called without a preceding execute_model().")
@@ -583,36 +660,70 @@ class GPUARModelRunner:
             if self.sampling_state is None:
                 raise RuntimeError("non-greedy sampling needs the device sampler (GPU, vocabulary <= 16368): "
                                    "there is no host fallback")
-            ids = self.sampling_state.sample(st.logits, states, self.sampled_ids_gpu)
-        # D2H on the side stream through pinned buffers (ids + hidden states)
-        cur = torch.cuda.current_stream() if self.copy_stream is not None else None
+            pending = 1 if (self._last_output is not None and not self._last_output.done) else 0
+            ids = self.sampling_state.sample(st.logits, states, self.sampled_ids_gpu, drawn_ahead=pending)
         want_hidden = self.engine_output_type != "text"
+        slot = self._out_slot
+        self._out_slot = (slot + 1) % self.OUT_SLOTS
+        if self._out_inflight[slot] is not None:      # its pinned buffers are about to be reused
+            self._out_inflight[slot].get_output()
         if self.copy_stream is not None:
+            cur = torch.cuda.current_stream()
+            # feed the drawn ids to the next step's embedding lookup on the device (pure-decode batches)
+            if st.num_tokens == n:
+                self.last_token_ids.gpu[:n].copy_(ids[:n])
+                self._ids_on_device_for = tuple(ib.req_ids[:n])
+            else:
+                self._ids_on_device_for = None
+            cur.wait_event(self._out_done[slot])      # the staging slot's previous copy (two steps ago) has drained
+            self._out_ids_stage[slot][:n].copy_(ids[:n])
+            if want_hidden:
+                self._out_hidden_stage[slot][:st.num_tokens].copy_(st.hidden_states[:st.num_tokens])
             self.copy_stream.wait_stream(cur)
             with torch.cuda.stream(self.copy_stream):
-                self.sampled_ids_cpu[:n].copy_(ids[:n], non_blocking=True)
+                self._out_ids_cpu[slot][:n].copy_(self._out_ids_stage[slot][:n], non_blocking=True)
                 if want_hidden:
-                    self.hidden_cpu[:st.num_tokens].copy_(st.hidden_states[:st.num_tokens], non_blocking=True)
-                self.copy_done.record(self.copy_stream)
-            self.copy_done.synchronize()
+                    self._out_hidden_cpu[slot][:st.num_tokens].copy_(self._out_hidden_stage[slot][:st.num_tokens],
+                                                                     non_blocking=True)
+                self._out_done[slot].record(self.copy_stream)
         else:
-            self.sampled_ids_cpu[:n].copy_(ids[:n])
+            self._out_ids_cpu[slot][:n].copy_(ids[:n])
             if want_hidden:
-                self.hidden_cpu[:st.num_tokens].copy_(st.hidden_states[:st.num_tokens])
-        ids_np = self.sampled_ids_cpu[:n].numpy()
-        # bookkeeping, vectorised: last token per row feeds the next step's embedding lookup
-        ib.last_token_ids_cpu[:n] = ids_np
+                self._out_hidden_cpu[slot][:st.num_tokens].copy_(st.hidden_states[:st.num_tokens])
+        prev = self._last_output if (self._last_output is not None and not self._last_output.done) else None
+        out = AsyncOmniModelRunnerOutput(self, st, slot, list(ib.req_ids[:n]), dict(ib.req_id_to_index), prev)
+        self._out_inflight[slot] = out
+        self._last_output = out
+        return out if async_output else out.get_output()
+
+    def _finish_output(self, out: AsyncOmniModelRunnerOutput) -> OmniModelRunnerOutput:
+        """Host half of a step's output: wait for its device->host copy, update the token state."""
+        st, slot = out.st, out.slot
+        n = st.num_reqs
+        if self._out_done is not None:
+            self._out_done[slot].synchronize()
+        ids_np = self._out_ids_cpu[slot][:n].numpy().copy()
+        ib = self.input_batch
+        # bookkeeping: last token per row feeds the next step's embedding lookup.  Rows are addressed by request
+        # id: the batch may have been reordered since the step ran.
+        for rid, tok in zip(out.req_ids, ids_np.tolist()):
+            req = self.requests.get(rid)
+            if req is not None:
+                req.output_token_ids.append(tok)
+            row = ib.req_id_to_index.get(rid)
+            if row is not None:
+                ib.last_token_ids_cpu[row] = tok
         sampled = ids_np.reshape(n, 1).tolist()
-        for rid, tok in zip(ib.req_ids[:n], ids_np.tolist()):
-            self.requests[rid].output_token_ids.append(tok)
         pooler: list[Optional[dict[str, Any]]]
-        if want_hidden:
+        if self.engine_output_type != "text":
             q = st.query_start_loc_np
-            chunks = torch.split(self.hidden_cpu[:st.num_tokens], np.diff(q).tolist())
-            pooler = [{"hidden": c} for c in chunks]
+            hidden = self._out_hidden_cpu[slot][:st.num_tokens]   # views of the pinned ring (see __init__)
+            pooler = [{"hidden": c} for c in torch.split(hidden, np.diff(q).tolist())]
         else:
             pooler = [None] * n
-        return OmniModelRunnerOutput(list(ib.req_ids[:n]), dict(ib.req_id_to_index), sampled, pooler,
+        if self._out_inflight[slot] is out:
+            self._out_inflight[slot] = None
+        return OmniModelRunnerOutput(out.req_ids, out.req_index, sampled, pooler,
                                      kv_extracted_req_ids=st.kv_extracted_req_ids)
 
     # ---------------------------------------------------------------- KV hand-off
