@@ -1,0 +1,123 @@
+"""GPU parity: Qwen3-Omni talker code predictor — the incremental-decode implementation against
+the oracle's re-prefill restatement of the reference.  Codes are integers: the device's draw at every step must be
+the sampler oracle's draw on the device's own logits (exact, up to flagged last-ulp coin flips), and those logits
+must match the oracle's teacher-forced logits to 16-bit accumulation noise (five layers, bf16)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_code_predictor as ref
+from oracle import ref_sampler
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(dev, cfg, b, seed=0):
+    from vllm_omni_amd.code_predictor import MI355XCodePredictor
+
+    w = ref.random_weights(cfg, seed=seed)
+    cp = MI355XCodePredictor(cfg, torch.bfloat16, dev, max_batch=8, seed=0)
+    loaded = cp.load_weights({k: v.to(dev) for k, v in w.items()})
+    assert loaded == set(w.keys())
+    g = torch.Generator().manual_seed(seed + 1)
+    hidden = torch.randn(b, cfg.hidden_size, generator=g).to(torch.bfloat16)
+    code0 = torch.randint(0, cfg.vocab_size, (b, 1), generator=g)
+    emb0 = torch.randn(b, 1, cfg.hidden_size, generator=g).to(torch.bfloat16)
+    return w, cp, hidden, code0, emb0
+
+
+@pytest.mark.parametrize("groups", [4, 32])
+def test_code_predictor_matches_oracle(dev, groups):
+    from vllm_omni_amd.code_predictor import CodePredictorConfig
+
+    cfg = CodePredictorConfig(hidden_size=256, num_hidden_layers=5, num_attention_heads=4, num_key_value_heads=2,
+                              head_dim=128, intermediate_size=512, vocab_size=512, num_code_groups=groups)
+    b = 5
+    w, cp, hidden, code0, emb0 = _mk(dev, cfg, b)
+    seed = torch.arange(11, 11 + b, dtype=torch.int64)
+    offset = torch.tensor([0, 3, 7, 100, 2**20], dtype=torch.int64)
+    codes, buf, logits = cp(code0.to(dev), emb0.to(dev), hidden.to(dev), seed=seed.to(dev), offset=offset.to(dev),
+                            return_logits=True)
+    torch.cuda.synchronize()
+    codes_c, buf_c = codes.cpu(), buf.cpu().float()
+    assert codes_c.shape == (b, groups, 1) and buf_c.shape == (b, groups + 1, cfg.hidden_size)
+    assert torch.equal(codes_c[:, 0], code0)
+    # 1. every draw is the sampler oracle's draw on the device's logits ("stored" mode: top_k 50, top_p 0.8, T = 1)
+    flips = 0
+    for step in range(1, groups):
+        lg = logits[step - 1].cpu().numpy()
+        want, margins = ref_sampler.sample(lg, [1.0] * b, [50] * b, [0.8] * b, None, None, None, seed.tolist(),
+                                           [int(o) * groups + step for o in offset])
+        for r in range(b):
+            if int(codes_c[r, step, 0]) != int(want[r]):
+                m = margins[r]
+                assert m["topp_gap"] < 1e-5 or m["race_ratio"] < 1 + 1e-4, (step, r, m)
+                flips += 1
+    assert flips <= 2
+    # 2. teacher-forced oracle (the reference's re-prefill loop): logits and the embedding buffer agree
+    _, buf_ref, logits_ref = ref.forward(cfg, w, code0, emb0, hidden, rt=torch.bfloat16, forced_codes=codes_c[:, :, 0])
+    torch.testing.assert_close(buf_c, buf_ref, rtol=0, atol=0)           # embeddings are looked up, not computed
+    for step in range(1, groups):
+        # logits reach |x| ~ 16 here: one bf16 ulp is 0.06-0.12, and five bf16 layers sit in front of them
+        torch.testing.assert_close(logits[step - 1].cpu(), logits_ref[step - 1], rtol=3e-2, atol=0.2,
+                                   msg=lambda m: f"step {step}: {m}")
+        assert (logits[step - 1].cpu() - logits_ref[step - 1]).abs().mean() < 0.03
+    # 3. same seeds -> same codes; greedy mode == argmax of the device logits
+    codes2, _ = cp(code0.to(dev), emb0.to(dev), hidden.to(dev), seed=seed.to(dev), offset=offset.to(dev))
+    assert torch.equal(codes2.cpu(), codes_c)
+    gcodes, _, glogits = cp(code0.to(dev), emb0.to(dev), hidden.to(dev), do_sample=False, return_logits=True)
+    for step in range(1, groups):
+        assert torch.equal(gcodes[:, step, 0].cpu(), glogits[step - 1].argmax(-1).cpu())
+
+
+def test_code_predictor_incremental_equals_reprefill_on_device(dev):
+    """Size-independent property at the real shape (H 1024, 16/8 heads, G 32, batch 8): the hidden state the
+    incremental path produces at the last position equals a from-scratch varlen prefill of the whole buffer."""
+    from vllm_omni_amd.code_predictor import CodePredictorConfig, MI355XCodePredictor
+    from vllm_omni_amd.layers import AttentionMetadata
+
+    cfg = CodePredictorConfig()
+    cp = MI355XCodePredictor(cfg, torch.bfloat16, dev, max_batch=8, seed=3)
+    b, g, h = 8, cfg.num_code_groups, cfg.hidden_size
+    gen = torch.Generator(device=dev).manual_seed(1)
+    hidden = torch.randn(b, h, device=dev, generator=gen).to(torch.bfloat16)
+    emb0 = torch.randn(b, h, device=dev, generator=gen).to(torch.bfloat16)
+    code0 = torch.randint(0, cfg.vocab_size, (b,), device=dev, generator=gen)
+    codes, buf, logits = cp(code0, emb0, hidden, return_logits=True)
+    # re-prefill positions 0 .. g-1 of every sequence in one varlen call into the same private cache
+    t = g
+    x = buf[:, :t].reshape(b * t, h).clone()
+    pos = torch.arange(t, device=dev).repeat(b)
+    slots = (cp.block_table[:b].to(torch.int64) * cp.BLOCK + torch.arange(t, device=dev)).reshape(-1)
+    md = AttentionMetadata(num_actual_tokens=b * t, max_query_len=t,
+                           query_start_loc=torch.arange(0, b * t + 1, t, dtype=torch.int32, device=dev),
+                           seq_lens=torch.full((b,), t, dtype=torch.int32, device=dev), max_seq_len=t,
+                           block_table=cp.block_table[:b], slot_mapping=slots, num_reqs=b, num_decodes=0)
+    full = cp._stack(x, pos, md).view(b, t, h)
+    last = torch.nn.functional.linear(full[:, g - 1], cp.lm_head[g - 2]).float()
+    torch.testing.assert_close(last, logits[g - 2], rtol=3e-2, atol=3e-2)
+    assert int(codes.min()) >= 0 and int(codes.max()) < cfg.vocab_size
+
+
+def test_code_predictor_graph_replay_equals_eager(dev):
+    from vllm_omni_amd.code_predictor import CodePredictorConfig, MI355XCodePredictor
+
+    cfg = CodePredictorConfig(hidden_size=256, num_hidden_layers=5, num_attention_heads=4, num_key_value_heads=2,
+                              head_dim=128, intermediate_size=512, vocab_size=512, num_code_groups=8)
+    cp = MI355XCodePredictor(cfg, torch.bfloat16, dev, max_batch=8, seed=1)
+    b = 6
+    gen = torch.Generator(device=dev).manual_seed(4)
+    mk = lambda: (torch.randint(0, 512, (b,), device=dev, generator=gen),  # noqa: E731
+                  torch.randn(b, 256, device=dev, generator=gen).to(torch.bfloat16),
+                  torch.randn(b, 256, device=dev, generator=gen).to(torch.bfloat16))
+    seed = torch.arange(b, device=dev, dtype=torch.int64)
+    a1, a2 = mk(), mk()
+    off1, off2 = torch.full((b,), 5, device=dev, dtype=torch.int64), torch.full((b,), 6, device=dev, dtype=torch.int64)
+    e1 = [t.clone() for t in cp(*a1, seed=seed, offset=off1)]
+    e2 = [t.clone() for t in cp(*a2, seed=seed, offset=off2)]
+    cp.capture(b)
+    g1 = [t.clone() for t in cp(*a1, seed=seed, offset=off1)]
+    g2 = [t.clone() for t in cp(*a2, seed=seed, offset=off2)]
+    for x, y in zip(e1 + e2, g1 + g2):
+        assert torch.equal(x, y)
+    assert not torch.equal(e1[0], e2[0])
