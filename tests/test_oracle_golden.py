@@ -230,3 +230,34 @@ def test_sampler_oracle_semantics():
     draws = np.array([ref_sampler.sample_row(lg, 1.0, seed=5, offset=o)[0] for o in range(4000)])
     freq = np.bincount(draws, minlength=5) / 4000
     assert np.abs(freq - p).max() < 0.03
+
+
+# ------------------------------------------------------------------ code predictor oracle (N4)
+def test_code_predictor_oracle_loop_properties():
+    """The restated re-prefill loop (qwen3_code_predictor.py:503-626): the buffer holds [talker hidden, emb(c0),
+    emb(c1), ...]; teacher forcing with the codes a free run drew reproduces its logits exactly; positions past
+    the frontier never influence a prediction (causality), so zero-filling them — as the reference does — is
+    equivalent to truncating the sequence."""
+    from types import SimpleNamespace
+
+    from oracle import ref_code_predictor as rcp
+
+    cfg = SimpleNamespace(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, head_dim=32,
+                          intermediate_size=96, vocab_size=40, num_code_groups=5, rms_norm_eps=1e-6, rope_theta=10000.0)
+    w = rcp.random_weights(cfg, seed=1, dtype=torch.float32)
+    g = torch.Generator().manual_seed(0)
+    code0 = torch.randint(0, 40, (3, 1), generator=g)
+    emb0, hid = torch.randn(3, 1, 64, generator=g), torch.randn(3, 64, generator=g)
+    codes, buf, logits = rcp.forward(cfg, w, code0, emb0, hid, seed=[5, 6, 7], offset=[0, 1, 2])
+    assert codes.shape == (3, 5, 1) and buf.shape == (3, 6, 64) and len(logits) == 4
+    assert torch.equal(codes[:, 0], code0) and torch.equal(buf[:, 0], hid) and torch.equal(buf[:, 1], emb0[:, 0])
+    for s in range(1, 5):
+        assert torch.equal(buf[:, s + 1], w[f"model.codec_embedding.{s - 1}.weight"][codes[:, s, 0]])
+    codes2, buf2, logits2 = rcp.forward(cfg, w, code0, emb0, hid, forced_codes=codes[:, :, 0])
+    assert torch.equal(codes2, codes) and all(torch.equal(a, b) for a, b in zip(logits, logits2))
+    # causality: the hidden state at position s of the zero-padded buffer == that of the sequence cut at s + 1
+    full = rcp.stack(cfg, w, buf[:, :5])
+    cut = rcp.stack(cfg, w, buf[:, :3])
+    torch.testing.assert_close(full[:, :3], cut, rtol=1e-5, atol=1e-5)
+    greedy, _, gl = rcp.forward(cfg, w, code0, emb0, hid, do_sample=False)
+    assert all(torch.equal(greedy[:, s, 0], gl[s - 1].argmax(-1)) for s in range(1, 5))
