@@ -261,3 +261,37 @@ def test_code_predictor_oracle_loop_properties():
     torch.testing.assert_close(full[:, :3], cut, rtol=1e-5, atol=1e-5)
     greedy, _, gl = rcp.forward(cfg, w, code0, emb0, hid, do_sample=False)
     assert all(torch.equal(greedy[:, s, 0], gl[s - 1].argmax(-1)) for s in range(1, 5))
+
+
+# ------------------------------------------------------------------ Qwen3-Omni talker modules pinned by HF outputs
+@pytest.fixture(scope="module")
+def hf_q3():
+    return torch.load(os.path.join(GOLD, "hf_qwen3_talker_mini.pt"), weights_only=False)
+
+
+def test_code_predictor_oracle_stack_matches_hf(hf_q3):
+    """oracle/ref_code_predictor.stack == transformers' Qwen3OmniMoeTalkerCodePredictorModel (the module the
+    reference's code predictor says it re-implements exactly)."""
+    from oracle import ref_code_predictor as rcp
+
+    fx = hf_q3["code_predictor"]
+    cfg = SimpleNamespace(**fx["config"])
+    w = {k: v.float() for k, v in fx["weights_fp16"].items()}
+    got = rcp.stack(cfg, w, fx["inputs_embeds_fp16"].float())
+    torch.testing.assert_close(got, fx["expected_hidden_fp32"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["moe", "moe_norm_topk"])
+def test_moe_oracle_matches_hf_block(hf_q3, tag):
+    """oracle/ref_moe.moe_block == transformers' Qwen3OmniMoeTalkerTextSparseMoeBlock: fp32 softmax router, top-k
+    (with and without renormalisation), per-expert SiLU-gated MLPs, sigmoid-gated shared expert."""
+    from oracle import ref_moe
+
+    fx = hf_q3[tag]
+    w = {k: v.float() for k, v in fx["weights_fp16"].items()}
+    c = fx["config"]
+    got = ref_moe.moe_block(fx["x_fp16"].float(), w, c["num_experts_per_tok"], c["norm_topk_prob"])
+    torch.testing.assert_close(got, fx["expected_fp32"], rtol=1e-4, atol=1e-5)
+    rw, re = ref_moe.route(fx["x_fp16"].float(), w["gate.weight"], c["num_experts_per_tok"], c["norm_topk_prob"])
+    assert re.shape == (19, 3) and (rw[:, :-1] >= rw[:, 1:]).all()
+    assert (abs(rw.sum(-1) - 1) < 1e-6).all() == c["norm_topk_prob"]
