@@ -195,6 +195,49 @@ int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_
                           void* stream);
 
 /* ------------------------------------------------------------------------
+ * N4 — fused sparse-MoE decode.  Replaces upstream
+ * `SharedFusedMoE` of the Qwen3-Omni talker (vllm_omni/model_executor/models/
+ * qwen3_omni/qwen3_omni_moe_talker.py:476-513; algorithm: transformers
+ * Qwen3OmniMoeTalkerTextSparseMoeBlock).  Five launches, no host sync:
+ *   mi_moe_route   p = softmax_fp32(router_logits[t, :]); top-k ids (int32) and
+ *                  weights (fp32, optionally renormalised, optionally rounded to
+ *                  weight_round_dtype as HF does; -1 = keep fp32); per-expert
+ *                  pair counts (zeroed inside).  num_experts in {64, 128, 256}.
+ *   mi_moe_align   groups the T*k (token, slot) pairs by expert, each group padded
+ *                  to a multiple of rows_per_tile (32 or 64; mi_moe_rows_per_tile()
+ *                  picks by mean pairs per expert): sorted_pairs[row] = pair or -1,
+ *                  row_of_pair[pair], tile_expert[row / rows_per_tile], num_tiles[0].
+ *                  Buffers sized by mi_moe_max_rows().
+ *   mi_moe_expert_gemm  gated != 0: out[row, :n_out] = silu(a[tok] . Wg_e^T) *
+ *                  (a[tok] . Wu_e^T), weights [E, 2*n_out, k] (gate rows then up
+ *                  rows), a = x [T, k], tok = sorted_pairs[row] / top_k;
+ *                  gated == 0: out[row, :n_out] = a[row] . W_e^T, weights
+ *                  [E, n_out, k], a = the gated output.  max_tiles bounds the
+ *                  grid; tiles >= num_tiles[0] exit.  k % 64 == 0; n_out % 64
+ *                  (gated) / % 128 == 0.
+ *   mi_moe_combine out[t] = sum_j w[t, j] * partial[row_of_pair[t*k + j]]
+ *                  (+ g * shared_out[t], g = sigmoid(x[t] . shared_gate_weight) or 1).
+ * ---------------------------------------------------------------------- */
+int32_t mi_moe_rows_per_tile(int32_t num_tokens, int32_t top_k, int32_t num_experts); /* 32 or 64 */
+int64_t mi_moe_max_rows(int32_t num_tokens, int32_t top_k, int32_t num_experts, int32_t rows_per_tile);
+int mi_moe_route(int32_t* topk_ids, float* topk_weights, int32_t* expert_counts, const void* router_logits,
+                 int32_t num_tokens, int32_t num_experts, int64_t logits_row_stride, int32_t top_k,
+                 int32_t norm_topk_prob, int logits_dtype, int weight_round_dtype, void* stream);
+int mi_moe_align(int32_t* sorted_pairs, int32_t* row_of_pair, int32_t* tile_expert, int32_t* num_tiles,
+                 const int32_t* topk_ids, const int32_t* expert_counts, int32_t num_pairs,
+                 int32_t num_experts, int64_t max_rows, int32_t rows_per_tile, void* stream);
+int mi_moe_expert_gemm(void* out, const void* a_rows, const void* weights, const int32_t* sorted_pairs,
+                       const int32_t* tile_expert, const int32_t* num_tiles, int32_t max_tiles,
+                       int32_t gated, int32_t n_out, int32_t k, int32_t top_k, int64_t a_row_stride,
+                       int64_t out_row_stride, int64_t weight_expert_stride, int32_t rows_per_tile, int dtype,
+                       void* stream);
+int mi_moe_combine(void* out, const void* partial, const int32_t* row_of_pair, const float* topk_weights,
+                   const void* shared_out, const void* x, const void* shared_gate_weight,
+                   int32_t num_tokens, int32_t hidden, int32_t top_k, int64_t partial_row_stride,
+                   int64_t out_row_stride, int64_t x_row_stride, int64_t shared_row_stride, int dtype,
+                   void* stream);
+
+/* ------------------------------------------------------------------------
  * N3 — KV extract for the stage hand-off, fused.  Replaces,
  * for raw-data connectors, `_extract_kv_cache` -> `_slice_transfer_data_for_
  * target` -> `KVCacheTransferData.to_gpu_tensor`

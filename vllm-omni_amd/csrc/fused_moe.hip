@@ -1,0 +1,424 @@
+// N4 — fused sparse-MoE decode for the Qwen3-Omni talker.  Replaces upstream `SharedFusedMoE`
+// behind `Qwen3OmniMoeModel` (vllm_omni/model_executor/models/qwen3_omni/qwen3_omni_moe_talker.py:476-513;
+// algorithm as in transformers' Qwen3OmniMoeTalkerTextSparseMoeBlock): 128 experts, top-8, H 1024, I 384.
+//
+//   route   : p = softmax_fp32(router logits); (w, e) = top-k(p); optional renormalisation        one wave / token
+//   align   : group the T*k (token, slot) pairs by expert, every group padded to a multiple of 32 rows so that a
+//             32-row tile never straddles two experts; tile -> expert map; pair -> row map          one workgroup
+//   gemm 1  : act[row, :] = silu(x[tok] . Wg_e^T) * (x[tok] . Wu_e^T)                               MFMA, bf16
+//   gemm 2  : part[row, :] = act[row, :] . Wd_e^T                                                   MFMA, bf16
+//   combine : out[t] = sum_j w[t, j] * part[row(t, j)] + sigmoid(x[t] . w_sg) * shared[t]           one WG / token
+//
+// At decode the op is weight-streaming: every expert that is hit (all of them at T*k >= a few hundred pairs)
+// streams its 1.2 MB of weights once per 32-row tile; 302 MB per layer at the real shape.  Both GEMMs use the
+// swapped form D = W . X^T (A operand = 16 weight rows, B operand = 16 token rows, K-contiguous 16-byte
+// fragments straight from global memory): a lane then owns 4 consecutive output features of one token, so the
+// SiLU-gate epilogue is lane-local (a wave computes the matching gate and up rows) and stores are 8 bytes.
+#include "common.h"
+#include "mfma_attn_common.h"
+
+namespace mi {
+namespace {
+
+// Rows (token, slot pairs) per tile: 32 or 64, chosen by the caller from the mean pairs per expert — a tile streams
+// its expert's weights once, so an expert whose pairs spill into a second tile reads them twice (measured at
+// T = 512, 32 pairs per expert on average: 190 tiles of 32 for 128 experts = 1.5x the weight bytes).
+
+// ---------------------------------------------------------------- route
+template <int DT, int EPL>  // EPL = experts per lane = E / 64
+__global__ __launch_bounds__(256) void moe_route_kernel(const void* __restrict__ logits, int64_t row_stride,
+                                                        int32_t* __restrict__ ids, float* __restrict__ weights,
+                                                        int32_t* __restrict__ counts, int T, int top_k, int norm,
+                                                        int round_dt) {
+  scalar_cache_acquire();
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  float p[EPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const int e = lane + 64 * i;
+    if constexpr (DT == MI_DTYPE_F32) p[i] = reinterpret_cast<const float*>(logits)[t * row_stride + e];
+    else if constexpr (DT == MI_DTYPE_BF16)
+      p[i] = Elem<bf16_tag>::from_bits(reinterpret_cast<const uint16_t*>(logits)[t * row_stride + e]);
+    else p[i] = Elem<f16_tag>::from_bits(reinterpret_cast<const uint16_t*>(logits)[t * row_stride + e]);
+    mx = fmaxf(mx, p[i]);
+  }
+  mx = wave_allreduce_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    p[i] = __expf(p[i] - mx);
+    s += p[i];
+  }
+  s = wave_allreduce_sum(s);
+  const float inv = 1.f / s;
+  float wsum = 0.f, myw = 0.f;
+  int mye = 0;
+  for (int j = 0; j < top_k; ++j) {  // k rounds of wave arg-max, lowest expert id on ties
+    float best = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+      if (p[i] > best) { best = p[i]; bi = lane + 64 * i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+      if (lane + 64 * i == bi) p[i] = -1.f;  // taken
+    const float w = best * inv;
+    wsum += w;
+    if (lane == j) { myw = w; mye = bi; }
+  }
+  if (lane < top_k) {
+    float w = norm ? myw / wsum : myw;
+    if (round_dt == MI_DTYPE_BF16) w = Elem<bf16_tag>::from_bits(Elem<bf16_tag>::to_bits(w));
+    else if (round_dt == MI_DTYPE_F16) w = Elem<f16_tag>::from_bits(Elem<f16_tag>::to_bits(w));
+    ids[t * top_k + lane] = mye;
+    weights[t * top_k + lane] = w;
+    atomicAdd(&counts[mye], 1);
+  }
+}
+
+// ---------------------------------------------------------------- align (one workgroup)
+__global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restrict__ ids,
+                                                         const int32_t* __restrict__ counts, int num_pairs, int E,
+                                                         int32_t* __restrict__ sorted_pairs,
+                                                         int32_t* __restrict__ row_of_pair,
+                                                         int32_t* __restrict__ tile_expert,
+                                                         int32_t* __restrict__ num_tiles, int max_rows, int rpt) {
+  scalar_cache_acquire();
+  __shared__ int32_t start[257];   // padded row offset of every expert
+  __shared__ int32_t cursor[256];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int acc = 0;
+    for (int e = 0; e < E; ++e) {
+      start[e] = acc;
+      acc += (counts[e] + rpt - 1) / rpt * rpt;
+    }
+    start[E] = acc;
+    num_tiles[0] = acc / rpt;
+  }
+  for (int e = tid; e < E; e += 1024) cursor[e] = 0;
+  __syncthreads();
+  const int total = start[E];
+  for (int r = tid; r < total && r < max_rows; r += 1024) sorted_pairs[r] = -1;
+  for (int e = tid; e < E; e += 1024)
+    for (int r = start[e]; r < start[e + 1]; r += rpt) tile_expert[r / rpt] = e;
+  __syncthreads();
+  for (int i = tid; i < num_pairs; i += 1024) {
+    const int e = ids[i];
+    const int r = start[e] + atomicAdd(&cursor[e], 1);
+    sorted_pairs[r] = i;
+    row_of_pair[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------- expert GEMMs
+struct MoeGemmParams {
+  const uint16_t* a_rows;        // gemm 1: x [T, K];  gemm 2: act [rows, K]
+  const uint16_t* w;             // [E, N_total, K]
+  uint16_t* out;                 // gemm 1: act [rows, I];  gemm 2: part [rows, H]
+  const int32_t* sorted_pairs;   // row -> pair (t * top_k + j) or -1
+  const int32_t* tile_expert;
+  const int32_t* num_tiles;
+  int32_t K, N_out, top_k;
+  int64_t a_stride, out_stride, w_expert_stride;
+};
+
+// GATED: gemm 1 — a wave owns 16 gate rows and the 16 matching up rows; WG = 4 waves = 64 outputs.
+// !GATED: gemm 2 — a wave owns 32 weight rows; WG = 4 waves = 128 outputs.
+template <typename Tag, bool GATED, int MT>  // MT = 16-row token tiles per workgroup tile (2 or 4)
+__global__ __launch_bounds__(256) void moe_gemm_kernel(const MoeGemmParams p) {
+  constexpr int kMoeRows = 16 * MT;
+  scalar_cache_acquire();
+  using E = Elem<Tag>;
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so hand every XCD
+  // a CONTIGUOUS range of tiles — the tiles of one expert then stream its weights through one L2, back to back
+  // (gridDim.x is a multiple of 8, so the XCD of a workgroup is blockIdx.x % 8 for every blockIdx.y)
+  const int nt = p.num_tiles[0];
+  const int per_xcd = (nt + 7) >> 3;   // ranges sized by the LIVE tile count, or the last XCDs would sit idle
+  const int slot = blockIdx.x >> 3;
+  const int tile = (blockIdx.x & 7) * per_xcd + slot;
+  if (slot >= per_xcd || tile >= nt) return;  // whole workgroup: uniform
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int e = p.tile_expert[tile];
+  const int row0 = tile * kMoeRows;
+  // B operand rows (tokens): MT m-tiles of 16
+  const uint16_t* brow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = row0 + 16 * mt + r16;
+    if constexpr (GATED) {
+      const int pair = p.sorted_pairs[row];
+      brow[mt] = p.a_rows + (int64_t)(pair < 0 ? 0 : pair / p.top_k) * p.a_stride + 16 * kg;
+    } else {
+      brow[mt] = p.a_rows + (int64_t)row * p.a_stride + 16 * kg;
+    }
+  }
+  // A operand rows (weights)
+  const int n_base = GATED ? blockIdx.y * 64 + 16 * wid : blockIdx.y * 128 + 32 * wid;
+  const uint16_t* wexp = p.w + (int64_t)e * p.w_expert_stride;
+  const uint16_t* arow[2];
+  arow[0] = wexp + (int64_t)(n_base + r16) * p.K + 16 * kg;                                  // gate / rows 0-15
+  arow[1] = wexp + (int64_t)(GATED ? p.N_out + n_base + r16 : n_base + 16 + r16) * p.K + 16 * kg;  // up / rows 16-31
+  f32x4_t acc[2][MT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // Software pipeline, by hand (hipcc does not unroll this runtime-trip-count loop: it emitted 4 loads -> wait ->
+  // 4 MFMAs per iteration, i.e. one 4 KB k-step in flight per wave).  Groups of UNR k-steps: the 4*UNR fragment
+  // loads of the next group are issued before the MFMAs of the current one.
+  constexpr int UNR = 2;   // 2 k-steps per group: ~100 VGPRs -> 5 workgroups per CU, every tile of a decode batch resident at once
+  uint4 fa[2][UNR][2], fb[2][UNR][MT];
+  auto load_group = [&](int buf, int k0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      // k permutation inside a 64-wide block (the MFMA only needs A and B to agree on it): lane group kg holds
+      // elements 16 kg .. 16 kg + 7 for the even k-step and 16 kg + 8 .. + 15 for the odd one, so the four lanes of
+      // a row cover one whole 128-byte line per instruction pair instead of two half lines
+      const int k = k0 + 64 * (u >> 1);
+      const bool ok = k < p.K;   // K is a multiple of 64, not necessarily of 32 * UNR
+      const int kk = (ok ? k : 0) + 8 * (u & 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[buf][u][i] = *reinterpret_cast<const uint4*>(arow[i] + kk);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fb[buf][u][i] = *reinterpret_cast<const uint4*>(brow[i] + kk);
+      if (!ok) fa[buf][u][0] = fa[buf][u][1] = make_uint4(0, 0, 0, 0);   // a zero weight fragment adds nothing
+    }
+  };
+  auto mma_group = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        acc[0][j] = mfma16<Tag>(fa[buf][u][0], fb[buf][u][j], acc[0][j]);
+        acc[1][j] = mfma16<Tag>(fa[buf][u][1], fb[buf][u][j], acc[1][j]);
+      }
+    }
+  };
+  load_group(0, 0);
+  for (int k0 = 0; k0 < p.K; k0 += 2 * 32 * UNR) {
+    load_group(1, k0 + 32 * UNR);       // past-the-end groups load row starts and contribute zeros
+    mma_group(0);
+    if (k0 + 32 * UNR >= p.K) break;
+    load_group(0, k0 + 2 * 32 * UNR);
+    mma_group(1);
+  }
+  static_assert(UNR % 2 == 0, "a group covers whole 64-wide k blocks");
+  // D[n][m]: lane = column m (token r16 of m-tile), rows n = 4 kg + r
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = row0 + 16 * mt + r16;
+    uint16_t* o = p.out + (int64_t)row * p.out_stride;
+    if constexpr (GATED) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // the 16-bit grid of the two GEMM outputs first (what separate GEMM + SiLU-mul kernels would see)
+        const float g = E::from_bits(E::to_bits(acc[0][mt][r])), u = E::from_bits(E::to_bits(acc[1][mt][r]));
+        v[r] = g / (1.f + __expf(-g)) * u;
+      }
+      uint2 q;
+      q.x = E::pack(v[0], v[1]);
+      q.y = E::pack(v[2], v[3]);
+      *reinterpret_cast<uint2*>(o + n_base + 4 * kg) = q;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint2 q;
+        q.x = E::pack(acc[i][mt][0], acc[i][mt][1]);
+        q.y = E::pack(acc[i][mt][2], acc[i][mt][3]);
+        *reinterpret_cast<uint2*>(o + n_base + 16 * i + 4 * kg) = q;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- combine
+template <typename Tag>
+__global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ part,
+                                                          const int32_t* __restrict__ row_of_pair,
+                                                          const float* __restrict__ weights,
+                                                          const uint16_t* __restrict__ shared,
+                                                          const uint16_t* __restrict__ x,
+                                                          const uint16_t* __restrict__ shared_gate_w, int H, int top_k,
+                                                          int64_t part_stride, int64_t out_stride, int64_t x_stride,
+                                                          int64_t shared_stride) {
+  scalar_cache_acquire();
+  using E = Elem<Tag>;
+  __shared__ float red[4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  float gate = 0.f;
+  if (shared) {
+    gate = 1.f;
+    if (shared_gate_w) {  // sigmoid(x[t] . w_sg)
+      float d = 0.f;
+      for (int i = tid; i < H; i += 256) d += E::from_bits(x[t * x_stride + i]) * E::from_bits(shared_gate_w[i]);
+      d = wave_allreduce_sum(d);
+      if ((tid & 63) == 0) red[tid >> 6] = d;
+      __syncthreads();
+      d = (red[0] + red[1]) + (red[2] + red[3]);
+      gate = 1.f / (1.f + __expf(-d));
+    }
+  }
+  for (int c = tid * 4; c < H; c += 1024) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < top_k; ++j) {
+      const float w = weights[t * top_k + j];
+      const uint2 v = *reinterpret_cast<const uint2*>(part + (int64_t)row_of_pair[t * top_k + j] * part_stride + c);
+      a[0] += w * E::lo(v.x); a[1] += w * E::hi(v.x); a[2] += w * E::lo(v.y); a[3] += w * E::hi(v.y);
+    }
+    if (shared) {
+      const uint2 v = *reinterpret_cast<const uint2*>(shared + t * shared_stride + c);
+      a[0] += gate * E::lo(v.x); a[1] += gate * E::hi(v.x); a[2] += gate * E::lo(v.y); a[3] += gate * E::hi(v.y);
+    }
+    uint2 q;
+    q.x = E::pack(a[0], a[1]);
+    q.y = E::pack(a[2], a[3]);
+    *reinterpret_cast<uint2*>(out + t * out_stride + c) = q;
+  }
+}
+
+}  // namespace
+}  // namespace mi
+
+extern "C" int32_t mi_moe_rows_per_tile(int32_t num_tokens, int32_t top_k, int32_t num_experts) {
+  if (num_tokens <= 0 || top_k <= 0 || num_experts <= 0) return 32;
+  // 64-row tiles halve the tile count once experts average more than a tile, but measured slower at the talker
+  // shape (T = 512: 172 us against 158 us: twice the token fragments per workgroup, half the loads in flight);
+  // with the XCD-aware tile order the second tile of an expert finds the weights in L2 anyway
+  (void)num_tokens; (void)top_k; (void)num_experts;
+  return 32;
+}
+
+extern "C" int64_t mi_moe_max_rows(int32_t num_tokens, int32_t top_k, int32_t num_experts, int32_t rows_per_tile) {
+  if (num_tokens <= 0 || top_k <= 0 || num_experts <= 0 || (rows_per_tile != 32 && rows_per_tile != 64)) return 0;
+  const int64_t pairs = (int64_t)num_tokens * top_k;
+  const int64_t hit = pairs < num_experts ? pairs : num_experts;  // each hit expert pads by < rows_per_tile rows
+  return (pairs + hit * (rows_per_tile - 1) + rows_per_tile - 1) / rows_per_tile * rows_per_tile;
+}
+
+extern "C" int mi_moe_route(int32_t* topk_ids, float* topk_weights, int32_t* expert_counts, const void* router_logits,
+                            int32_t num_tokens, int32_t num_experts, int64_t logits_row_stride, int32_t top_k,
+                            int32_t norm_topk_prob, int logits_dtype, int weight_round_dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!topk_ids || !topk_weights || !expert_counts || !router_logits || num_tokens < 0) return MI_ERR_INVALID_ARG;
+  if (num_experts != 64 && num_experts != 128 && num_experts != 256) return MI_ERR_UNSUPPORTED;
+  if (top_k <= 0 || top_k > 16 || top_k > num_experts) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(expert_counts, 0, sizeof(int32_t) * num_experts, s) != hipSuccess) return MI_ERR_LAUNCH;
+  const dim3 grid((num_tokens + 3) / 4), block(256);
+#define MI_ROUTE(DT, EPL)                                                                                        \
+  hipLaunchKernelGGL((moe_route_kernel<DT, EPL>), grid, block, 0, s, router_logits, logits_row_stride, topk_ids, \
+                     topk_weights, expert_counts, num_tokens, top_k, norm_topk_prob, weight_round_dtype)
+#define MI_ROUTE_E(DT)                                  \
+  do {                                                  \
+    if (num_experts == 64) MI_ROUTE(DT, 1);             \
+    else if (num_experts == 128) MI_ROUTE(DT, 2);       \
+    else MI_ROUTE(DT, 4);                               \
+  } while (0)
+  switch (logits_dtype) {
+    case MI_DTYPE_F32: MI_ROUTE_E(MI_DTYPE_F32); break;
+    case MI_DTYPE_BF16: MI_ROUTE_E(MI_DTYPE_BF16); break;
+    case MI_DTYPE_F16: MI_ROUTE_E(MI_DTYPE_F16); break;
+    default: return MI_ERR_UNSUPPORTED;
+  }
+#undef MI_ROUTE_E
+#undef MI_ROUTE
+  return launch_status();
+}
+
+extern "C" int mi_moe_align(int32_t* sorted_pairs, int32_t* row_of_pair, int32_t* tile_expert, int32_t* num_tiles,
+                            const int32_t* topk_ids, const int32_t* expert_counts, int32_t num_pairs,
+                            int32_t num_experts, int64_t max_rows, int32_t rows_per_tile, void* stream) {
+  using namespace mi;
+  if (num_pairs == 0) return MI_OK;
+  if (!sorted_pairs || !row_of_pair || !tile_expert || !num_tiles || !topk_ids || !expert_counts || num_pairs < 0)
+    return MI_ERR_INVALID_ARG;
+  if (num_experts <= 0 || num_experts > 256 || max_rows > 0x7fffffff) return MI_ERR_UNSUPPORTED;
+  if (rows_per_tile != 32 && rows_per_tile != 64) return MI_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), topk_ids,
+                     expert_counts, num_pairs, num_experts, sorted_pairs, row_of_pair, tile_expert, num_tiles,
+                     (int)max_rows, (int)rows_per_tile);
+  return launch_status();
+}
+
+extern "C" int mi_moe_expert_gemm(void* out, const void* a_rows, const void* weights, const int32_t* sorted_pairs,
+                                  const int32_t* tile_expert, const int32_t* num_tiles, int32_t max_tiles,
+                                  int32_t gated, int32_t n_out, int32_t k, int32_t top_k, int64_t a_row_stride,
+                                  int64_t out_row_stride, int64_t weight_expert_stride, int32_t rows_per_tile,
+                                  int dtype, void* stream) {
+  using namespace mi;
+  if (max_tiles == 0) return MI_OK;
+  if (!out || !a_rows || !weights || !sorted_pairs || !tile_expert || !num_tiles || max_tiles < 0)
+    return MI_ERR_INVALID_ARG;
+  if (k <= 0 || k % 64 || n_out <= 0 || n_out % (gated ? 64 : 128)) return MI_ERR_UNSUPPORTED;
+  if (rows_per_tile != 32 && rows_per_tile != 64) return MI_ERR_INVALID_ARG;
+  if (a_row_stride % 8 || out_row_stride % 4 || weight_expert_stride % 8) return MI_ERR_INVALID_ARG;
+  if (((uintptr_t)a_rows | (uintptr_t)weights) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
+  MoeGemmParams p;
+  p.a_rows = reinterpret_cast<const uint16_t*>(a_rows);
+  p.w = reinterpret_cast<const uint16_t*>(weights);
+  p.out = reinterpret_cast<uint16_t*>(out);
+  p.sorted_pairs = sorted_pairs;
+  p.tile_expert = tile_expert;
+  p.num_tiles = num_tiles;
+  p.K = k;
+  p.N_out = n_out;
+  p.top_k = top_k;
+  p.a_stride = a_row_stride;
+  p.out_stride = out_row_stride;
+  p.w_expert_stride = weight_expert_stride;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((max_tiles + 7) / 8 * 8, gated ? n_out / 64 : n_out / 128), block(256);
+#define MI_MOE_GEMM(TAG, G, M) hipLaunchKernelGGL((moe_gemm_kernel<TAG, G, M>), grid, block, 0, s, p)
+#define MI_MOE_GEMM_T(TAG)                                \
+  do {                                                    \
+    if (gated && rows_per_tile == 32) MI_MOE_GEMM(TAG, true, 2);        \
+    else if (gated) MI_MOE_GEMM(TAG, true, 4);            \
+    else if (rows_per_tile == 32) MI_MOE_GEMM(TAG, false, 2);           \
+    else MI_MOE_GEMM(TAG, false, 4);                      \
+  } while (0)
+  if (dtype == MI_DTYPE_BF16) MI_MOE_GEMM_T(bf16_tag);
+  else if (dtype == MI_DTYPE_F16) MI_MOE_GEMM_T(f16_tag);
+  else return MI_ERR_UNSUPPORTED;
+#undef MI_MOE_GEMM_T
+#undef MI_MOE_GEMM
+  return launch_status();
+}
+
+extern "C" int mi_moe_combine(void* out, const void* partial, const int32_t* row_of_pair, const float* topk_weights,
+                              const void* shared_out, const void* x, const void* shared_gate_weight,
+                              int32_t num_tokens, int32_t hidden, int32_t top_k, int64_t partial_row_stride,
+                              int64_t out_row_stride, int64_t x_row_stride, int64_t shared_row_stride, int dtype,
+                              void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!out || !partial || !row_of_pair || !topk_weights || num_tokens < 0 || hidden <= 0 || top_k <= 0)
+    return MI_ERR_INVALID_ARG;
+  if (hidden % 4 || partial_row_stride % 4 || out_row_stride % 4 || shared_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if (shared_gate_weight && (!shared_out || !x)) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto pp = reinterpret_cast<const uint16_t*>(partial);
+  auto sh = reinterpret_cast<const uint16_t*>(shared_out);
+  auto xx = reinterpret_cast<const uint16_t*>(x);
+  auto gw = reinterpret_cast<const uint16_t*>(shared_gate_weight);
+  if (dtype == MI_DTYPE_BF16)
+    hipLaunchKernelGGL((moe_combine_kernel<bf16_tag>), dim3(num_tokens), dim3(256), 0, s, o, pp, row_of_pair, topk_weights, sh, xx, gw, hidden, top_k, partial_row_stride, out_row_stride, x_row_stride, shared_row_stride);
+  else if (dtype == MI_DTYPE_F16)
+    hipLaunchKernelGGL((moe_combine_kernel<f16_tag>), dim3(num_tokens), dim3(256), 0, s, o, pp, row_of_pair, topk_weights, sh, xx, gw, hidden, top_k, partial_row_stride, out_row_stride, x_row_stride, shared_row_stride);
+  else
+    return MI_ERR_UNSUPPORTED;
+  return launch_status();
+}

@@ -47,6 +47,14 @@ SIGNATURES = {
     "mi_silu_and_mul": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_mask_logits_argmax": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int, _P]),
+    "mi_moe_rows_per_tile": (c_int32, [c_int32, c_int32, c_int32]),
+    "mi_moe_max_rows": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "mi_moe_route": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32, c_int, c_int, _P]),
+    "mi_moe_align": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P]),
+    "mi_moe_expert_gemm": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64,
+                                   c_int64, c_int32, c_int, _P]),
+    "mi_moe_combine": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,
+                               c_int, _P]),
     "mi_int8_dequant": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_kv_pack": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                            c_int64, c_int64, c_int64, _P]),

@@ -337,3 +337,60 @@ def int8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: 
     else:
         y = int8_gemm_dequant(xq, xs, wq, w_scale, bias, x.dtype)
     return y.view(*x.shape[:-1], n)
+
+
+# --------------------------------------------------------------------------- N4: fused sparse MoE
+def moe_route(router_logits: torch.Tensor, top_k: int, norm_topk_prob: bool, round_to: Optional[torch.dtype] = None):
+    """-> (topk_ids int32 [T, k], topk_weights fp32 [T, k], expert_counts int32 [E])."""
+    _gpu(router_logits)
+    t, e = router_logits.shape
+    ids = torch.empty(t, top_k, dtype=torch.int32, device=router_logits.device)
+    w = torch.empty(t, top_k, dtype=torch.float32, device=router_logits.device)
+    counts = torch.empty(e, dtype=torch.int32, device=router_logits.device)
+    check("mi_moe_route", lib.mi_moe_route(_p(ids), _p(w), _p(counts), _p(router_logits), t, e, router_logits.stride(0),
+                                           int(top_k), 1 if norm_topk_prob else 0, _dt(router_logits.dtype),
+                                           -1 if round_to is None else _dt(round_to), _stream()))
+    return ids, w, counts
+
+
+def fused_moe(x: torch.Tensor, router_logits: torch.Tensor, w_gate_up: torch.Tensor, w_down: torch.Tensor, top_k: int,
+              norm_topk_prob: bool = False, shared_out: Optional[torch.Tensor] = None,
+              shared_gate_weight: Optional[torch.Tensor] = None, routing=None,
+              rows_per_tile: int = 0) -> torch.Tensor:
+    """Sparse-MoE layer output for x [T, H]: route -> align -> gated expert GEMM -> down expert GEMM ->
+    weighted combine (+ sigmoid-gated shared expert output computed by the caller).  w_gate_up [E, 2I, H] (gate rows
+    then up rows), w_down [E, H, I].  ``routing`` = (ids int32, weights fp32) skips the router (tests)."""
+    _gpu(x, router_logits, w_gate_up, w_down, shared_out, shared_gate_weight)
+    t, h = x.shape
+    e, two_i, _ = w_gate_up.shape
+    i = two_i // 2
+    dev = x.device
+    if routing is None:
+        ids, w, counts = moe_route(router_logits, top_k, norm_topk_prob, round_to=x.dtype)
+    else:
+        ids, w = routing
+        counts = torch.bincount(ids.reshape(-1).long(), minlength=e).to(torch.int32)
+    pairs = t * top_k
+    rpt = rows_per_tile or int(lib.mi_moe_rows_per_tile(t, top_k, e))
+    max_rows = int(lib.mi_moe_max_rows(t, top_k, e, rpt))
+    i32 = dict(dtype=torch.int32, device=dev)
+    sorted_pairs = torch.empty(max_rows, **i32)
+    row_of_pair = torch.empty(pairs, **i32)
+    tile_expert = torch.empty(max_rows // rpt, **i32)
+    num_tiles = torch.empty(1, **i32)
+    check("mi_moe_align", lib.mi_moe_align(_p(sorted_pairs), _p(row_of_pair), _p(tile_expert), _p(num_tiles), _p(ids),
+                                           _p(counts), pairs, e, max_rows, rpt, _stream()))
+    act = torch.empty(max_rows, i, dtype=x.dtype, device=dev)
+    part = torch.empty(max_rows, h, dtype=x.dtype, device=dev)
+    dt = _dt(x.dtype)
+    check("mi_moe_expert_gemm", lib.mi_moe_expert_gemm(
+        _p(act), _p(x), _p(w_gate_up), _p(sorted_pairs), _p(tile_expert), _p(num_tiles), max_rows // rpt, 1, i, h, top_k,
+        x.stride(0), act.stride(0), w_gate_up.stride(0), rpt, dt, _stream()))
+    check("mi_moe_expert_gemm", lib.mi_moe_expert_gemm(
+        _p(part), _p(act), _p(w_down), _p(sorted_pairs), _p(tile_expert), _p(num_tiles), max_rows // rpt, 0, h, i, top_k,
+        act.stride(0), part.stride(0), w_down.stride(0), rpt, dt, _stream()))
+    out = torch.empty_like(x)
+    check("mi_moe_combine", lib.mi_moe_combine(
+        _p(out), _p(part), _p(row_of_pair), _p(w), _p(shared_out), _p(x), _p(shared_gate_weight), t, h, top_k,
+        part.stride(0), out.stride(0), x.stride(0), shared_out.stride(0) if shared_out is not None else 0, dt, _stream()))
+    return out
