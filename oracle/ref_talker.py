@@ -91,8 +91,22 @@ def decoder_stack(cfg, weights: dict, h: torch.Tensor, positions: torch.Tensor, 
         a = R._rt(a.reshape(t, nq * d), rt)
         o = _lin(a, weights[p + "self_attn.o_proj.weight"], None, rt)
         x, residual = R.fused_add_rms_norm(o, residual, weights[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps, rt)
-        gu = _lin(x, weights[p + "mlp.gate_up_proj.weight"], None, rt)
-        h = _lin(R.silu_and_mul(gu, rt), weights[p + "mlp.down_proj.weight"], None, rt)
+        if p + "mlp.gate.weight" in weights:   # Qwen3-Omni talker: sparse-MoE MLP (oracle/ref_moe.py)
+            from . import ref_moe
+
+            mw = {k[len(p + "mlp."):]: v for k, v in weights.items() if k.startswith(p + "mlp.")}
+            if "shared_expert.gate_up_proj.weight" in mw:
+                gu_w = mw.pop("shared_expert.gate_up_proj.weight")
+                mw["shared_expert.gate_proj.weight"], mw["shared_expert.up_proj.weight"] = gu_w.chunk(2, 0)
+            logits = R._rt(x @ mw["gate.weight"].to(F32).t(), rt)       # the device routes on 16-bit router logits
+            pr = torch.softmax(logits, -1)
+            rw, re = torch.topk(pr, cfg.num_experts_per_tok, -1)
+            if cfg.norm_topk_prob:
+                rw = rw / rw.sum(-1, keepdim=True)
+            h = ref_moe.moe_block(x, mw, cfg.num_experts_per_tok, cfg.norm_topk_prob, rt, routing=(rw, re))
+        else:
+            gu = _lin(x, weights[p + "mlp.gate_up_proj.weight"], None, rt)
+            h = _lin(R.silu_and_mul(gu, rt), weights[p + "mlp.down_proj.weight"], None, rt)
     hidden, _ = R.fused_add_rms_norm(h, residual, weights["language_model.model.norm.weight"], cfg.rms_norm_eps, rt)
     return hidden
 
@@ -128,8 +142,18 @@ def random_weights(cfg, seed: int = 0, dtype=torch.bfloat16, num_layers: Optiona
         if cfg.qk_norm:
             out[p + "self_attn.q_norm.weight"] = w(d, std=0.01, mean=1.0)
             out[p + "self_attn.k_norm.weight"] = w(d, std=0.01, mean=1.0)
-        out[p + "mlp.gate_up_proj.weight"] = w(2 * i, h)
-        out[p + "mlp.down_proj.weight"] = w(h, i)
+        if getattr(cfg, "num_experts", 0):
+            e, mi, si = cfg.num_experts, cfg.moe_intermediate_size, cfg.shared_expert_intermediate_size
+            out[p + "mlp.gate.weight"] = w(e, h, std=0.1)
+            out[p + "mlp.experts.gate_up_proj"] = w(e, 2 * mi, h, std=0.05)
+            out[p + "mlp.experts.down_proj"] = w(e, h, mi, std=0.05)
+            if si:
+                out[p + "mlp.shared_expert.gate_up_proj.weight"] = w(2 * si, h)
+                out[p + "mlp.shared_expert.down_proj.weight"] = w(h, si)
+                out[p + "mlp.shared_expert_gate.weight"] = w(1, h, std=0.1)
+        else:
+            out[p + "mlp.gate_up_proj.weight"] = w(2 * i, h)
+            out[p + "mlp.down_proj.weight"] = w(h, i)
         out[p + "input_layernorm.weight"] = w(h, std=0.01, mean=1.0)
         out[p + "post_attention_layernorm.weight"] = w(h, std=0.01, mean=1.0)
     return out

@@ -413,3 +413,56 @@ def test_async_output_pipeline_equals_sync(dev, enforce_eager):
     for rid in h_sync:
         for a_, b_ in zip(h_sync[rid], h_async[rid]):
             assert torch.equal(a_, b_)
+
+
+def test_moe_talker_decode_steps_match_oracle(dev):
+    """Qwen3-Omni talker layer in small (q/k-norm attention + sparse-MoE MLP with a shared expert)
+    through the runner — eager and as a hipGraph — against the oracle stack with ref_moe in the MLP position."""
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SchedulerOutput
+
+    for enforce_eager in (True, False):
+        ctxs = [5, 16, 40, 1, 33]
+        cfg, runner, w, cpu_caches, mgr, reqs = _setup(dev, "mini_moe_talker", ctxs, enforce_eager, False)
+        B, bs = len(reqs), 16
+        csc = ref_ops.build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
+        last_ids = torch.tensor([r.prompt_token_ids[-1] for r in reqs], dtype=torch.int64)
+        table = torch.zeros(B, 16, dtype=torch.int32)
+        for step in range(2):
+            sched = {r.request_id: 1 for r in reqs}
+            if step == 0:
+                so = SchedulerOutput(scheduled_new_reqs=[
+                    NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id),
+                                   r.num_computed_tokens, additional_information=r.additional_information) for r in reqs],
+                    num_scheduled_tokens=sched, total_num_scheduled_tokens=B)
+            else:
+                new_blocks = []
+                for r in reqs:
+                    nb_ = mgr.allocate_slots(r, 1)
+                    new_blocks.append(nb_.get_block_ids() if nb_.blocks[0] else None)
+                so = SchedulerOutput(scheduled_cached_reqs=CachedRequestData(
+                    req_ids=[r.request_id for r in reqs], new_block_ids=new_blocks,
+                    num_computed_tokens=[r.num_computed_tokens for r in reqs], num_output_tokens=[step] * B),
+                    num_scheduled_tokens=sched, total_num_scheduled_tokens=B)
+            for i, r in enumerate(reqs):
+                ids = mgr.get_block_ids(r.request_id)[0]
+                table[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+            runner.execute_model(so)
+            out = runner.sample_tokens()
+            order = [out.req_id_to_index[r.request_id] for r in reqs]
+            pos = torch.tensor([r.num_computed_tokens for r in reqs], dtype=torch.int64)
+            step_vec = torch.stack([r.additional_information["thinker_reply_part"][step] for r in reqs])
+            emb = ref_talker.decode_embeds(w, last_ids, step_vec, torch.bfloat16)
+            slots = ref_ops.slot_mapping(table, torch.arange(B), pos, bs)
+            hidden = ref_talker.talker_step(cfg, w, emb, pos, cpu_caches, table, (pos + 1).to(torch.int32),
+                                            torch.arange(B + 1, dtype=torch.int32), slots, csc, torch.bfloat16)
+            got = torch.stack([out.pooler_output[j]["hidden"][0] for j in order]).float()
+            # an expert swapped on a near-tie of two router probabilities moves a whole row: allow one such row
+            row_err = (got - hidden).abs().amax(-1)
+            assert (row_err > 0.1).sum() <= 1, row_err
+            ok = row_err <= 0.1
+            torch.testing.assert_close(got[ok], hidden[ok], rtol=3e-2, atol=3e-2)
+            got_ids = torch.tensor([out.sampled_token_ids[j][0] for j in order])
+            last_ids = got_ids.clone()
+            for r, t in zip(reqs, got_ids.tolist()):
+                r.num_computed_tokens += 1
+                r.output_token_ids.append(t)

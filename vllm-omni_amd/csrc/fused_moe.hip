@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const void* __restrict__
 #pragma unroll
     for (int i = 0; i < EPL; ++i)
       if (lane + 64 * i == bi) p[i] = -1.f;  // taken
+    if (bi == 0x7fffffff) {  // NaN logits: no comparison succeeds.  Never let an out-of-range id reach the
+      bi = j;                // counters or the grouping; experts 0..k-1 with weight NaN keep the poison visible
+      best = __builtin_nanf("");
+    }
     const float w = best * inv;
     wsum += w;
     if (lane == j) { myw = w; mye = bi; }
@@ -83,6 +87,10 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const void* __restrict__
     weights[t * top_k + lane] = w;
     atomicAdd(&counts[mye], 1);
   }
+}
+
+__global__ __launch_bounds__(256) void moe_zero_counts_kernel(int32_t* __restrict__ counts, int E) {
+  for (int e = threadIdx.x; e < E; e += 256) counts[e] = 0;
 }
 
 // ---------------------------------------------------------------- align (one workgroup)
@@ -114,7 +122,9 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
   __syncthreads();
   for (int i = tid; i < num_pairs; i += 1024) {
     const int e = ids[i];
+    if (e < 0 || e >= E) { row_of_pair[i] = 0; continue; }   // caller-supplied routing out of range: row 0, never OOB
     const int r = start[e] + atomicAdd(&cursor[e], 1);
+    if (r >= start[e + 1] || r >= max_rows) { row_of_pair[i] = 0; continue; }   // counts disagree with ids
     sorted_pairs[r] = i;
     row_of_pair[i] = r;
   }
@@ -316,7 +326,9 @@ extern "C" int mi_moe_route(int32_t* topk_ids, float* topk_weights, int32_t* exp
   if (num_experts != 64 && num_experts != 128 && num_experts != 256) return MI_ERR_UNSUPPORTED;
   if (top_k <= 0 || top_k > 16 || top_k > num_experts) return MI_ERR_INVALID_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(expert_counts, 0, sizeof(int32_t) * num_experts, s) != hipSuccess) return MI_ERR_LAUNCH;
+  // (a kernel, not hipMemsetAsync: twenty memset nodes inside the decode hipGraph of the 20-layer talker ended in
+  //  "write access to a read-only page" at replay on this stack, while the same graph with 2-3 of them was fine)
+  hipLaunchKernelGGL(moe_zero_counts_kernel, dim3(1), dim3(256), 0, s, expert_counts, num_experts);
   const dim3 grid((num_tokens + 3) / 4), block(256);
 #define MI_ROUTE(DT, EPL)                                                                                        \
   hipLaunchKernelGGL((moe_route_kernel<DT, EPL>), grid, block, 0, s, router_logits, logits_row_stride, topk_ids, \

@@ -51,6 +51,12 @@ class TalkerConfig:
     tts_codec_end_token_id: Optional[int] = 8294
     tts_codec_pad_token_id: Optional[int] = 8292
     tts_codec_mask_token_id: Optional[int] = 8296
+    # sparse-MoE MLP (Qwen3-Omni talker); num_experts == 0: dense SiLU MLP
+    num_experts: int = 0
+    num_experts_per_tok: int = 0
+    moe_intermediate_size: int = 0
+    norm_topk_prob: bool = False
+    shared_expert_intermediate_size: int = 0
 
     @classmethod
     def from_json(cls, path_or_name: str) -> "TalkerConfig":
@@ -152,7 +158,18 @@ class Qwen2Attention:
 class Qwen2DecoderLayer:
     def __init__(self, cfg: TalkerConfig, dtype, device, prefix: str, generator=None):
         self.self_attn = Qwen2Attention(cfg, dtype, device, f"{prefix}.self_attn", generator)
-        self.mlp = Qwen2MLP(cfg, dtype, device, generator)
+        if cfg.num_experts:
+            # Qwen3-Omni talker: every layer's MLP is the sparse-MoE block (decoder_sparse_step 1,
+            # qwen3_omni_moe_talker.py:476-513); experts are not sharded over TP ranks here
+            from .moe import MoEConfig, Qwen3OmniMoeSparseMoeBlock
+
+            if get_tensor_model_parallel_world_size() > 1:
+                raise NotImplementedError("the MoE talker runs data-parallel only (tp_size 1)")
+            self.mlp = Qwen3OmniMoeSparseMoeBlock(
+                MoEConfig(cfg.hidden_size, cfg.moe_intermediate_size, cfg.num_experts, cfg.num_experts_per_tok,
+                          cfg.norm_topk_prob, cfg.shared_expert_intermediate_size or None), dtype, device, generator)
+        else:
+            self.mlp = Qwen2MLP(cfg, dtype, device, generator)
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
 
@@ -288,8 +305,17 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
             if a.q_norm is not None:
                 yield p + "self_attn.q_norm.weight", a.q_norm.weight
                 yield p + "self_attn.k_norm.weight", a.k_norm.weight
-            yield p + "mlp.gate_up_proj.weight", m.gate_up_proj.weight
-            yield p + "mlp.down_proj.weight", m.down_proj.weight
+            if self.config.num_experts:
+                yield p + "mlp.gate.weight", m.gate_weight
+                yield p + "mlp.experts.gate_up_proj", m.gate_up_proj
+                yield p + "mlp.experts.down_proj", m.down_proj
+                if m.shared_gate_up is not None:
+                    yield p + "mlp.shared_expert.gate_up_proj.weight", m.shared_gate_up
+                    yield p + "mlp.shared_expert.down_proj.weight", m.shared_down
+                    yield p + "mlp.shared_expert_gate.weight", m.shared_expert_gate
+            else:
+                yield p + "mlp.gate_up_proj.weight", m.gate_up_proj.weight
+                yield p + "mlp.down_proj.weight", m.down_proj.weight
             yield p + "input_layernorm.weight", layer.input_layernorm.weight
             yield p + "post_attention_layernorm.weight", layer.post_attention_layernorm.weight
 
@@ -302,8 +328,9 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
             p = f"language_model.model.layers.{i}."
             yield p + "self_attn.qkv_proj.weight", layer.self_attn.qkv_proj
             yield p + "self_attn.o_proj.weight", layer.self_attn.o_proj
-            yield p + "mlp.gate_up_proj.weight", layer.mlp.gate_up_proj
-            yield p + "mlp.down_proj.weight", layer.mlp.down_proj
+            if not self.config.num_experts:      # expert weights stay 16-bit
+                yield p + "mlp.gate_up_proj.weight", layer.mlp.gate_up_proj
+                yield p + "mlp.down_proj.weight", layer.mlp.down_proj
 
     def quantize_int8(self) -> None:
         from .layers import quantize_int8_
@@ -328,7 +355,9 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
             if name not in full or dst is None:
                 continue
             w = full[name]
-            if name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
+            if ".mlp.experts." in name or ".mlp.shared_expert" in name or name.endswith(".mlp.gate.weight"):
+                pass   # MoE weights are replicated (tp_size 1)
+            elif name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
                 w = shard_qkv(w, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, tp, r)
             elif name.endswith("gate_up_proj.weight"):
                 w = shard_merged_column(w, [cfg.intermediate_size] * 2, tp, r)
