@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--sync-output", action="store_true",
                     help="wait for every step's ids + hidden states on the host before launching the next step (the "
                          "default pipelines them one step behind: sample_tokens(async_output=True))")
+    ap.add_argument("--code-predictor", action="store_true",
+                    help="Qwen3-Omni: run the code predictor inside every decode step (talker_mtp); needs a config with "
+                         "input_projection=false, e.g. --config qwen3_omni_talker")
     ap.add_argument("--simulate-shard", default=None, metavar="TP,DP",
                     help="ONE GPU runs rank 0 of a (tp, dp) plan with the collectives stubbed: per-rank compute time of "
                          "that plan, i.e. its step time without communication.  A sizing estimate, flagged in the JSON")
@@ -76,6 +79,12 @@ def parallel_plan(n_gpus: int, cfg) -> tuple[int, int, str]:
         tp //= 2
     dp = n_gpus // tp
     return tp, dp, plan_label(tp, dp)
+
+
+def _code_predictor_config():
+    from vllm_omni_amd.code_predictor import CodePredictorConfig
+
+    return CodePredictorConfig()
 
 
 def plan_label(tp: int, dp: int) -> str:
@@ -327,7 +336,8 @@ def main():
     max_model_len = a.ctx + a.block_size
     runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=local_batch, max_model_len=max_model_len,
                               max_num_batched_tokens=max(local_batch, 256), block_size=a.block_size,
-                              kv_layout=a.kv_layout, enforce_eager=a.eager, seed=0, quantization=a.quantization)
+                              kv_layout=a.kv_layout, enforce_eager=a.eager, seed=0, quantization=a.quantization,
+                              code_predictor=_code_predictor_config() if a.code_predictor else None)
     runner.load_model()
     # every rank of a TP group must see the same schedule: seed by data-parallel replica only
     sched = SyntheticScheduler(local_batch, a.ctx, a.block_size, cfg.vocab_size, rank_seed=rank // tp)
@@ -395,8 +405,9 @@ def main():
     out = {
         "simulated": bool(a.simulate_shard),
         "metric": ("decode tokens/s, Qwen-Omni-7B talker, bs=256 ctx=4k"
-                   if (a.config, a.batch, a.ctx, a.quantization) == ("qwen2_5_omni_talker", 256, 4096, None)
-                   else f"decode tokens/s, {cfg.name}{' int8' if a.quantization else ''}, bs={a.batch} ctx={a.ctx} (not the headline shape)"),
+                   if (a.config, a.batch, a.ctx, a.quantization, a.code_predictor) == ("qwen2_5_omni_talker", 256, 4096, None, False)
+                   else f"decode tokens/s, {cfg.name}{' int8' if a.quantization else ''}"
+                        f"{' + code predictor' if a.code_predictor else ''}, bs={a.batch} ctx={a.ctx} (not the headline shape)"),
         "value": round(tokens_per_s, 1),
         "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

@@ -43,7 +43,10 @@ def talker_step(cfg, weights: dict, inputs_embeds: torch.Tensor, positions: torc
     Returns (hidden [T, H] after the final norm, as fp32 values on the ``round_to`` grid).
     """
     rt = round_to
-    h = _lin(inputs_embeds.to(F32), weights["thinker_to_talker_proj.weight"], weights["thinker_to_talker_proj.bias"], rt)
+    if "thinker_to_talker_proj.weight" in weights:   # Qwen2.5-Omni; the Qwen3-Omni talker has no input projection
+        h = _lin(inputs_embeds.to(F32), weights["thinker_to_talker_proj.weight"], weights["thinker_to_talker_proj.bias"], rt)
+    else:
+        h = inputs_embeds.to(F32)
     return decoder_stack(cfg, weights, h, positions, kv_caches, block_table, seq_lens, query_start_loc, slot_map,
                          cos_sin_cache, round_to, num_layers, quant)
 
@@ -126,13 +129,14 @@ def random_weights(cfg, seed: int = 0, dtype=torch.bfloat16, num_layers: Optiona
         return (torch.randn(*shape, generator=g) * std + mean).to(dtype)
 
     d, nq, nkv, h, i = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.hidden_size, cfg.intermediate_size
-    out = {
-        "thinker_to_talker_proj.weight": w(h, cfg.embedding_size),
-        "thinker_to_talker_proj.bias": w(h),
+    out = {}
+    if getattr(cfg, "input_projection", True):
+        out = {"thinker_to_talker_proj.weight": w(h, cfg.embedding_size), "thinker_to_talker_proj.bias": w(h)}
+    out.update({
         "language_model.lm_head.weight": w(cfg.vocab_size, h),
         "language_model.model.embed_tokens.weight": w(cfg.vocab_size, cfg.embedding_size),
         "language_model.model.norm.weight": w(h, std=0.01, mean=1.0),
-    }
+    })
     for li in range(nl):
         p = f"language_model.model.layers.{li}."
         out[p + "self_attn.qkv_proj.weight"] = w((nq + 2 * nkv) * d, h)

@@ -466,3 +466,95 @@ def test_moe_talker_decode_steps_match_oracle(dev):
             for r, t in zip(reqs, got_ids.tolist()):
                 r.num_computed_tokens += 1
                 r.output_token_ids.append(t)
+
+
+@pytest.mark.parametrize("enforce_eager", [True, False])
+def test_qwen3_talker_step_with_code_predictor(dev, enforce_eager):
+    """`talker_mtp` through the runner (qwen3_omni.py:681-705): every decode step runs the code predictor on (last
+    codec token, its embedding, last talker hidden state); the talker's input is the sum of the G codebook
+    embeddings + the text step.  Oracle: ref_code_predictor (teacher-forced with the device's codes) -> sum -> talker
+    stack with the MoE MLP.  Codes are handed back per request."""
+    from oracle import ref_code_predictor as rcp
+    from vllm_omni_amd.code_predictor import CodePredictorConfig
+    from vllm_omni_amd.kv_cache import KVCacheManager, normalize_layer_kv
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, Request, SamplingParams, SchedulerOutput
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_qwen3_talker")
+    cpc = CodePredictorConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                              head_dim=128, intermediate_size=256, vocab_size=256, num_code_groups=4)
+    bs, nb, B = 16, 48, 3
+    runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=4, max_model_len=128, max_num_batched_tokens=64,
+                              block_size=bs, enforce_eager=enforce_eager, max_reply_rows=32, seed=0, code_predictor=cpc)
+    runner.load_model()
+    w = ref_talker.random_weights(cfg, seed=3)
+    assert runner.model.load_weights({k: v.to(dev) for k, v in w.items()}) == set(w.keys())
+    wcp = rcp.random_weights(cpc, seed=4)
+    assert runner.code_predictor.load_weights({k: v.to(dev) for k, v in wcp.items()}) == set(wcp.keys())
+    runner.initialize_kv_cache(nb)
+    g = torch.Generator().manual_seed(5)
+    cpu_caches = []
+    for kv in runner.kv_caches:
+        init = torch.randn(nb, 2, bs, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
+        kb, vb = normalize_layer_kv(kv)
+        kb.copy_(init[:, 0].to(dev))
+        vb.copy_(init[:, 1].to(dev))
+        cpu_caches.append((init[:, 0].clone(), init[:, 1].clone()))
+    mgr = KVCacheManager(nb, bs)
+    reqs = []
+    for i, c in enumerate([7, 20, 1]):
+        r = Request(f"r{i}", list(range(c + 1)), SamplingParams(temperature=0.0, seed=100 + i))
+        r.additional_information = {"thinker_reply_part": torch.randn(4, cfg.embedding_size, generator=g).to(torch.bfloat16)}
+        assert mgr.allocate_slots(r, c + 1) is not None
+        r.num_computed_tokens = c
+        reqs.append(r)
+    csc = ref_ops.build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
+    last_ids = torch.tensor([r.prompt_token_ids[-1] for r in reqs], dtype=torch.int64)
+    last_hidden = torch.zeros(B, cfg.hidden_size)
+    table = torch.zeros(B, 8, dtype=torch.int32)
+    for step in range(3):
+        sched = {r.request_id: 1 for r in reqs}
+        if step == 0:
+            so = SchedulerOutput(scheduled_new_reqs=[
+                NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id),
+                               r.num_computed_tokens, additional_information=r.additional_information) for r in reqs],
+                num_scheduled_tokens=sched, total_num_scheduled_tokens=B)
+        else:
+            new_blocks = []
+            for r in reqs:
+                nb_ = mgr.allocate_slots(r, 1)
+                new_blocks.append(nb_.get_block_ids() if nb_.blocks[0] else None)
+            so = SchedulerOutput(scheduled_cached_reqs=CachedRequestData(
+                req_ids=[r.request_id for r in reqs], new_block_ids=new_blocks,
+                num_computed_tokens=[r.num_computed_tokens for r in reqs], num_output_tokens=[step] * B),
+                num_scheduled_tokens=sched, total_num_scheduled_tokens=B)
+        for i, r in enumerate(reqs):
+            ids = mgr.get_block_ids(r.request_id)[0]
+            table[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+        runner.execute_model(so)
+        out = runner.sample_tokens()
+        order = [out.req_id_to_index[r.request_id] for r in reqs]
+        codes = torch.stack([out.pooler_output[j]["code_predictor_codes"] for j in order])
+        assert codes.shape == (B, cpc.num_code_groups) and torch.equal(codes[:, 0], last_ids)
+        assert int(codes[:, 1:].min()) >= 0 and int(codes[:, 1:].max()) < cpc.vocab_size
+        # ---- oracle
+        emb0 = w["language_model.model.embed_tokens.weight"].float()[last_ids]
+        _, buf, _ = rcp.forward(cpc, wcp, last_ids.view(B, 1), emb0.view(B, 1, -1), last_hidden, rt=torch.bfloat16,
+                                forced_codes=codes)
+        step_vec = torch.stack([r.additional_information["thinker_reply_part"][step] for r in reqs]).float()
+        x = (buf[:, 1:].sum(1) + step_vec).to(torch.bfloat16).float()
+        pos = torch.tensor([r.num_computed_tokens for r in reqs], dtype=torch.int64)
+        slots = ref_ops.slot_mapping(table, torch.arange(B), pos, bs)
+        hidden = ref_talker.talker_step(cfg, w, x, pos, cpu_caches, table, (pos + 1).to(torch.int32),
+                                        torch.arange(B + 1, dtype=torch.int32), slots, csc, torch.bfloat16)
+        got = torch.stack([out.pooler_output[j]["hidden"][0] for j in order]).float()
+        row_err = (got - hidden).abs().amax(-1)
+        assert (row_err > 0.15).sum() <= 1, row_err          # one row may move on an expert near-tie
+        ok = row_err <= 0.15
+        torch.testing.assert_close(got[ok], hidden[ok], rtol=4e-2, atol=4e-2)
+        got_ids = torch.tensor([out.sampled_token_ids[j][0] for j in order])
+        last_ids, last_hidden = got_ids.clone(), got.clone()     # feed the device's state to both sides
+        for r, t in zip(reqs, got_ids.tolist()):
+            r.num_computed_tokens += 1
+            r.output_token_ids.append(t)

@@ -26,6 +26,7 @@ from typing import Any, Optional
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import ops
 from .block_table import MultiGroupBlockTable
@@ -48,6 +49,7 @@ class CachedRequestState:
     additional_information: Optional[dict] = None
     sample_seed: int = 0                                  # Philox key of the request's draws
     seen_slot: int = -1                                   # row of the device seen-token bitmap, -1 = none
+    state_slot: int = -1                                  # row of the device per-request state (last talker hidden)
 
     @property
     def num_tokens(self) -> int:
@@ -231,7 +233,7 @@ class GPUARModelRunner:
                  max_num_reqs: int = 256, max_model_len: int = 4096, max_num_batched_tokens: int = 8192,
                  block_size: int = 16, kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: bool = False,
                  engine_output_type: str = "latent", max_reply_rows: int = 0, seed: Optional[int] = 0,
-                 quantization: Optional[str] = None):
+                 quantization: Optional[str] = None, code_predictor=None):
         from .distributed import get_parallel_state
 
         self.config = config
@@ -248,6 +250,11 @@ class GPUARModelRunner:
         if quantization not in (None, "int8"):
             raise ValueError(f"unsupported quantization {quantization!r} (None or 'int8')")
         self.quantization = quantization
+        # Qwen3-Omni: a CodePredictorConfig turns every decode step into `talker_mtp`
+        # (vllm_omni/model_executor/models/qwen3_omni/qwen3_omni.py:681-705): the code predictor expands the last
+        # codec token into all residual codebooks, the talker's input is the SUM of their embeddings + the text step
+        self.code_predictor_config = code_predictor
+        self.code_predictor = None
         self.parallel = get_parallel_state()
         self.model: Optional[Qwen2_5OmniTalkerForConditionalGeneration] = None
         self.kv_caches: list = []
@@ -311,6 +318,27 @@ class GPUARModelRunner:
         self.model = Qwen2_5OmniTalkerForConditionalGeneration(self.config, self.dtype, self.device, self.seed)
         if self.quantization == "int8":   # online W8A8 of the decoder linears (int8_config.py:391-418)
             self.model.quantize_int8()
+        if self.code_predictor_config is not None:
+            from .block_table import CpuGpuBuffer
+            from .code_predictor import MI355XCodePredictor
+
+            cpc = self.code_predictor_config
+            if self.config.input_projection or self.config.embedding_size != cpc.hidden_size:
+                raise ValueError("the code predictor feeds the talker's hidden space: needs input_projection=False and "
+                                 "embedding_size == code predictor hidden_size")
+            self.code_predictor = MI355XCodePredictor(cpc, self.dtype, self.device, max_batch=self.max_num_reqs,
+                                                      seed=(self.seed or 0) + 17)
+            n = self.max_num_reqs
+            self._state_free = list(range(n - 1, -1, -1))
+            self._last_hidden = torch.zeros(n, self.config.hidden_size, dtype=self.dtype, device=self.device)
+            self._state_rows = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
+            self._cp_seed = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
+            self._cp_offset = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
+            self._cp_codes = torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, device=self.device)
+            k = self.OUT_SLOTS
+            on_gpu = torch.device(self.device).type == "cuda"
+            self._out_codes_cpu = [torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, pin_memory=on_gpu) for _ in range(k)]
+            self._out_codes_stage = [torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, device=self.device) for _ in range(k)]
         if torch.device(self.device).type == "cuda" and self.config.vocab_size <= 16368:
             self.sampling_state = SamplingState(self.max_num_reqs, self.config.vocab_size, self.device, self.seed or 0)
         if self.max_reply_rows:
@@ -352,6 +380,9 @@ class GPUARModelRunner:
             st = self.requests.pop(rid, None)
             if self.sampling_state is not None:
                 self.sampling_state.remove(st)
+            if self.code_predictor is not None and st is not None and st.state_slot >= 0:
+                self._state_free.append(st.state_slot)
+                st.state_slot = -1
             ib.remove_request(rid)
         if so.new_block_ids_to_zero:
             self._zero_block_ids(so.new_block_ids_to_zero)
@@ -369,6 +400,9 @@ class GPUARModelRunner:
             self.requests[nr.req_id] = st
             if self.sampling_state is not None:
                 self.sampling_state.add(st)
+            if self.code_predictor is not None:
+                st.state_slot = self._state_free.pop()
+                self._last_hidden[st.state_slot].zero_()
             to_add.append(st)
 
         for i, rid in enumerate(cached.req_ids):
@@ -492,6 +526,7 @@ class GPUARModelRunner:
                 self.last_token_ids.np[:nd] = ib.last_token_ids_cpu[:nd]
                 self.last_token_ids.copy_to_gpu(nd)
             self.reply_idx.copy_to_gpu(nd)
+            self._commit_predictor_inputs(n)
             self._decode_embeds(nd)
         # prefill rows: per-request prompt embeddings (thinker hidden states) or token embeddings
         t0 = num_decodes
@@ -506,7 +541,37 @@ class GPUARModelRunner:
                 self.inputs_embeds[t0:t0 + k] = self.model.embed_input_ids(ids.to(self.device))
             t0 += k
 
+    def _commit_predictor_inputs(self, n: int) -> None:
+        """Per-request state rows, Philox keys and draw bases of the code predictor for this step's batch rows."""
+        if self.code_predictor is None:
+            return
+        pending = 1 if (self._last_output is not None and not self._last_output.done) else 0
+        for i, rid in enumerate(self.input_batch.req_ids[:n]):
+            st = self.requests[rid]
+            self._state_rows.np[i] = st.state_slot
+            self._cp_seed.np[i] = st.sample_seed
+            self._cp_offset.np[i] = len(st.output_token_ids) + pending
+        self._state_rows.copy_to_gpu(n)
+        self._cp_seed.copy_to_gpu(n)
+        self._cp_offset.copy_to_gpu(n)
+
     def _decode_embeds(self, nd: int) -> None:
+        if self.code_predictor is not None:
+            # talker_mtp (qwen3_omni.py:681-705): codes = code_predictor(last codec token, its embedding, last talker
+            # hidden state); input = sum over the G codebook embeddings + the text step of the thinker's reply
+            ids = self.last_token_ids.gpu[:nd]
+            emb0 = F.embedding(ids.clamp(0, self.config.vocab_size - 1), self.model.language_model.model.embed_tokens)
+            last_h = self._last_hidden.index_select(0, self._state_rows.gpu[:nd])
+            codes, buf = self.code_predictor._run(nd, ids, emb0, last_h, self._cp_seed.gpu[:nd], self._cp_offset.gpu[:nd],
+                                                  True, False)
+            summed = buf[:, 1:].float().sum(dim=1)
+            if self._reply_pool is not None:
+                ridx = self.reply_idx.gpu[:nd]
+                step = self._reply_pool.index_select(0, ridx.clamp(min=0)).float() * (ridx >= 0).unsqueeze(-1)
+                summed = summed + step
+            self.inputs_embeds[:nd] = summed.to(self.dtype)
+            self._cp_codes[:nd] = codes[:, :, 0]
+            return
         ops.talker_decode_embeds(self.inputs_embeds[:nd], self.model.language_model.model.embed_tokens,
                                  self.last_token_ids.gpu[:nd], self._reply_pool,
                                  self.reply_idx.gpu[:nd] if self._reply_pool is not None else None)
@@ -518,6 +583,8 @@ class GPUARModelRunner:
             hidden = self.model(input_ids=None, positions=self.positions.gpu[:total],
                                 inputs_embeds=self.inputs_embeds[:total])
         sample_h = hidden if total == n else hidden.index_select(0, self.logits_indices.gpu[:n])
+        if self.code_predictor is not None:   # `last_talker_hidden` of the next step (talker_postprocess, qwen3_omni.py:634-640)
+            self._last_hidden.index_copy_(0, self._state_rows.gpu[:n], sample_h)
         logits, ids = self.model.compute_logits_and_greedy(sample_h, self.sampled_ids_gpu[:n])
         return hidden, logits, ids
 
@@ -638,6 +705,7 @@ class GPUARModelRunner:
             self.last_token_ids.np[:n] = ib.last_token_ids_cpu[:n]
             self.last_token_ids.copy_to_gpu(n)
         self.reply_idx.copy_to_gpu(n)
+        self._commit_predictor_inputs(n)
 
     @torch.inference_mode()
     def sample_tokens(self, grammar_output=None, async_output: bool = False):
@@ -677,11 +745,15 @@ class GPUARModelRunner:
                 self._ids_on_device_for = None
             cur.wait_event(self._out_done[slot])      # the staging slot's previous copy (two steps ago) has drained
             self._out_ids_stage[slot][:n].copy_(ids[:n])
+            if self.code_predictor is not None:
+                self._out_codes_stage[slot][:n].copy_(self._cp_codes[:n])
             if want_hidden:
                 self._out_hidden_stage[slot][:st.num_tokens].copy_(st.hidden_states[:st.num_tokens])
             self.copy_stream.wait_stream(cur)
             with torch.cuda.stream(self.copy_stream):
                 self._out_ids_cpu[slot][:n].copy_(self._out_ids_stage[slot][:n], non_blocking=True)
+                if self.code_predictor is not None:
+                    self._out_codes_cpu[slot][:n].copy_(self._out_codes_stage[slot][:n], non_blocking=True)
                 if want_hidden:
                     self._out_hidden_cpu[slot][:st.num_tokens].copy_(self._out_hidden_stage[slot][:st.num_tokens],
                                                                      non_blocking=True)
@@ -721,6 +793,11 @@ class GPUARModelRunner:
             pooler = [{"hidden": c} for c in torch.split(hidden, np.diff(q).tolist())]
         else:
             pooler = [None] * n
+        if self.code_predictor is not None and st.num_tokens == n:
+            # the codes that produced THIS step's talker input (multimodal output `code_predictor_codes`,
+            # qwen3_omni.py:480-494), one row of G codes per decode request
+            codes = self._out_codes_cpu[slot][:n]
+            pooler = [dict(p_ or {}, code_predictor_codes=codes[i]) for i, p_ in enumerate(pooler)]
         if self._out_inflight[slot] is out:
             self._out_inflight[slot] = None
         return OmniModelRunnerOutput(out.req_ids, out.req_index, sampled, pooler,

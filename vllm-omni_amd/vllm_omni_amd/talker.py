@@ -57,6 +57,10 @@ class TalkerConfig:
     moe_intermediate_size: int = 0
     norm_topk_prob: bool = False
     shared_expert_intermediate_size: int = 0
+    # Qwen2.5-Omni: a Linear embedding_size -> hidden_size in front of the decoder (thinker_to_talker_proj,
+    # qwen2_5_omni_talker.py:72-75).  Qwen3-Omni: inputs arrive in the talker's hidden space and go straight into the
+    # decoder (qwen3_omni_moe_talker.py:286-300), embedding_size == hidden_size
+    input_projection: bool = True
 
     @classmethod
     def from_json(cls, path_or_name: str) -> "TalkerConfig":
@@ -256,7 +260,8 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
         assert input_ids is not None or inputs_embeds is not None, "input_ids or inputs_embeds must be provided"
         if inputs_embeds is None:
             inputs_embeds = self.embed_input_ids(input_ids)  # profile run
-        inputs_embeds = F.linear(inputs_embeds, self.thinker_to_talker_proj_weight, self.thinker_to_talker_proj_bias)
+        if self.config.input_projection:
+            inputs_embeds = F.linear(inputs_embeds, self.thinker_to_talker_proj_weight, self.thinker_to_talker_proj_bias)
         return self.language_model.model(None, positions, intermediate_tensors, inputs_embeds=inputs_embeds)
 
     __call__ = forward
@@ -289,8 +294,9 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
 
     # ---- weights ------------------------------------------------------------------
     def named_weights(self) -> Iterable[tuple[str, torch.Tensor]]:
-        yield "thinker_to_talker_proj.weight", self.thinker_to_talker_proj_weight
-        yield "thinker_to_talker_proj.bias", self.thinker_to_talker_proj_bias
+        if self.config.input_projection:
+            yield "thinker_to_talker_proj.weight", self.thinker_to_talker_proj_weight
+            yield "thinker_to_talker_proj.bias", self.thinker_to_talker_proj_bias
         lm = self.language_model
         yield "language_model.lm_head.weight", lm.lm_head
         yield "language_model.model.embed_tokens.weight", lm.model.embed_tokens
