@@ -317,6 +317,23 @@ int mi_int8_dequant(void* out, const int32_t* acc, const float* x_scale, const f
                     const void* bias, int32_t m, int32_t n, int64_t acc_row_stride,
                     int64_t out_row_stride, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Decode-batch linear layer: out[m, n] = x[m, k] . weight[n, k]^T (+ bias[n]),
+ * m <= 256 — the projections of one decode step (qkv_proj / o_proj /
+ * gate_up_proj / down_proj of vllm_omni/model_executor/models/qwen2_5_omni/
+ * qwen2_5_omni_talker.py, which the reference runs as library GEMMs through
+ * vLLM's ColumnParallelLinear / RowParallelLinear).  Weight-streaming kernel:
+ * weights HBM -> registers once, x through LDS, split-K with fp32 partials in
+ * `workspace` where n alone does not fill the chip (deterministic reduce, no
+ * atomics).  k % 128 == 0, n % 16 == 0, rows 16-byte aligned.
+ * mi_linear_workspace_bytes: bytes mi_linear needs for this shape (0 = none).
+ * Returns MI_ERR_UNSUPPORTED for shapes outside the envelope (callers fall to
+ * the library GEMM), MI_ERR_WORKSPACE if the workspace is too small. */
+int64_t mi_linear_workspace_bytes(int32_t m, int32_t n, int32_t k);
+int mi_linear(void* out, const void* x, const void* weight, const void* bias, int32_t m, int32_t n,
+              int32_t k, int64_t x_row_stride, int64_t out_row_stride, void* workspace,
+              int64_t workspace_bytes, int dtype, void* stream);
+
 
 /* ------------------------------------------------------------------------
  * A1 — KV block pool (host side, no GPU).  The allocator underneath the

@@ -1,0 +1,83 @@
+"""Decode-batch linear kernel (csrc/skinny_gemm.hip) against an fp32 reference of the same op.
+
+The op is floating point: the tolerance is the bf16/f16 output grid plus fp32 summation-order noise — the kernel
+accumulates in fp32 in a different order than a library GEMM (k permuted inside 64-wide blocks, split-K partials),
+so results are compared to a float64-accumulated reference rounded to the output type, within 1 output ulp + 1e-3 of
+the row's magnitude.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # (m, n, k, bias)  — the four projections of the headline talker, then edge shapes
+    (256, 4608, 3584, True),     # qkv_proj (bias)
+    (256, 3584, 3584, False),    # o_proj
+    (256, 37888, 3584, False),   # gate_up_proj: 160-row tiles, last tile hangs over n
+    (256, 3584, 18944, False),   # down_proj: split-K
+    (1, 3584, 3584, True),
+    (17, 1024, 1024, False),     # ragged m
+    (64, 2048, 256, True),       # two k blocks
+    (100, 48, 128, False),       # one k block, n smaller than a tile
+    (128, 6144, 2048, True),
+    (255, 160, 384, True),
+]
+
+
+def _ref(x, w, b):
+    y = x.double() @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    return y
+
+
+@pytest.mark.parametrize("m,n,k,bias", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_matches_reference(m, n, k, bias, dtype):
+    from vllm_omni_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1234 + m + n + k)
+    x = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(dtype)
+    b = torch.randn(n, device="cuda", generator=g).to(dtype) if bias else None
+    assert ops.linear_supported(m, n, k, dtype)
+    y = ops.linear(x, w, b)
+    assert y.shape == (m, n) and y.dtype == dtype
+    ref = _ref(x, w, b)
+    err = (y.double() - ref).abs()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    tol = ref.abs() * ulp + 1e-3 * ref.abs().amax(dim=1, keepdim=True).clamp_min(1.0)
+    assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol {tol.min().item():.4g}..)"
+
+
+def test_linear_strided_input_and_3d():
+    from vllm_omni_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(7)
+    big = torch.randn(4, 32, 1024, device="cuda", generator=g).to(torch.bfloat16)
+    x = big[:, :, :512]            # row stride 1024, 512 columns
+    w = (torch.randn(256, 512, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    y = ops.linear(x, w)
+    assert y.shape == (4, 32, 256)
+    ref = x.double() @ w.double().t()
+    assert (y.double() - ref).abs().max().item() < 0.05
+
+
+def test_linear_deterministic():
+    from vllm_omni_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(256, 18944, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(3584, 18944, device="cuda", generator=g) * 0.01).to(torch.bfloat16)
+    a = ops.linear(x, w)
+    b = ops.linear(x, w)
+    assert torch.equal(a, b)     # split-K goes through a workspace and an ordered reduce: no atomics
+
+
+def test_linear_rejects_unsupported():
+    from vllm_omni_amd import ops
+    x = torch.zeros(300, 256, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(64, 256, device="cuda", dtype=torch.bfloat16)
+    assert not ops.linear_supported(300, 64, 256, torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 256), torch.zeros(64, 256))    # CPU tensors: no fallback

@@ -1,0 +1,53 @@
+"""Decode-batch linear kernel against the library GEMM (torch F.linear, TunableOp-selected hipBLASLt/rocBLAS) on the
+headline talker's four projections.  Prints us per call and the weight-streaming rate."""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vllm-omni_amd"))
+from vllm_omni_amd import ops  # noqa: E402
+
+
+def timed(fn, iters=50, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / iters * 1e3
+
+
+def main():
+    m = int(os.environ.get("M", 256))
+    shapes = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gate_up", 37888, 3584), ("down", 3584, 18944)]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    # rotate over several weight copies so that no weight is served from the 256 MB Infinity Cache
+    for name, n, k in shapes:
+        copies = max(2, int(600e6 // (n * k * 2)))
+        ws = [(torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16) for _ in range(copies)]
+        x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+        i = [0]
+
+        def lib():
+            i[0] = (i[0] + 1) % copies
+            return F.linear(x, ws[i[0]])
+
+        def mine():
+            i[0] = (i[0] + 1) % copies
+            return ops.linear(x, ws[i[0]])
+
+        err = (ops.linear(x, ws[0]).float() - F.linear(x, ws[0]).float()).abs().max().item()
+        t_lib, t_mine = timed(lib), timed(mine)
+        gb = n * k * 2 / 1e9
+        print(f"{name:8s} m={m} n={n} k={k}: library {t_lib:7.1f} us ({gb / t_lib * 1e3:5.2f} TB/s)   "
+              f"skinny {t_mine:7.1f} us ({gb / t_mine * 1e3:5.2f} TB/s)   max|diff| {err:.3g}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,360 @@
+// Decode-batch linear layer: y[M, N] = x[M, K] . W[N, K]^T (+ bias), M <= 256 rows (one decode step's batch).
+//
+// The reference runs these projections (qkv_proj, o_proj, gate_up_proj, down_proj of every decoder layer:
+// vllm_omni/model_executor/models/qwen2_5_omni/qwen2_5_omni_talker.py through vLLM's ColumnParallelLinear /
+// RowParallelLinear) as library GEMMs.  At M = 256 the job is weight streaming: 256 flop per weight byte is
+// under the ~310 flop/B ridge of the chip, so the bound is HBM (the weights, read once) plus the L2 traffic of
+// re-reading x for every weight tile.  The library's tiles are sized for big GEMMs and reach 1.8-3.4 TB/s on
+// these shapes; this kernel is laid out for the streaming case instead:
+//   * swapped form D = W . x^T: a wave owns 16*RG weight rows and ALL the (<= 256) activation rows, so every
+//     weight element is needed by exactly one wave and goes HBM -> VGPR directly as an MFMA A operand (16-byte
+//     loads, two k-blocks ahead) — the weights never touch LDS;
+//   * x is the shared operand: one [16*MT rows][64 k] block per step, staged global -> VGPR -> LDS one block
+//     ahead in a two-stage ring, read back as conflict-free `ds_read_b128` B operands (128-byte rows, 16-byte
+//     chunk XORed with the row-pair index; the k order inside a 64-wide block is permuted the same way for W
+//     and x, chosen so that a lane's two W loads are adjacent and the two k-groups of a `ds_read_b128` lane
+//     group differ by 6 in chunk index — see MI355X_MICROARCH.md "LDS");
+//   * split-K where N alone does not fill the chip (down_proj: 28 tiles x 8 slices = 224 workgroups): fp32
+//     partials to a workspace and a small reduce kernel (+ bias, convert) — deterministic, no atomics.
+#include "mfma_attn_common.h"
+
+namespace mi {
+namespace {
+
+struct SkinnyParams {
+  const uint16_t* x;
+  const uint16_t* w;
+  const uint16_t* bias;   // may be null
+  uint16_t* out;          // S == 1
+  float* part;            // S > 1: [S][M][N]
+  int32_t M, N, K, S;
+  int64_t ldx, ldo;
+};
+
+// operands as plain vectors (a HIP `uint4` is a struct: its copies between address spaces become memcpys that keep
+// the staging array in scratch)
+template <typename Tag>
+__device__ __forceinline__ f32x4_t mma(u32x4_t a, u32x4_t b, f32x4_t c) {
+  if constexpr (std::is_same_v<Tag, bf16_tag>)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int kperm(int u, int kg) {
+  // logical 16-byte chunk (8 elements) of a 64-wide k block held by k-group kg at k-step u
+  const int sig = (0x2130 >> (4 * kg)) & 3;   // sigma = {0, 3, 1, 2}
+  return 2 * sig + u;
+}
+
+// 8 fragment reads (4 m-tiles x 2 k-steps) and their wait in ONE statement (see mfma_attn_common.h: LDS reads are
+// inline asm so that hipcc does not drain the outstanding LDS-DMA in front of them)
+template <int OFF>
+__device__ __forceinline__ void lds_read_x8(uint32_t a0, uint32_t a1, u32x4_t (&b0)[4], u32x4_t (&b1)[4]) {
+  asm volatile(
+      "ds_read_b128 %0, %8 offset:%10\n\t"
+      "ds_read_b128 %4, %9 offset:%10\n\t"
+      "ds_read_b128 %1, %8 offset:%11\n\t"
+      "ds_read_b128 %5, %9 offset:%11\n\t"
+      "ds_read_b128 %2, %8 offset:%12\n\t"
+      "ds_read_b128 %6, %9 offset:%12\n\t"
+      "ds_read_b128 %3, %8 offset:%13\n\t"
+      "ds_read_b128 %7, %9 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3]), "=&v"(b1[0]), "=&v"(b1[1]), "=&v"(b1[2]), "=&v"(b1[3])
+      : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 2048), "i"(OFF + 4096), "i"(OFF + 6144)
+      : "memory");
+}
+// the wave's own weight fragments: RG row groups x 2 k-steps
+template <int OFF>
+__device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w)[1][2]) {
+  asm volatile(
+      "ds_read_b128 %0, %2 offset:%4\n\t"
+      "ds_read_b128 %1, %3 offset:%4\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(w[0][0]), "=&v"(w[0][1])
+      : "v"(a0), "v"(a1), "i"(OFF)
+      : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w)[2][2]) {
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%6\n\t"
+      "ds_read_b128 %1, %5 offset:%6\n\t"
+      "ds_read_b128 %2, %4 offset:%7\n\t"
+      "ds_read_b128 %3, %5 offset:%7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(w[0][0]), "=&v"(w[0][1]), "=&v"(w[1][0]), "=&v"(w[1][1])
+      : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 2048)
+      : "memory");
+}
+
+// NSLAB: 32-row weight slabs per tile (tile = 32 NSLAB rows); MT: 16-row m-tiles (x rows padded to 16 MT);
+// MH: consumer waves per slab, each with MT / MH m-tiles; NL: loader waves.
+template <typename Tag, int NSLAB, int MT, int MH, int NL>
+__global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(const SkinnyParams p) {
+  // One pipeline step = one 64-wide k block.  A stage of the LDS ring is one image of 128-byte rows: the 16 MT rows of
+  // x, then the tile's 32 NSLAB weight rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7).  The image is
+  // filled by LDS-DMA in 1 KiB pieces (8 rows per wave-instruction, the swizzle applied on the source side).
+  // Roles: NL loader waves only issue DMA; NSLAB * MH consumer waves only read fragments and run MFMAs — the DMA issue
+  // cost (60-180 cycles per piece) then overlaps the other waves' MFMAs instead of sitting in front of them.  One raw
+  // s_barrier per step: a loader arrives once its pieces of step `it` have landed, a consumer once it is done reading
+  // step it - 1; past it the loaders refill that stage with step it + 2.  Three stages, two steps always in flight.
+  constexpr int TR = 32 * NSLAB;
+  constexpr int NC = NSLAB * MH;
+  constexpr int MTW = MT / MH;
+  constexpr int kXBytes = MT * 2048;
+  constexpr int kStage = kXBytes + TR * 128;
+  constexpr int NST = 3;
+  constexpr int XI = MT * 2, PIECES = XI + TR / 8;
+  constexpr int PPL = PIECES / NL;
+  static_assert(PIECES % NL == 0 && PPL <= 63, "equal shares; one step of pieces must fit vmcnt");
+  static_assert(MTW % 4 == 0 && NST * kStage <= 160 * 1024, "m-tiles are read in fours; the ring must fit the LDS");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using E = Elem<Tag>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so slice = id % S puts every k slice of x on the
+  // XCDs congruent to it (S = 8: one slice per XCD) — its rows are then re-read from ONE L2 by all the tiles
+  const int wg = blockIdx.x;
+  const int s = wg % p.S, tile = wg / p.S;
+  const int nb = p.K >> 6;
+  const int b_lo = (int)((int64_t)s * nb / p.S), b_hi = (int)((int64_t)(s + 1) * nb / p.S);
+  const int n_it = b_hi - b_lo;
+
+  if (wid >= NC) {
+    // ------------------------------------------------------------------ loader
+    const int l = wid - NC;
+    const int drow = lane >> 3, dpc = lane & 7;
+    const char* src[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+      const int q = l + NL * i;                    // piece: image rows 8 q .. 8 q + 7
+      const int row = 8 * q + drow;
+      const int lc = dpc ^ ((row >> 1) & 7);
+      if (q < XI) {
+        const int m = row < p.M ? row : p.M - 1;   // rows past M repeat the last one; never stored
+        src[i] = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + 64 * (int64_t)b_lo + 8 * lc);
+      } else {
+        int n = tile * TR + (row - 16 * MT);
+        n = n < p.N ? n : p.N - 1;                 // a tile may hang over N: those row groups are never stored
+        src[i] = reinterpret_cast<const char*>(p.w + (int64_t)n * p.K + 64 * (int64_t)b_lo + 8 * lc);
+      }
+    }
+    auto issue = [&](int it, int stage) {
+      char* st = smem + stage * kStage;
+#pragma unroll
+      for (int i = 0; i < PPL; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it), (lds_void*)(st + (l + NL * i) * 1024), 16,
+                                         0, 0);
+    };
+    if (n_it > 0) issue(0, 0);
+    if (n_it > 1) issue(1, 1);
+    int stage = 2;   // stage of step it + 2
+    for (int it = 0; it < n_it; ++it) {
+      if (it + 1 < n_it) wait_vmcnt<PPL>();   // step `it` landed; step it + 1 may still be in flight
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (it + 2 < n_it) issue(it + 2, stage);
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int slab = wid % NSLAB, mh = wid / NSLAB;
+  const int n_base = tile * TR + 32 * slab;
+  // fragment reads: image row 16 j + r16 -> (row >> 1) & 7 == r16 >> 1
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+  uint32_t frag[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) frag[u] = lds0 + r16 * 128 + ((kperm(u, kg) ^ (r16 >> 1)) << 4);
+  const uint32_t x_off = mh * (MTW * 2048), w_off = kXBytes + slab * 4096;
+
+  f32x4_t acc[2][MTW];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) acc[g][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int stage = 0;
+  for (int it = 0; it < n_it; ++it) {
+    __builtin_amdgcn_s_barrier();
+    const uint32_t a0 = frag[0] + stage * kStage, a1 = frag[1] + stage * kStage;
+    u32x4_t a[2][2];
+    lds_read_w<0>(a0 + w_off, a1 + w_off, a);
+#pragma unroll
+    for (int jg = 0; jg < MTW / 4; ++jg) {
+      u32x4_t b[2][4];
+      if (jg == 0) lds_read_x8<0 * 8192>(a0 + x_off, a1 + x_off, b[0], b[1]);
+      else if (jg == 1) lds_read_x8<1 * 8192>(a0 + x_off, a1 + x_off, b[0], b[1]);
+      else if (jg == 2) lds_read_x8<2 * 8192>(a0 + x_off, a1 + x_off, b[0], b[1]);
+      else lds_read_x8<3 * 8192>(a0 + x_off, a1 + x_off, b[0], b[1]);
+      // eight independent accumulators between two uses of the same one
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) acc[g][4 * jg + i] = mma<Tag>(a[g][u], b[u][i], acc[g][4 * jg + i]);
+    }
+    stage = stage == NST - 1 ? 0 : stage + 1;
+  }
+
+  // D[n][m]: lane = column m (row r16 of m-tile j), rows n = 4 kg + r of the row group
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int n = n_base + 16 * g + 4 * kg;
+    if (n >= p.N) continue;   // N % 16 == 0: a row group is all in or all out
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.S == 1 && p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = E::from_bits(p.bias[n + r]);
+    }
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+      const int m = 16 * (mh * MTW + j) + r16;
+      if (m >= p.M) continue;
+      if (p.S == 1) {
+        uint2 q;
+        q.x = E::pack(acc[g][j][0] + bv[0], acc[g][j][1] + bv[1]);
+        q.y = E::pack(acc[g][j][2] + bv[2], acc[g][j][3] + bv[3]);
+        *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = q;
+      } else {
+        *reinterpret_cast<f32x4_t*>(p.part + ((int64_t)s * p.M + m) * p.N + n) = acc[g][j];
+      }
+    }
+  }
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(uint16_t* __restrict__ out, const float* __restrict__ part,
+                                                            const uint16_t* __restrict__ bias, int M, int N, int S,
+                                                            int64_t ldo) {
+  using E = Elem<Tag>;
+  const int64_t quads = (int64_t)M * N / 4;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int m = (int)(q / (N / 4)), n = (int)(q - (int64_t)m * (N / 4)) * 4;
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(part + (int64_t)m * N + n);
+  for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4_t*>(part + ((int64_t)s * M + m) * N + n);
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] += E::from_bits(bias[n + r]);
+  }
+  uint2 o;
+  o.x = E::pack(a[0], a[1]);
+  o.y = E::pack(a[2], a[3]);
+  *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o;
+}
+
+struct SkinnyPlan {
+  int nslab, mt, tiles, split;
+};
+
+// Tile shape and split-K factor for one problem.  Goal: one workgroup per CU in ONE round (256 CUs), every CU busy.
+//   * 160-row tiles when that lands the tile count just under 256 (gate_up_proj: 37888 / 160 = 237 tiles), else
+//     128-row tiles with K cut into S slices so that tiles x S <= 256;
+//   * S is capped so the fp32 partials stay a fraction of the weight bytes and every slice keeps >= 4 k-blocks.
+SkinnyPlan skinny_plan(int m, int n, int k, int force_split) {
+  SkinnyPlan pl;
+  pl.mt = m <= 64 ? 4 : m <= 128 ? 8 : 16;
+  const int nb = k / 64;
+  const int t160 = (n + 159) / 160, t128 = (n + 127) / 128;
+  if (t160 > 128 && t160 <= 256 && force_split <= 1) {
+    pl.nslab = 5; pl.tiles = t160; pl.split = 1;
+    return pl;
+  }
+  pl.nslab = 4; pl.tiles = t128;
+  int s = 256 / t128;
+  if (s < 1) s = 1;
+  if (s > nb / 4) s = nb / 4 > 0 ? nb / 4 : 1;
+  if (s > 16) s = 16;
+  if (force_split > 0) s = force_split;
+  pl.split = s;
+  return pl;
+}
+
+}  // namespace
+}  // namespace mi
+
+namespace {
+int forced_split() {   // MI_LINEAR_SPLIT=<S>: tuning override of the split-K factor (tools/bench_skinny_gemm.py)
+  static const int v = [] {
+    const char* e = getenv("MI_LINEAR_SPLIT");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+}  // namespace
+
+extern "C" int64_t mi_linear_workspace_bytes(int32_t m, int32_t n, int32_t k) {
+  using namespace mi;
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  const SkinnyPlan pl = skinny_plan(m, n, k, forced_split());
+  return pl.split > 1 ? (int64_t)pl.split * m * n * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int mi_linear(void* out, const void* x, const void* weight, const void* bias, int32_t m, int32_t n, int32_t k,
+                         int64_t x_row_stride, int64_t out_row_stride, void* workspace, int64_t workspace_bytes,
+                         int dtype, void* stream) {
+  using namespace mi;
+  if (m == 0 || n == 0) return MI_OK;
+  if (!out || !x || !weight || m < 0 || n < 0 || k <= 0) return MI_ERR_INVALID_ARG;
+  if (m > 256 || k % 64 || n % 16 || x_row_stride % 8 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)weight) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
+  const SkinnyPlan pl = skinny_plan(m, n, k, forced_split());
+  if (pl.split > 1 && (!workspace || ((uintptr_t)workspace & 15))) return MI_ERR_INVALID_ARG;
+  if (pl.split > 1 && workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(float)) return MI_ERR_WORKSPACE;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(x);
+  p.w = reinterpret_cast<const uint16_t*>(weight);
+  p.bias = reinterpret_cast<const uint16_t*>(bias);
+  p.out = reinterpret_cast<uint16_t*>(out);
+  p.part = reinterpret_cast<float*>(workspace);
+  p.M = m; p.N = n; p.K = k; p.S = pl.split;
+  p.ldx = x_row_stride;
+  p.ldo = out_row_stride;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(pl.tiles * pl.split);
+#define MI_SKINNY(TAG, NSLAB, MT, MH, NL)                                                                         \
+  do {                                                                                                            \
+    auto kern = skinny_gemm_kernel<TAG, NSLAB, MT, MH, NL>;                                                       \
+    constexpr int lds = 3 * (MT * 2048 + NSLAB * 4096);                                                           \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
+    if (attr != hipSuccess) return MI_ERR_LAUNCH;                                                                 \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * (NSLAB * MH + NL)), lds, s, p);                                      \
+  } while (0)
+#define MI_SKINNY_T(TAG)                                     \
+  do {                                                       \
+    if (pl.nslab == 5) {                                     \
+      if (pl.mt == 16) MI_SKINNY(TAG, 5, 16, 2, 2);          \
+      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, 2, 2);       \
+      else MI_SKINNY(TAG, 5, 4, 1, 2);                       \
+    } else {                                                 \
+      if (pl.mt == 16) MI_SKINNY(TAG, 4, 16, 2, 4);          \
+      else if (pl.mt == 8) MI_SKINNY(TAG, 4, 8, 2, 4);       \
+      else MI_SKINNY(TAG, 4, 4, 1, 4);                       \
+    }                                                        \
+  } while (0)
+  if (dtype == MI_DTYPE_BF16) MI_SKINNY_T(bf16_tag);
+  else if (dtype == MI_DTYPE_F16) MI_SKINNY_T(f16_tag);
+  else return MI_ERR_UNSUPPORTED;
+#undef MI_SKINNY_T
+#undef MI_SKINNY
+  if (launch_status() != MI_OK) return MI_ERR_LAUNCH;
+  if (pl.split > 1) {
+    const int64_t quads = (int64_t)m * n / 4;
+    const dim3 rgrid((unsigned)((quads + 255) / 256));
+    auto o = reinterpret_cast<uint16_t*>(out);
+    auto b = reinterpret_cast<const uint16_t*>(bias);
+    if (dtype == MI_DTYPE_BF16)
+      hipLaunchKernelGGL((skinny_reduce_kernel<bf16_tag>), rgrid, dim3(256), 0, s, o, p.part, b, m, n, pl.split, out_row_stride);
+    else
+      hipLaunchKernelGGL((skinny_reduce_kernel<f16_tag>), rgrid, dim3(256), 0, s, o, p.part, b, m, n, pl.split, out_row_stride);
+  }
+  return launch_status();
+}

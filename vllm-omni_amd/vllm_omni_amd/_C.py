@@ -56,6 +56,8 @@ SIGNATURES = {
     "mi_moe_combine": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,
                                c_int, _P]),
     "mi_int8_dequant": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
+    "mi_linear_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "mi_linear": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, _P, c_int64, c_int, _P]),
     "mi_kv_pack": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                            c_int64, c_int64, c_int64, _P]),
     "mi_sample_tokens": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P]),

@@ -316,6 +316,35 @@ def int8_dequant(acc: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor
     return out
 
 
+_LINEAR_WS: dict = {}
+
+
+def linear_supported(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
+    """Shape envelope of ``mi_linear`` (decode batches): rows <= 256, k a multiple of 128, n of 16."""
+    return 0 < m <= 256 and k % 128 == 0 and n % 16 == 0 and dtype in (torch.bfloat16, torch.float16)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x W^T (+ b) for a decode batch (<= 256 rows) by the weight-streaming kernel of csrc/skinny_gemm.hip;
+    stands in for the library GEMM behind vLLM's ColumnParallelLinear / RowParallelLinear on the decode path."""
+    _gpu(x, weight, bias)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    m, k = x2.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k or not weight.is_contiguous() or weight.dtype != x.dtype:
+        raise ValueError("weight must be a contiguous [n, k] tensor of x's dtype")
+    out = torch.empty(m, n, dtype=x.dtype, device=x.device)
+    need = lib.mi_linear_workspace_bytes(m, n, k)
+    ws = _LINEAR_WS.get(x.device)
+    if need and (ws is None or ws.numel() < need):
+        ws = _LINEAR_WS[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    check("mi_linear", lib.mi_linear(_p(out), _p(x2), _p(weight), _p(bias), m, n, k, x2.stride(0), out.stride(0),
+                                     _p(ws) if need else None, ws.numel() if need else 0, _dt(x.dtype), _stream()))
+    return out.view(*x.shape[:-1], n)
+
+
 # Library int8 GEMM (hipBLASLt behind torch._int_mm) needs M > 16 and K, N multiples of 8; everything else
 # goes through the hand-written MFMA kernel.  VLLM_OMNI_AMD_INT8_GEMM=mfma forces the latter.
 _INT8_FORCE_MFMA = __import__("os").environ.get("VLLM_OMNI_AMD_INT8_GEMM", "") == "mfma"
