@@ -81,3 +81,28 @@ def test_linear_rejects_unsupported():
         ops.linear(x, w)
     with pytest.raises(RuntimeError):
         ops.linear(torch.zeros(4, 256), torch.zeros(64, 256))    # CPU tensors: no fallback
+
+
+def test_row_parallel_linear_routes_deep_projections_to_the_kernel(monkeypatch):
+    """The "auto" policy (layers._streaming_kernel_wins): a decode batch of 129..256 rows through a deep, narrow
+    projection (k >= 8192, k >= 2 n — the headline talker's down_proj) runs the streaming kernel; other shapes and
+    larger batches stay on the library GEMM.  Either way the layer's result matches an fp32 reference."""
+    from vllm_omni_amd import layers, ops
+    calls = []
+    real = ops.linear
+    monkeypatch.setattr(ops, "linear", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(layers, "_LINEAR_MODE", "auto")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    lin = layers.RowParallelLinear(8192, 1024, bias=False, dtype=torch.bfloat16, device="cuda")
+    lin.weight = (torch.randn(1024, 8192, device="cuda", generator=g) * 0.01).to(torch.bfloat16)
+    for m, expect in [(256, 1), (200, 1), (128, 0), (512, 0)]:
+        calls.clear()
+        x = torch.randn(m, 8192, device="cuda", generator=g).to(torch.bfloat16)
+        y, _ = lin(x)
+        assert len(calls) == expect, (m, calls)
+        ref = x.double() @ lin.weight.double().t()
+        assert (y.double() - ref).abs().max().item() < 0.03
+    monkeypatch.setattr(layers, "_LINEAR_MODE", "library")
+    calls.clear()
+    lin(torch.randn(256, 8192, device="cuda", generator=g).to(torch.bfloat16))
+    assert not calls

@@ -54,11 +54,20 @@ def _setup(dev, cfg_name, ctxs, enforce_eager, mrope, quant=None):
     return cfg, runner, w, cpu_caches, mgr, reqs
 
 
-@pytest.mark.parametrize("enforce_eager,quant", [(True, None), (False, None), (True, "int8"), (False, "int8")])
-def test_decode_steps_match_oracle(dev, enforce_eager, quant):
+@pytest.mark.parametrize("enforce_eager,quant,linear_mode",
+                         [(True, None, "auto"), (False, None, "auto"), (True, "int8", "auto"), (False, "int8", "auto"),
+                          (True, None, "kernel"), (False, None, "kernel")])
+def test_decode_steps_match_oracle(dev, enforce_eager, quant, linear_mode, monkeypatch):
     """quant="int8": the decoder linears run W8A8 (online-quantised after load_weights) and the
-    oracle quantises the same weights / activations with the reference's scheme."""
+    oracle quantises the same weights / activations with the reference's scheme.  linear_mode="kernel": every 16-bit
+    projection runs the decode-batch streaming kernel (csrc/skinny_gemm.hip) instead of the library GEMM."""
+    from vllm_omni_amd import layers, ops
     from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SchedulerOutput
+
+    monkeypatch.setattr(layers, "_LINEAR_MODE", linear_mode)
+    kernel_calls = []
+    real_linear = ops.linear
+    monkeypatch.setattr(ops, "linear", lambda *a, **k: (kernel_calls.append(1), real_linear(*a, **k))[1])
 
     ctxs = [5, 16, 40, 1]
     # decode positions are 1-D (all three M-RoPE rows equal at decode => plain RoPE, SURVEY A7)
@@ -135,6 +144,10 @@ def test_decode_steps_match_oracle(dev, enforce_eager, quant):
             r.num_computed_tokens += 1
             r.output_token_ids.append(t)
     assert total == 0 or agree == total, f"greedy ids disagree on {total - agree} of {total} confident rows"
+    if linear_mode == "kernel":
+        assert len(kernel_calls) >= 4 * cfg.num_hidden_layers   # qkv, o, gate_up, down of every layer went through it
+    else:
+        assert not kernel_calls                                 # 4 rows: outside the shapes "auto" hands to the kernel
 
 
 def test_finished_requests_are_removed_and_kv_extracted(dev):

@@ -2,20 +2,23 @@
 //
 // The reference runs these projections (qkv_proj, o_proj, gate_up_proj, down_proj of every decoder layer:
 // vllm_omni/model_executor/models/qwen2_5_omni/qwen2_5_omni_talker.py through vLLM's ColumnParallelLinear /
-// RowParallelLinear) as library GEMMs.  At M = 256 the job is weight streaming: 256 flop per weight byte is
-// under the ~310 flop/B ridge of the chip, so the bound is HBM (the weights, read once) plus the L2 traffic of
-// re-reading x for every weight tile.  The library's tiles are sized for big GEMMs and reach 1.8-3.4 TB/s on
-// these shapes; this kernel is laid out for the streaming case instead:
-//   * swapped form D = W . x^T: a wave owns 16*RG weight rows and ALL the (<= 256) activation rows, so every
-//     weight element is needed by exactly one wave and goes HBM -> VGPR directly as an MFMA A operand (16-byte
-//     loads, two k-blocks ahead) — the weights never touch LDS;
-//   * x is the shared operand: one [16*MT rows][64 k] block per step, staged global -> VGPR -> LDS one block
-//     ahead in a two-stage ring, read back as conflict-free `ds_read_b128` B operands (128-byte rows, 16-byte
-//     chunk XORed with the row-pair index; the k order inside a 64-wide block is permuted the same way for W
-//     and x, chosen so that a lane's two W loads are adjacent and the two k-groups of a `ds_read_b128` lane
-//     group differ by 6 in chunk index — see MI355X_MICROARCH.md "LDS");
-//   * split-K where N alone does not fill the chip (down_proj: 28 tiles x 8 slices = 224 workgroups): fp32
-//     partials to a workspace and a small reduce kernel (+ bias, convert) — deterministic, no atomics.
+// RowParallelLinear) as library GEMMs.  At M = 256 the job is weight streaming: 256 flop per weight byte is under
+// the ~310 flop/B ridge of the chip, so the bound is HBM (the weights, read once) plus the per-CU intake of
+// re-reading x for every weight tile (~68 GB/s per CU from L2: MI355X_MICROARCH.md "Indexed rows").  The library's
+// tiles reach 1.8-3.4 TB/s of weight bytes on these shapes; where N alone does not fill the chip and the library has
+// to fall back to small tiles (down_proj: N 3584, K 18944 -> 1.8 TB/s) this kernel is faster:
+//   * swapped form D = W . x^T on MFMA 16x16x32: a consumer wave owns 32 weight rows x 128 activation rows;
+//   * one 64-wide k block per step; a stage of the LDS ring is ONE image of 128-byte rows — the (<= 256) rows of x, then
+//     the tile's 128 / 160 weight rows — with 16-byte chunk c of row r at c ^ ((r >> 1) & 7): `ds_read_b128`
+//     operand reads are conflict-free.  The k order inside a block is permuted identically for W and x, chosen so
+//     that the two k-groups served by one `ds_read_b128` lane group differ by 6 in chunk index;
+//   * the image is filled by LDS-DMA in 1 KiB pieces by dedicated loader waves; consumer waves only read fragments and
+//     run MFMAs; one raw s_barrier per step; three stages, two steps (~100 KB per CU) in flight;
+//   * split-K where N alone does not fill the chip (down_proj: 28 tiles x 8 slices = 224 workgroups, slice = workgroup
+//     id % 8 so that each XCD's L2 serves one slice of x): fp32 partials to a workspace and a small reduce kernel
+//     (+ bias, convert) — deterministic, no atomics.
+// Measured (tools/bench_skinny_gemm.py): down_proj 51 us against 77 us for the TunableOp-selected
+// library kernel; the other three projections are within +-15 % of the library, which keeps them (layers.py).
 #include "mfma_attn_common.h"
 
 namespace mi {
@@ -28,6 +31,7 @@ struct SkinnyParams {
   uint16_t* out;          // S == 1
   float* part;            // S > 1: [S][M][N]
   int32_t M, N, K, S;
+  int32_t dbg;            // MI_LINEAR_DBG (timing experiments only): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no reduce launch, 8 = no output stores
   int64_t ldx, ldo;
 };
 
@@ -148,14 +152,14 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
         __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it), (lds_void*)(st + (l + NL * i) * 1024), 16,
                                          0, 0);
     };
-    if (n_it > 0) issue(0, 0);
-    if (n_it > 1) issue(1, 1);
+    if (n_it > 0 && !(p.dbg & 1)) issue(0, 0);
+    if (n_it > 1 && !(p.dbg & 1)) issue(1, 1);
     int stage = 2;   // stage of step it + 2
     for (int it = 0; it < n_it; ++it) {
       if (it + 1 < n_it) wait_vmcnt<PPL>();   // step `it` landed; step it + 1 may still be in flight
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      if (it + 2 < n_it) issue(it + 2, stage);
+      if (it + 2 < n_it && !(p.dbg & 1)) issue(it + 2, stage);
       stage = stage == NST - 1 ? 0 : stage + 1;
     }
     return;
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   int stage = 0;
   for (int it = 0; it < n_it; ++it) {
     __builtin_amdgcn_s_barrier();
+    if (p.dbg & 2) continue;
     const uint32_t a0 = frag[0] + stage * kStage, a1 = frag[1] + stage * kStage;
     u32x4_t a[2][2];
     lds_read_w<0>(a0 + w_off, a1 + w_off, a);
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
     stage = stage == NST - 1 ? 0 : stage + 1;
   }
 
+  if (p.dbg & 8) return;
   // D[n][m]: lane = column m (row r16 of m-tile j), rows n = 4 kg + r of the row group
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -315,6 +321,11 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
   p.out = reinterpret_cast<uint16_t*>(out);
   p.part = reinterpret_cast<float*>(workspace);
   p.M = m; p.N = n; p.K = k; p.S = pl.split;
+  static const int dbg = [] {
+    const char* e = getenv("MI_LINEAR_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  p.dbg = dbg;
   p.ldx = x_row_stride;
   p.ldo = out_row_stride;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -346,7 +357,7 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
 #undef MI_SKINNY_T
 #undef MI_SKINNY
   if (launch_status() != MI_OK) return MI_ERR_LAUNCH;
-  if (pl.split > 1) {
+  if (pl.split > 1 && !(p.dbg & 4)) {
     const int64_t quads = (int64_t)m * n / 4;
     const dim3 rgrid((unsigned)((quads + 255) / 256));
     auto o = reinterpret_cast<uint16_t*>(out);

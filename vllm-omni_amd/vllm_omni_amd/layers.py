@@ -3,13 +3,14 @@
 Same names, argument meaning and call order as the classes imported at
 vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:10-17 (``RMSNorm``, ``SiluAndMul``,
 ``get_rope``, ``Attention``, ``QKVParallelLinear``, ``MergedColumnParallelLinear``,
-``RowParallelLinear``).  Every forward is a call into the HIP kernels (``ops``) except the dense
-GEMMs, which are library GEMMs (hipBLASLt through ``torch.nn.functional.linear``; SURVEY A10
-"not a named kernel").  Inference only; parameters are plain tensors.
+``RowParallelLinear``).  Every forward is a call into the HIP kernels (``ops``); the dense GEMMs are
+library GEMMs (hipBLASLt through ``torch.nn.functional.linear``; SURVEY A10 "not a named kernel") except where
+the decode-batch streaming kernel is faster (``_apply_linear``).  Inference only; parameters are plain tensors.
 """
 from __future__ import annotations
 
 import math
+import os
 from contextlib import contextmanager
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -247,11 +248,30 @@ def _init_weight(out_f: int, in_f: int, dtype, device, generator=None, std: floa
     return w.to(dtype)
 
 
+# Which GEMM runs a 16-bit linear layer.  "auto": the hand-written weight-streaming kernel (csrc/skinny_gemm.hip)
+# for decode batches on the shapes where it is measured faster than the TunableOp-selected library GEMM — deep, narrow
+# projections that need split-K to fill the chip (down_proj of the headline talker: 52 us against 77 us, DESIGN.md
+# §3.6) — and the library everywhere else; "library" / "kernel" force one side (the latter wherever the kernel's
+# shape envelope allows).
+_LINEAR_MODE = os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
+
+
+def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
+    return 128 < m <= 256 and k >= 8192 and k >= 2 * n
+
+
 def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """bf16 library GEMM, or the W8A8 path once ``quantize_int8_`` has run on the layer."""
+    """16-bit GEMM (library or the decode-batch streaming kernel), or the W8A8 path once ``quantize_int8_`` has run
+    on the layer."""
     if getattr(layer, "qweight", None) is not None:
         return ops.int8_linear(x, layer.qweight, layer.weight_scale, bias)
-    return F.linear(x, layer.weight, bias)
+    w = layer.weight
+    if _LINEAR_MODE != "library" and x.is_cuda:
+        m = x.numel() // x.shape[-1]
+        n, k = w.shape
+        if ops.linear_supported(m, n, k, x.dtype) and (_LINEAR_MODE == "kernel" or _streaming_kernel_wins(m, n, k)):
+            return ops.linear(x, w, bias)
+    return F.linear(x, w, bias)
 
 
 def quantize_int8_(layer) -> None:
