@@ -317,6 +317,7 @@ def int8_dequant(acc: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor
 
 
 _LINEAR_WS: dict = {}
+_LINEAR_WS_RETIRED: list = []   # outgrown workspaces stay allocated: a captured hipGraph may still write to them
 
 
 def linear_supported(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
@@ -339,6 +340,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     need = lib.mi_linear_workspace_bytes(m, n, k)
     ws = _LINEAR_WS.get(x.device)
     if need and (ws is None or ws.numel() < need):
+        if ws is not None:
+            _LINEAR_WS_RETIRED.append(ws)
         ws = _LINEAR_WS[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
     check("mi_linear", lib.mi_linear(_p(out), _p(x2), _p(weight), _p(bias), m, n, k, x2.stride(0), out.stride(0),
                                      _p(ws) if need else None, ws.numel() if need else 0, _dt(x.dtype), _stream()))
