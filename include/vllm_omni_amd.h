@@ -333,6 +333,14 @@ int64_t mi_linear_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int mi_linear(void* out, const void* x, const void* weight, const void* bias, int32_t m, int32_t n,
               int32_t k, int64_t x_row_stride, int64_t out_row_stride, void* workspace,
               int64_t workspace_bytes, int dtype, void* stream);
+/* gate_up_proj and the SiluAndMul behind it in one launch (Qwen2MLP.forward,
+ * qwen2_old.py:62-66: act_fn(gate_up_proj(x))): weight [2 * inter, k] with the
+ * gate rows first, then the up rows (MergedColumnParallelLinear layout);
+ * out[m, inter] = silu(x . gate^T) * (x . up^T), each GEMM output rounded to
+ * the 16-bit type before the activation, as the unfused pair rounds. */
+int mi_linear_silu_mul(void* out, const void* x, const void* weight, int32_t m, int32_t inter,
+                       int32_t k, int64_t x_row_stride, int64_t out_row_stride, int dtype,
+                       void* stream);
 
 
 /* ------------------------------------------------------------------------

@@ -106,3 +106,32 @@ def test_row_parallel_linear_routes_deep_projections_to_the_kernel(monkeypatch):
     calls.clear()
     lin(torch.randn(256, 8192, device="cuda", generator=g).to(torch.bfloat16))
     assert not calls
+
+
+@pytest.mark.parametrize("m,inter,k", [(256, 18944, 3584), (256, 1024, 512), (100, 80, 128), (17, 4736, 1024),
+                                        (64, 96, 256), (128, 9472, 3584)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_silu_mul_matches_unfused_pair(m, inter, k, dtype):
+    """gate_up_proj + SiluAndMul in one launch against the same two steps done apart with the rounding the unfused
+    pair has: GEMM outputs rounded to the 16-bit type, SiLU and product in fp32, one rounding.  Tolerance: one output
+    ulp for the final rounding + the effect of a one-ulp difference in either rounded GEMM output (fp32 summation
+    order differs from the float64 reference)."""
+    from vllm_omni_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(99 + m + inter + k)
+    x = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(2 * inter, k, device="cuda", generator=g) * k ** -0.5).to(dtype)
+    y = ops.linear_silu_mul(x, w)
+    assert y.shape == (m, inter) and y.dtype == dtype
+    gu = (x.double() @ w.double().t()).to(dtype).float()          # the unfused pair's intermediate
+    gate, up = gu[:, :inter], gu[:, inter:]
+    ref = (gate / (1.0 + torch.exp(-gate)) * up)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # d(silu(g) u) <= |u| * 1.1 * dg + |silu(g)| * du with dg, du one ulp of g, u
+    slack = (up.abs() * 1.1 * gate.abs() + (gate / (1.0 + torch.exp(-gate))).abs() * up.abs()) * ulp
+    tol = ref.abs() * ulp + slack + 1e-3
+    err = (y.float() - ref).abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.4g}"
+    # and against the product's own unfused kernels
+    z = ops.silu_and_mul(ops.linear(x, w)) if ops.linear_supported(m, 2 * inter, k, dtype) else None
+    if z is not None:
+        assert (y.float() - z.float()).abs().max().item() <= float(tol.max())

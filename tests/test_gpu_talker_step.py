@@ -68,6 +68,8 @@ def test_decode_steps_match_oracle(dev, enforce_eager, quant, linear_mode, monke
     kernel_calls = []
     real_linear = ops.linear
     monkeypatch.setattr(ops, "linear", lambda *a, **k: (kernel_calls.append(1), real_linear(*a, **k))[1])
+    real_fused = ops.linear_silu_mul
+    monkeypatch.setattr(ops, "linear_silu_mul", lambda *a, **k: (kernel_calls.append(1), real_fused(*a, **k))[1])
 
     ctxs = [5, 16, 40, 1]
     # decode positions are 1-D (all three M-RoPE rows equal at decode => plain RoPE)
@@ -145,7 +147,7 @@ def test_decode_steps_match_oracle(dev, enforce_eager, quant, linear_mode, monke
             r.output_token_ids.append(t)
     assert total == 0 or agree == total, f"greedy ids disagree on {total - agree} of {total} confident rows"
     if linear_mode == "kernel":
-        assert len(kernel_calls) >= 4 * cfg.num_hidden_layers   # qkv, o, gate_up, down of every layer went through it
+        assert len(kernel_calls) >= 4 * cfg.num_hidden_layers   # qkv, o, gate_up (+ SiLU, fused), down of every layer
     else:
         assert not kernel_calls                                 # 4 rows: outside the shapes "auto" hands to the kernel
 

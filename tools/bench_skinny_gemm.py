@@ -49,5 +49,27 @@ def main():
               f"skinny {t_mine:7.1f} us ({gb / t_mine * 1e3:5.2f} TB/s)   max|diff| {err:.3g}", flush=True)
 
 
+def fused_gate_up():
+    m = int(os.environ.get("M", 256))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    n, k = 37888, 3584
+    ws = [(torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16) for _ in range(3)]
+    x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    i = [0]
+
+    def lib():
+        i[0] = (i[0] + 1) % 3
+        return ops.silu_and_mul(F.linear(x, ws[i[0]]))
+
+    def mine():
+        i[0] = (i[0] + 1) % 3
+        return ops.linear_silu_mul(x, ws[i[0]])
+
+    err = (ops.linear_silu_mul(x, ws[0]).float() - ops.silu_and_mul(F.linear(x, ws[0])).float()).abs().max().item()
+    print(f"gate_up + SiluAndMul m={m}: library GEMM + silu kernel {timed(lib):7.1f} us   fused {timed(mine):7.1f} us   "
+          f"max|diff| {err:.3g}", flush=True)
+
+
 if __name__ == "__main__":
+    fused_gate_up()
     main()

@@ -30,7 +30,7 @@ struct SkinnyParams {
   const uint16_t* bias;   // may be null
   uint16_t* out;          // S == 1
   float* part;            // S > 1: [S][M][N]
-  int32_t M, N, K, S;
+  int32_t M, N, K, S;     // GATED: N = output columns I; the weight has 2 I rows (gate rows, then up rows)
   int32_t dbg;            // MI_LINEAR_DBG (timing experiments only): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no reduce launch, 8 = no output stores
   int64_t ldx, ldo;
 };
@@ -95,7 +95,10 @@ __device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w
 
 // NSLAB: 32-row weight slabs per tile (tile = 32 NSLAB rows); MT: 16-row m-tiles (x rows padded to 16 MT);
 // MH: consumer waves per slab, each with MT / MH m-tiles; NL: loader waves.
-template <typename Tag, int NSLAB, int MT, int MH, int NL>
+// GATED: gate_up_proj with the SiluAndMul that follows it (qwen2_old.py:62-66: act_fn(gate_up_proj(x))) in the epilogue —
+// a slab is 16 gate rows and the 16 matching up rows, a tile covers 16 NSLAB output columns, and the [M, 2 I]
+// intermediate never goes to memory.
+template <typename Tag, int NSLAB, int MT, int MH, int NL, bool GATED>
 __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(const SkinnyParams p) {
   // One pipeline step = one 64-wide k block.  A stage of the LDS ring is one image of 128-byte rows: the 16 MT rows of
   // x, then the tile's 32 NSLAB weight rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7).  The image is
@@ -140,8 +143,16 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
         const int m = row < p.M ? row : p.M - 1;   // rows past M repeat the last one; never stored
         src[i] = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + 64 * (int64_t)b_lo + 8 * lc);
       } else {
-        int n = tile * TR + (row - 16 * MT);
-        n = n < p.N ? n : p.N - 1;                 // a tile may hang over N: those row groups are never stored
+        const int r = row - 16 * MT;               // row of the weight image
+        int n;
+        if constexpr (GATED) {
+          int col = tile * (16 * NSLAB) + 16 * (r >> 5) + (r & 15);
+          col = col < p.N ? col : p.N - 1;
+          n = ((r >> 4) & 1) * p.N + col;          // rows 16-31 of a slab: the up rows of the same columns
+        } else {
+          n = tile * TR + r;
+          n = n < p.N ? n : p.N - 1;               // a tile may hang over N: those row groups are never stored
+        }
         src[i] = reinterpret_cast<const char*>(p.w + (int64_t)n * p.K + 64 * (int64_t)b_lo + 8 * lc);
       }
     }
@@ -208,6 +219,28 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   }
 
   if (p.dbg & 8) return;
+  if constexpr (GATED) {
+    // acc[0] = gate, acc[1] = up of output columns n .. n + 3.  Rounding as in the unfused pair: both GEMM outputs go
+    // to the 16-bit grid first, SiLU and the product in fp32, one more rounding (norm_act.hip silu_mul_kernel)
+    const int n = tile * (16 * NSLAB) + 16 * slab + 4 * kg;
+    if (n >= p.N) return;
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+      const int m = 16 * (mh * MTW + j) + r16;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gt = E::from_bits(E::to_bits(acc[0][j][r])), up = E::from_bits(E::to_bits(acc[1][j][r]));
+        v[r] = gt / (1.f + __expf(-gt)) * up;
+      }
+      uint2 q;
+      q.x = E::pack(v[0], v[1]);
+      q.y = E::pack(v[2], v[3]);
+      *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = q;
+    }
+    return;
+  }
   // D[n][m]: lane = column m (row r16 of m-tile j), rows n = 4 kg + r of the row group
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -285,6 +318,57 @@ SkinnyPlan skinny_plan(int m, int n, int k, int force_split) {
 }  // namespace
 }  // namespace mi
 
+namespace mi {
+namespace {
+
+int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int dtype, hipStream_t s) {
+  const dim3 grid(pl.tiles * pl.split);
+#define MI_SKINNY(TAG, NSLAB, MT, MH, NL, GATED)                                                                  \
+  do {                                                                                                            \
+    auto kern = skinny_gemm_kernel<TAG, NSLAB, MT, MH, NL, GATED>;                                                \
+    constexpr int lds = 3 * (MT * 2048 + NSLAB * 4096);                                                           \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
+    if (attr != hipSuccess) return MI_ERR_LAUNCH;                                                                 \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * (NSLAB * MH + NL)), lds, s, p);                                      \
+  } while (0)
+#define MI_SKINNY_T(TAG, GATED)                              \
+  do {                                                       \
+    if (pl.nslab == 5) {                                     \
+      if (pl.mt == 16) MI_SKINNY(TAG, 5, 16, 2, 2, GATED);   \
+      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, 2, 2, GATED);\
+      else MI_SKINNY(TAG, 5, 4, 1, 2, GATED);                \
+    } else {                                                 \
+      if (pl.mt == 16) MI_SKINNY(TAG, 4, 16, 2, 4, GATED);   \
+      else if (pl.mt == 8) MI_SKINNY(TAG, 4, 8, 2, 4, GATED);\
+      else MI_SKINNY(TAG, 4, 4, 1, 4, GATED);                \
+    }                                                        \
+  } while (0)
+  if (dtype == MI_DTYPE_BF16) {
+    if (gated) MI_SKINNY_T(bf16_tag, true);
+    else MI_SKINNY_T(bf16_tag, false);
+  } else if (dtype == MI_DTYPE_F16) {
+    if (gated) MI_SKINNY_T(f16_tag, true);
+    else MI_SKINNY_T(f16_tag, false);
+  } else {
+    return MI_ERR_UNSUPPORTED;
+  }
+#undef MI_SKINNY_T
+#undef MI_SKINNY
+  return launch_status();
+}
+
+int linear_dbg() {   // MI_LINEAR_DBG: timing experiments only (see SkinnyParams::dbg)
+  static const int v = [] {
+    const char* e = getenv("MI_LINEAR_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+}  // namespace
+}  // namespace mi
+
 namespace {
 int forced_split() {   // MI_LINEAR_SPLIT=<S>: tuning override of the split-K factor (tools/bench_skinny_gemm.py)
   static const int v = [] {
@@ -321,42 +405,12 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
   p.out = reinterpret_cast<uint16_t*>(out);
   p.part = reinterpret_cast<float*>(workspace);
   p.M = m; p.N = n; p.K = k; p.S = pl.split;
-  static const int dbg = [] {
-    const char* e = getenv("MI_LINEAR_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  p.dbg = dbg;
+  p.dbg = linear_dbg();
   p.ldx = x_row_stride;
   p.ldo = out_row_stride;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid(pl.tiles * pl.split);
-#define MI_SKINNY(TAG, NSLAB, MT, MH, NL)                                                                         \
-  do {                                                                                                            \
-    auto kern = skinny_gemm_kernel<TAG, NSLAB, MT, MH, NL>;                                                       \
-    constexpr int lds = 3 * (MT * 2048 + NSLAB * 4096);                                                           \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
-    if (attr != hipSuccess) return MI_ERR_LAUNCH;                                                                 \
-    hipLaunchKernelGGL(kern, grid, dim3(64 * (NSLAB * MH + NL)), lds, s, p);                                      \
-  } while (0)
-#define MI_SKINNY_T(TAG)                                     \
-  do {                                                       \
-    if (pl.nslab == 5) {                                     \
-      if (pl.mt == 16) MI_SKINNY(TAG, 5, 16, 2, 2);          \
-      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, 2, 2);       \
-      else MI_SKINNY(TAG, 5, 4, 1, 2);                       \
-    } else {                                                 \
-      if (pl.mt == 16) MI_SKINNY(TAG, 4, 16, 2, 4);          \
-      else if (pl.mt == 8) MI_SKINNY(TAG, 4, 8, 2, 4);       \
-      else MI_SKINNY(TAG, 4, 4, 1, 4);                       \
-    }                                                        \
-  } while (0)
-  if (dtype == MI_DTYPE_BF16) MI_SKINNY_T(bf16_tag);
-  else if (dtype == MI_DTYPE_F16) MI_SKINNY_T(f16_tag);
-  else return MI_ERR_UNSUPPORTED;
-#undef MI_SKINNY_T
-#undef MI_SKINNY
-  if (launch_status() != MI_OK) return MI_ERR_LAUNCH;
+  const int lrc = launch_skinny(p, pl, false, dtype, s);
+  if (lrc != MI_OK) return lrc;
   if (pl.split > 1 && !(p.dbg & 4)) {
     const int64_t quads = (int64_t)m * n / 4;
     const dim3 rgrid((unsigned)((quads + 255) / 256));
@@ -368,4 +422,32 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
       hipLaunchKernelGGL((skinny_reduce_kernel<f16_tag>), rgrid, dim3(256), 0, s, o, p.part, b, m, n, pl.split, out_row_stride);
   }
   return launch_status();
+}
+
+extern "C" int mi_linear_silu_mul(void* out, const void* x, const void* weight, int32_t m, int32_t inter, int32_t k,
+                                  int64_t x_row_stride, int64_t out_row_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (m == 0 || inter == 0) return MI_OK;
+  if (!out || !x || !weight || m < 0 || inter < 0 || k <= 0) return MI_ERR_INVALID_ARG;
+  if (m > 256 || k % 64 || inter % 16 || x_row_stride % 8 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)weight) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
+  // a tile = 16 NSLAB output columns (gate + up rows of each); no split-K: the activation needs the whole sum
+  SkinnyPlan pl;
+  pl.mt = m <= 64 ? 4 : m <= 128 ? 8 : 16;
+  const int t80 = (inter + 79) / 80, t64 = (inter + 63) / 64;
+  if (t80 > 128 && t80 <= 256) { pl.nslab = 5; pl.tiles = t80; }
+  else { pl.nslab = 4; pl.tiles = t64; }
+  pl.split = 1;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(x);
+  p.w = reinterpret_cast<const uint16_t*>(weight);
+  p.bias = nullptr;
+  p.out = reinterpret_cast<uint16_t*>(out);
+  p.part = nullptr;
+  p.M = m; p.N = inter; p.K = k; p.S = 1;
+  p.dbg = linear_dbg();
+  p.ldx = x_row_stride;
+  p.ldo = out_row_stride;
+  return launch_skinny(p, pl, true, dtype, reinterpret_cast<hipStream_t>(stream));
 }

@@ -260,6 +260,29 @@ def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
     return 128 < m <= 256 and k >= 8192 and k >= 2 * n
 
 
+def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """``act_fn(gate_up_proj(x))`` in one launch (``ops.linear_silu_mul``) when the policy picks the streaming kernel
+    for this shape, else None (the caller runs the GEMM and ``SiluAndMul`` apart).  Column-parallel, no bias, 16-bit
+    weights only; under TP a rank's weight is [gate shard; up shard], the layout the kernel expects."""
+    if _LINEAR_MODE == "library" or not x.is_cuda or getattr(layer, "qweight", None) is not None:
+        return None
+    if layer.bias is not None or getattr(layer, "gather_output", False):
+        return None
+    w = layer.weight
+    m = x.numel() // x.shape[-1]
+    n, k = w.shape
+    if n % 32 or not ops.linear_supported(m, n // 2, k, x.dtype):
+        return None
+    if _LINEAR_MODE != "kernel" and not _fused_gate_up_wins(m, n // 2, k):
+        return None
+    return ops.linear_silu_mul(x, w)
+
+
+def _fused_gate_up_wins(m: int, inter: int, k: int) -> bool:
+    # one launch of 16 * NSLAB-column tiles must fill the chip about once: 129-256 tiles of 80 columns
+    return 128 < m <= 256 and 128 * 80 < inter <= 256 * 80
+
+
 def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """16-bit GEMM (library or the decode-batch streaming kernel), or the W8A8 path once ``quantize_int8_`` has run
     on the layer."""

@@ -348,6 +348,23 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out.view(*x.shape[:-1], n)
 
 
+def linear_silu_mul(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """silu(x Wg^T) * (x Wu^T) for a decode batch, weight = [gate rows; up rows] — ``gate_up_proj`` and the
+    ``SiluAndMul`` behind it (qwen2_old.py:62-66) in one launch; the [m, 2 I] intermediate never reaches memory."""
+    _gpu(x, weight)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    m, k = x2.shape
+    if weight.shape[0] % 2 or weight.shape[1] != k or not weight.is_contiguous() or weight.dtype != x.dtype:
+        raise ValueError("weight must be a contiguous [2 * inter, k] tensor of x's dtype")
+    inter = weight.shape[0] // 2
+    out = torch.empty(m, inter, dtype=x.dtype, device=x.device)
+    check("mi_linear_silu_mul", lib.mi_linear_silu_mul(_p(out), _p(x2), _p(weight), m, inter, k, x2.stride(0),
+                                                       out.stride(0), _dt(x.dtype), _stream()))
+    return out.view(*x.shape[:-1], inter)
+
+
 # Library int8 GEMM (hipBLASLt behind torch._int_mm) needs M > 16 and K, N multiples of 8; everything else
 # goes through the hand-written MFMA kernel.  VLLM_OMNI_AMD_INT8_GEMM=mfma forces the latter.
 _INT8_FORCE_MFMA = __import__("os").environ.get("VLLM_OMNI_AMD_INT8_GEMM", "") == "mfma"

@@ -20,7 +20,8 @@ import torch.nn.functional as F
 from . import ops
 from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size
 from .layers import (Attention, MergedColumnParallelLinear, QKVParallelLinear, RMSNorm, RowParallelLinear,
-                     SiluAndMul, _init_weight, get_rope, shard_column, shard_merged_column, shard_qkv, shard_row)
+                     SiluAndMul, _init_weight, fused_gate_up_silu, get_rope, shard_column, shard_merged_column,
+                     shard_qkv, shard_row)
 from .distributed import tensor_model_parallel_all_gather
 
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
@@ -112,9 +113,11 @@ class Qwen2MLP:
         self.act_fn = SiluAndMul()
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        gate_up, _ = self.gate_up_proj(x)
-        x = self.act_fn(gate_up)
-        x, _ = self.down_proj(x)
+        act = fused_gate_up_silu(self.gate_up_proj, x)   # one launch where the streaming kernel wins (layers.py)
+        if act is None:
+            gate_up, _ = self.gate_up_proj(x)
+            act = self.act_fn(gate_up)
+        x, _ = self.down_proj(act)
         return x
 
 
