@@ -21,6 +21,17 @@
 // library kernel; the other three projections are within +-15 % of the library, which keeps them (layers.py).
 #include "mfma_attn_common.h"
 
+// experiment switches (csrc/Makefile `make variant VARIANT_DEFS=...`); the defaults are the measured best
+#ifndef MI_SKINNY_W_AUX
+#define MI_SKINNY_W_AUX 2        // cache policy of the weight pieces: 0 default, 2 = nt (streamed once: -0.6 % on the step)
+#endif
+#ifndef MI_SKINNY_NL5
+#define MI_SKINNY_NL5 2          // loader waves of the 160-row tile (10 consumer waves)
+#endif
+#ifndef MI_SKINNY_LOADER_PRIO
+#define MI_SKINNY_LOADER_PRIO 3  // s_setprio of the loader waves (their issue slots come before the consumers')
+#endif
+
 namespace mi {
 namespace {
 
@@ -132,6 +143,7 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   if (wid >= NC) {
     // ------------------------------------------------------------------ loader
     const int l = wid - NC;
+    if (MI_SKINNY_LOADER_PRIO) __builtin_amdgcn_s_setprio(MI_SKINNY_LOADER_PRIO);
     const int drow = lane >> 3, dpc = lane & 7;
     const char* src[PPL];
 #pragma unroll
@@ -159,9 +171,14 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
     auto issue = [&](int it, int stage) {
       char* st = smem + stage * kStage;
 #pragma unroll
-      for (int i = 0; i < PPL; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it), (lds_void*)(st + (l + NL * i) * 1024), 16,
-                                         0, 0);
+      for (int i = 0; i < PPL; ++i) {
+        if (l + NL * i < XI)
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it),
+                                           (lds_void*)(st + (l + NL * i) * 1024), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it),
+                                           (lds_void*)(st + (l + NL * i) * 1024), 16, 0, MI_SKINNY_W_AUX);
+      }
     };
     if (n_it > 0 && !(p.dbg & 1)) issue(0, 0);
     if (n_it > 1 && !(p.dbg & 1)) issue(1, 1);
@@ -276,8 +293,15 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(uint16_t* __restrict
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= quads) return;
   const int m = (int)(q / (N / 4)), n = (int)(q - (int64_t)m * (N / 4)) * 4;
-  f32x4_t a = *reinterpret_cast<const f32x4_t*>(part + (int64_t)m * N + n);
-  for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4_t*>(part + ((int64_t)s * M + m) * N + n);
+  // all the slices' loads in flight at once (S <= 16: skinny_plan), then summed in slice order
+  f32x4_t v[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+    if (s < S) v[s] = *reinterpret_cast<const f32x4_t*>(part + ((int64_t)s * M + m) * N + n);
+  f32x4_t a = v[0];
+#pragma unroll
+  for (int s = 1; s < 16; ++s)
+    if (s < S) a += v[s];
   if (bias) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] += E::from_bits(bias[n + r]);
@@ -310,7 +334,7 @@ SkinnyPlan skinny_plan(int m, int n, int k, int force_split) {
   if (s < 1) s = 1;
   if (s > nb / 4) s = nb / 4 > 0 ? nb / 4 : 1;
   if (s > 16) s = 16;
-  if (force_split > 0) s = force_split;
+  if (force_split > 0) s = force_split < 16 ? force_split : 16;
   pl.split = s;
   return pl;
 }
@@ -335,9 +359,9 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
 #define MI_SKINNY_T(TAG, GATED)                              \
   do {                                                       \
     if (pl.nslab == 5) {                                     \
-      if (pl.mt == 16) MI_SKINNY(TAG, 5, 16, 2, 2, GATED);   \
-      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, 2, 2, GATED);\
-      else MI_SKINNY(TAG, 5, 4, 1, 2, GATED);                \
+      if (pl.mt == 16) MI_SKINNY(TAG, 5, 16, 2, MI_SKINNY_NL5, GATED);   \
+      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, 2, MI_SKINNY_NL5, GATED);\
+      else MI_SKINNY(TAG, 5, 4, 1, MI_SKINNY_NL5, GATED);                \
     } else {                                                 \
       if (pl.mt == 16) MI_SKINNY(TAG, 4, 16, 2, 4, GATED);   \
       else if (pl.mt == 8) MI_SKINNY(TAG, 4, 8, 2, 4, GATED);\

@@ -9,7 +9,9 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvllm_omni_amd.so")
+# VLLM_OMNI_AMD_LIB: an alternative build of the same ABI (kernel experiments: csrc/Makefile `make variant`)
+_LIB_PATH = os.environ.get("VLLM_OMNI_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                                "libvllm_omni_amd.so")
 
 MI_DTYPE_F16, MI_DTYPE_BF16, MI_DTYPE_F32 = 0, 1, 2
 MI_OK = 0
