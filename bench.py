@@ -94,8 +94,8 @@ def plan_label(tp: int, dp: int) -> str:
 # Per-rank step time (ms) of every (tp, dp) plan at the headline shape, measured on ONE MI355X with the
 # collectives stubbed (`bench.py --simulate-shard TP,DP`, profiles/r01_scaling_estimate.md).  Decode sequences are
 # independent, so data parallelism needs no collective; tensor parallelism adds 2 all-reduces per layer.
-COMPUTE_MS = {(1, 1): 16.75, (2, 1): 9.87, (1, 2): 10.84, (4, 1): 6.59, (2, 2): 7.03, (1, 4): 7.58,
-              (4, 2): 4.58, (2, 4): 4.92, (1, 8): 5.63}
+COMPUTE_MS = {(1, 1): 15.59, (2, 1): 9.42, (1, 2): 9.51, (4, 1): 6.20, (2, 2): 6.44, (1, 4): 6.66,
+              (4, 2): 4.41, (2, 4): 4.47, (1, 8): 4.95}
 
 
 def choose_plan(world: int, rank: int, cfg, a, dev, probe: bool = True, backend: str = "nccl"):

@@ -84,9 +84,9 @@ def test_linear_rejects_unsupported():
 
 
 def test_row_parallel_linear_routes_deep_projections_to_the_kernel(monkeypatch):
-    """The "auto" policy (layers._streaming_kernel_wins): a decode batch of 129..256 rows through a deep, narrow
-    projection (k >= 8192, k >= 2 n — the headline talker's down_proj) runs the streaming kernel; other shapes and
-    larger batches stay on the library GEMM.  Either way the layer's result matches an fp32 reference."""
+    """The "auto" policy (layers._streaming_kernel_wins): a decode batch of up to 256 rows through a deep, narrow
+    projection (k >= 8192, k >= 2 n — the headline talker's down_proj at TP 1 and 2) runs the streaming kernel; other
+    shapes and larger batches stay on the library GEMM.  Either way the layer's result matches an fp32 reference."""
     from vllm_omni_amd import layers, ops
     calls = []
     real = ops.linear
@@ -95,7 +95,7 @@ def test_row_parallel_linear_routes_deep_projections_to_the_kernel(monkeypatch):
     g = torch.Generator(device="cuda").manual_seed(3)
     lin = layers.RowParallelLinear(8192, 1024, bias=False, dtype=torch.bfloat16, device="cuda")
     lin.weight = (torch.randn(1024, 8192, device="cuda", generator=g) * 0.01).to(torch.bfloat16)
-    for m, expect in [(256, 1), (200, 1), (128, 0), (512, 0)]:
+    for m, expect in [(256, 1), (200, 1), (128, 1), (32, 1), (512, 0)]:
         calls.clear()
         x = torch.randn(m, 8192, device="cuda", generator=g).to(torch.bfloat16)
         y, _ = lin(x)
@@ -135,3 +135,24 @@ def test_linear_silu_mul_matches_unfused_pair(m, inter, k, dtype):
     z = ops.silu_and_mul(ops.linear(x, w)) if ops.linear_supported(m, 2 * inter, k, dtype) else None
     if z is not None:
         assert (y.float() - z.float()).abs().max().item() <= float(tol.max())
+
+
+def test_mlp_uses_the_fused_gate_up_kernel_when_the_policy_says_so(monkeypatch):
+    """Qwen2MLP: act_fn(gate_up_proj(x)) runs as one launch for I >= 8192 per rank (auto), as two steps otherwise; both
+    ways equal the two-step result to the fused kernel's tolerance."""
+    from vllm_omni_amd import layers, ops
+    fused = []
+    real = ops.linear_silu_mul
+    monkeypatch.setattr(ops, "linear_silu_mul", lambda *a, **k: (fused.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(layers, "_LINEAR_MODE", "auto")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for inter, expect in [(8192, 1), (4096, 0)]:
+        gu = layers.MergedColumnParallelLinear(512, [inter] * 2, bias=False, dtype=torch.bfloat16, device="cuda")
+        gu.weight = (torch.randn(2 * inter, 512, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        x = torch.randn(64, 512, device="cuda", generator=g).to(torch.bfloat16)
+        fused.clear()
+        y = layers.fused_gate_up_silu(gu, x)
+        assert len(fused) == expect and (y is None) == (expect == 0)
+        if y is not None:
+            z = ops.silu_and_mul(torch.nn.functional.linear(x, gu.weight))
+            assert (y.float() - z.float()).abs().max().item() <= 0.02 * z.float().abs().max().item() + 1e-3

@@ -249,15 +249,17 @@ def _init_weight(out_f: int, in_f: int, dtype, device, generator=None, std: floa
 
 
 # Which GEMM runs a 16-bit linear layer.  "auto": the hand-written weight-streaming kernel (csrc/skinny_gemm.hip)
-# for decode batches on the shapes where it is measured faster than the TunableOp-selected library GEMM — deep, narrow
-# projections that need split-K to fill the chip (down_proj of the headline talker: 52 us against 77 us, DESIGN.md
-# §3.6) — and the library everywhere else; "library" / "kernel" force one side (the latter wherever the kernel's
-# shape envelope allows).
+# for decode batches on the shapes where it is measured faster than the TunableOp-selected library GEMM — the two MLP
+# projections of the headline talker at TP 1 and 2 — and the library everywhere else; "library" /
+# "kernel" force one side (the latter wherever the kernel's shape envelope allows); "mlp" forces the kernel for the
+# MLP pair only (policy experiments).
 _LINEAR_MODE = os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
 
 
 def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
-    return 128 < m <= 256 and k >= 8192 and k >= 2 * n
+    # measured in situ at the headline talker's shapes, whole and TP-sharded, batch 32-256 per rank:
+    # ahead of the library at K 18944 and 9472 (TP 1, 2), level at 4736 with 128 rows, behind with 256 (TP 4)
+    return m <= 256 and k >= 8192 and k >= 2 * n
 
 
 def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
@@ -273,14 +275,14 @@ def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
     n, k = w.shape
     if n % 32 or not ops.linear_supported(m, n // 2, k, x.dtype):
         return None
-    if _LINEAR_MODE != "kernel" and not _fused_gate_up_wins(m, n // 2, k):
+    if _LINEAR_MODE not in ("kernel", "mlp") and not _fused_gate_up_wins(m, n // 2, k):
         return None
     return ops.linear_silu_mul(x, w)
 
 
 def _fused_gate_up_wins(m: int, inter: int, k: int) -> bool:
-    # one launch of 16 * NSLAB-column tiles must fill the chip about once: 129-256 tiles of 80 columns
-    return 128 < m <= 256 and 128 * 80 < inter <= 256 * 80
+    # same measurements: ahead at I 18944 and 9472 per rank (>= ~120 tiles in one launch), not at 4736
+    return m <= 256 and inter >= 8192
 
 
 def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
@@ -292,7 +294,9 @@ def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch
     if _LINEAR_MODE != "library" and x.is_cuda:
         m = x.numel() // x.shape[-1]
         n, k = w.shape
-        if ops.linear_supported(m, n, k, x.dtype) and (_LINEAR_MODE == "kernel" or _streaming_kernel_wins(m, n, k)):
+        if ops.linear_supported(m, n, k, x.dtype) and (
+                _LINEAR_MODE == "kernel" or _streaming_kernel_wins(m, n, k)
+                or (_LINEAR_MODE == "mlp" and getattr(layer, "_is_down_proj", False))):
             return ops.linear(x, w, bias)
     return F.linear(x, w, bias)
 

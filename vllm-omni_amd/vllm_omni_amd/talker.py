@@ -110,6 +110,7 @@ class Qwen2MLP:
                                                        dtype=dtype, device=device, generator=generator)
         self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False, dtype=dtype,
                                            device=device, generator=generator)
+        self.down_proj._is_down_proj = True   # VLLM_OMNI_AMD_LINEAR=mlp (policy experiments): both MLP GEMMs on the kernel
         self.act_fn = SiluAndMul()
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
