@@ -333,6 +333,24 @@ int64_t mi_linear_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int mi_linear(void* out, const void* x, const void* weight, const void* bias, int32_t m, int32_t n,
               int32_t k, int64_t x_row_stride, int64_t out_row_stride, void* workspace,
               int64_t workspace_bytes, int dtype, void* stream);
+/* The two halves of a split-K mi_linear, for callers that fold the reduction
+ * into the next kernel: mi_linear_partials runs the streaming kernel only and
+ * leaves fp32 partials [split][m][n] in `workspace` (*split_out = split >= 2;
+ * MI_ERR_UNSUPPORTED when the shape's plan has no split — use mi_linear);
+ * mi_linear_reduce sums them in slice order (+ bias) into the 16-bit output;
+ * mi_fused_add_rms_norm_splitk does that sum inside the fused residual-add +
+ * RMSNorm that follows o_proj / down_proj (qwen2_old.py:212-216): out =
+ * rmsnorm(rnd(sum + bias) + residual) * weight, residual <- rnd(sum + bias) +
+ * residual — bit-identical to mi_linear followed by mi_fused_add_rms_norm. */
+int mi_linear_partials(const void* x, const void* weight, int32_t m, int32_t n, int32_t k,
+                       int64_t x_row_stride, void* workspace, int64_t workspace_bytes,
+                       int32_t* split_out, int dtype, void* stream);
+int mi_linear_reduce(void* out, const void* partials, int32_t split, const void* bias, int32_t m,
+                     int32_t n, int64_t out_row_stride, int dtype, void* stream);
+int mi_fused_add_rms_norm_splitk(void* out, const void* partials, int32_t split, const void* bias,
+                                 void* residual, const void* weight, float eps, int32_t num_tokens,
+                                 int32_t hidden, int64_t out_token_stride,
+                                 int64_t residual_token_stride, int dtype, void* stream);
 /* gate_up_proj and the SiluAndMul behind it in one launch (Qwen2MLP.forward,
  * qwen2_old.py:62-66: act_fn(gate_up_proj(x))): weight [2 * inter, k] with the
  * gate rows first, then the up rows (MergedColumnParallelLinear layout);

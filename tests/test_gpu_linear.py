@@ -156,3 +156,37 @@ def test_mlp_uses_the_fused_gate_up_kernel_when_the_policy_says_so(monkeypatch):
         if y is not None:
             z = ops.silu_and_mul(torch.nn.functional.linear(x, gu.weight))
             assert (y.float() - z.float()).abs().max().item() <= 0.02 * z.float().abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("m,n,k,bias", [(256, 3584, 18944, False), (32, 3584, 18944, True), (100, 512, 2048, True)])
+def test_deferred_splitk_reduce_is_bit_identical(m, n, k, bias):
+    """linear_partials + fused_add_rms_norm_splitk == linear + fused_add_rms_norm, bit for bit (same slice order, same
+    roundings), for the output and for the updated residual; materialize() == linear."""
+    from vllm_omni_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+    b = torch.randn(n, device="cuda", generator=g).to(torch.bfloat16) if bias else None
+    res = torch.randn(m, n, device="cuda", generator=g).to(torch.bfloat16)
+    nw = torch.randn(n, device="cuda", generator=g).to(torch.bfloat16)
+    y = ops.linear(x, w, b)
+    r1 = res.clone()
+    y1 = y.clone()
+    ops.fused_add_rms_norm(y1, r1, nw, 1e-6)
+    part = ops.linear_partials(x, w, b)
+    assert part is not None and part.split >= 2
+    assert torch.equal(part.materialize(), y)
+    r2 = res.clone()
+    y2 = ops.fused_add_rms_norm_splitk(part, r2, nw, 1e-6)
+    assert torch.equal(y2, y1) and torch.equal(r2, r1)
+    # partials are consumed in order: a later split-K linear invalidates them
+    ops.linear(x, w, b)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        part.materialize()
+
+
+def test_linear_partials_none_without_split():
+    from vllm_omni_amd import ops
+    x = torch.zeros(256, 3584, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(37888, 3584, device="cuda", dtype=torch.bfloat16)
+    assert ops.linear_partials(x, w) is None      # 237 tiles fill the chip: no split-K, nothing to defer

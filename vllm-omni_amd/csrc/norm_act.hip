@@ -85,6 +85,88 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ ou
   }
 }
 
+// The fused-add form fed by the split-K partials of the decode-batch linear kernel (skinny_gemm.hip) instead of a
+// 16-bit x: x = rnd(sum_s part[s] (+ bias)) — the reduce kernel's arithmetic, slice order and rounding — then exactly
+// the ADD path above.  Saves the reduce launch and the round trip of x through memory (down_proj -> next layer's
+// input_layernorm; qwen2_old.py:212-216).
+template <typename Tag, int MAXC>
+__global__ __launch_bounds__(256) void rms_norm_splitk_kernel(uint16_t* __restrict__ out, const float* __restrict__ part,
+                                                              int S, const uint16_t* __restrict__ bias,
+                                                              uint16_t* __restrict__ residual,
+                                                              const uint16_t* __restrict__ w, float eps, int T, int hidden,
+                                                              int64_t out_stride, int64_t r_stride) {
+  scalar_cache_acquire();
+  using E = Elem<Tag>;
+  __shared__ float smem[4];
+  const int row = blockIdx.x;
+  const int nchunk = hidden / 8;
+  uint16_t* rr = residual + row * r_stride;
+  uint16_t* orow = out + row * out_stride;
+  uint4 z[MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = threadIdx.x + k * 256;
+    if (ch < nchunk) {
+      const float* p0 = part + (int64_t)row * hidden + ch * 8;
+      // every slice's loads in flight at once (S <= 16), then summed in slice order
+      float4 vl[16], vh[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (s < S) {
+          const float* ps = p0 + (int64_t)s * T * hidden;
+          vl[s] = *reinterpret_cast<const float4*>(ps);
+          vh[s] = *reinterpret_cast<const float4*>(ps + 4);
+        }
+      float4 lo = vl[0], hi = vh[0];
+#pragma unroll
+      for (int s = 1; s < 16; ++s)
+        if (s < S) {
+          lo.x += vl[s].x; lo.y += vl[s].y; lo.z += vl[s].z; lo.w += vl[s].w;
+          hi.x += vh[s].x; hi.y += vh[s].y; hi.z += vh[s].z; hi.w += vh[s].w;
+        }
+      if (bias) {
+        const uint4 bv = *reinterpret_cast<const uint4*>(bias + ch * 8);
+        lo.x += E::lo(bv.x); lo.y += E::hi(bv.x); lo.z += E::lo(bv.y); lo.w += E::hi(bv.y);
+        hi.x += E::lo(bv.z); hi.y += E::hi(bv.z); hi.z += E::lo(bv.w); hi.w += E::hi(bv.w);
+      }
+      uint4 a = make_uint4(E::pack(lo.x, lo.y), E::pack(lo.z, lo.w), E::pack(hi.x, hi.y), E::pack(hi.z, hi.w));
+      const uint4 b = *reinterpret_cast<const uint4*>(rr + ch * 8);
+      a.x = E::pack(E::lo(a.x) + E::lo(b.x), E::hi(a.x) + E::hi(b.x));
+      a.y = E::pack(E::lo(a.y) + E::lo(b.y), E::hi(a.y) + E::hi(b.y));
+      a.z = E::pack(E::lo(a.z) + E::lo(b.z), E::hi(a.z) + E::hi(b.z));
+      a.w = E::pack(E::lo(a.w) + E::lo(b.w), E::hi(a.w) + E::hi(b.w));
+      *reinterpret_cast<uint4*>(rr + ch * 8) = a;
+      z[k] = a;
+      const uint32_t ws[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float l = E::lo(ws[i]), h = E::hi(ws[i]);
+        ss += l * l + h * h;
+      }
+    }
+  }
+  ss = block_allreduce_sum(ss, smem);
+  const float inv = __builtin_amdgcn_rsqf(ss / (float)hidden + eps);
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = threadIdx.x + k * 256;
+    if (ch < nchunk) {
+      const uint4 wv = *reinterpret_cast<const uint4*>(w + ch * 8);
+      const uint32_t zs[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
+      const uint32_t ws[4] = {wv.x, wv.y, wv.z, wv.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float nlo = E::from_bits(E::to_bits(E::lo(zs[i]) * inv));
+        const float nhi = E::from_bits(E::to_bits(E::hi(zs[i]) * inv));
+        o[i] = E::pack(nlo * E::lo(ws[i]), nhi * E::hi(ws[i]));
+      }
+      *reinterpret_cast<uint4*>(orow + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 // Any hidden size / alignment: scalar, two passes over memory (row re-read hits L2).
 template <typename Tag, bool ADD>
 __global__ __launch_bounds__(256) void rms_norm_generic_kernel(uint16_t* out, const uint16_t* x,
@@ -292,6 +374,42 @@ extern "C" int mi_fused_add_rms_norm(void* x, void* residual, const void* weight
     return launch_rms<f16_tag>(x, x, residual, weight, eps, num_tokens, hidden, x_token_stride,
                                x_token_stride, residual_token_stride, s);
   return MI_ERR_UNSUPPORTED;
+}
+
+extern "C" int mi_fused_add_rms_norm_splitk(void* out, const void* partials, int32_t split, const void* bias,
+                                            void* residual, const void* weight, float eps, int32_t num_tokens,
+                                            int32_t hidden, int64_t out_token_stride, int64_t residual_token_stride,
+                                            int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!out || !partials || !residual || !weight || num_tokens < 0 || hidden <= 0 || split < 1 || split > 16)
+    return MI_ERR_INVALID_ARG;
+  if (hidden % 8 || out_token_stride % 8 || residual_token_stride % 8 || hidden > 8 * 256 * 4) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)out | (uintptr_t)partials | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias) & 15)
+    return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto pp = reinterpret_cast<const float*>(partials);
+  auto bb = reinterpret_cast<const uint16_t*>(bias);
+  auto rr = reinterpret_cast<uint16_t*>(residual);
+  auto ww = reinterpret_cast<const uint16_t*>(weight);
+  const int c = (hidden / 8 + 255) / 256;
+  const dim3 grid(num_tokens), block(256);
+#define MI_RMS_SK(TAG, C)                                                                                       \
+  hipLaunchKernelGGL((rms_norm_splitk_kernel<TAG, C>), grid, block, 0, s, o, pp, split, bb, rr, ww, eps, num_tokens, \
+                     hidden, out_token_stride, residual_token_stride)
+#define MI_RMS_SK_T(TAG)              \
+  do {                                \
+    if (c <= 1) MI_RMS_SK(TAG, 1);    \
+    else if (c <= 2) MI_RMS_SK(TAG, 2); \
+    else MI_RMS_SK(TAG, 4);           \
+  } while (0)
+  if (dtype == MI_DTYPE_BF16) MI_RMS_SK_T(bf16_tag);
+  else if (dtype == MI_DTYPE_F16) MI_RMS_SK_T(f16_tag);
+  else return MI_ERR_UNSUPPORTED;
+#undef MI_RMS_SK_T
+#undef MI_RMS_SK
+  return launch_status();
 }
 
 extern "C" int mi_silu_and_mul(void* out, const void* x, int32_t num_tokens, int32_t inter,

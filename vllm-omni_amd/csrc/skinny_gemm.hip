@@ -448,6 +448,53 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
   return launch_status();
 }
 
+extern "C" int mi_linear_partials(const void* x, const void* weight, int32_t m, int32_t n, int32_t k,
+                                  int64_t x_row_stride, void* workspace, int64_t workspace_bytes, int32_t* split_out,
+                                  int dtype, void* stream) {
+  using namespace mi;
+  if (!x || !weight || !split_out || m <= 0 || n <= 0 || k <= 0) return MI_ERR_INVALID_ARG;
+  if (m > 256 || k % 64 || n % 16 || x_row_stride % 8) return MI_ERR_UNSUPPORTED;
+  if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)weight) & 15) return MI_ERR_INVALID_ARG;
+  const SkinnyPlan pl = skinny_plan(m, n, k, forced_split());
+  if (pl.split <= 1) return MI_ERR_UNSUPPORTED;   // nothing to defer: mi_linear writes the output directly
+  if (!workspace || ((uintptr_t)workspace & 15)) return MI_ERR_INVALID_ARG;
+  if (workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(float)) return MI_ERR_WORKSPACE;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(x);
+  p.w = reinterpret_cast<const uint16_t*>(weight);
+  p.bias = nullptr;
+  p.out = nullptr;
+  p.part = reinterpret_cast<float*>(workspace);
+  p.M = m; p.N = n; p.K = k; p.S = pl.split;
+  p.dbg = linear_dbg();
+  p.ldx = x_row_stride;
+  p.ldo = 0;
+  *split_out = pl.split;
+  return launch_skinny(p, pl, false, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int mi_linear_reduce(void* out, const void* partials, int32_t split, const void* bias, int32_t m, int32_t n,
+                                int64_t out_row_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (m == 0 || n == 0) return MI_OK;
+  if (!out || !partials || split < 1 || split > 16 || m < 0 || n < 0) return MI_ERR_INVALID_ARG;
+  if (n % 4 || out_row_stride % 4 || (((uintptr_t)out & 7) | ((uintptr_t)partials & 15))) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t quads = (int64_t)m * n / 4;
+  const dim3 rgrid((unsigned)((quads + 255) / 256));
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto pp = reinterpret_cast<const float*>(partials);
+  auto b = reinterpret_cast<const uint16_t*>(bias);
+  if (dtype == MI_DTYPE_BF16)
+    hipLaunchKernelGGL((skinny_reduce_kernel<bf16_tag>), rgrid, dim3(256), 0, s, o, pp, b, m, n, split, out_row_stride);
+  else if (dtype == MI_DTYPE_F16)
+    hipLaunchKernelGGL((skinny_reduce_kernel<f16_tag>), rgrid, dim3(256), 0, s, o, pp, b, m, n, split, out_row_stride);
+  else
+    return MI_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
 extern "C" int mi_linear_silu_mul(void* out, const void* x, const void* weight, int32_t m, int32_t inter, int32_t k,
                                   int64_t x_row_stride, int64_t out_row_stride, int dtype, void* stream) {
   using namespace mi;

@@ -59,6 +59,10 @@ SIGNATURES = {
                                c_int, _P]),
     "mi_int8_dequant": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_linear_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "mi_linear_partials": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int64, _P, c_int64, POINTER(c_int32), c_int, _P]),
+    "mi_linear_reduce": (c_int, [_P, _P, c_int32, _P, c_int32, c_int32, c_int64, c_int, _P]),
+    "mi_fused_add_rms_norm_splitk": (c_int, [_P, _P, c_int32, _P, _P, _P, c_float, c_int32, c_int32, c_int64, c_int64,
+                                             c_int, _P]),
     "mi_linear_silu_mul": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_linear": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, _P, c_int64, c_int, _P]),
     "mi_kv_pack": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -83,7 +83,11 @@ class RMSNorm:
         self.weight = torch.ones(hidden_size, dtype=dtype, device=device)
         self.variance_epsilon = eps
 
-    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None):
+    def __call__(self, x, residual: Optional[torch.Tensor] = None):
+        if isinstance(x, ops.SplitKPartials):   # a row-parallel linear left its split-K reduce to this kernel
+            if residual is not None:
+                return ops.fused_add_rms_norm_splitk(x, residual, self.weight, self.variance_epsilon), residual
+            x = x.materialize()
         if residual is None:
             return ops.rms_norm(x, self.weight, self.variance_epsilon)
         ops.fused_add_rms_norm(x, residual, self.weight, self.variance_epsilon)
@@ -254,6 +258,7 @@ def _init_weight(out_f: int, in_f: int, dtype, device, generator=None, std: floa
 # "kernel" force one side (the latter wherever the kernel's shape envelope allows); "mlp" forces the kernel for the
 # MLP pair only (policy experiments).
 _LINEAR_MODE = os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
+_DEFER_REDUCE = os.environ.get("VLLM_OMNI_AMD_DEFER_REDUCE", "1") != "0"   # split-K reduce inside the next RMSNorm
 
 
 def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
@@ -285,9 +290,10 @@ def _fused_gate_up_wins(m: int, inter: int, k: int) -> bool:
     return m <= 256 and inter >= 8192
 
 
-def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_reduce: bool = False):
     """16-bit GEMM (library or the decode-batch streaming kernel), or the W8A8 path once ``quantize_int8_`` has run
-    on the layer."""
+    on the layer.  ``defer_reduce``: when the streaming kernel runs split-K, return its partials
+    (``ops.SplitKPartials``) for the fused-add RMSNorm behind the layer to reduce."""
     if getattr(layer, "qweight", None) is not None:
         return ops.int8_linear(x, layer.qweight, layer.weight_scale, bias)
     w = layer.weight
@@ -297,6 +303,10 @@ def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor]) -> torch
         if ops.linear_supported(m, n, k, x.dtype) and (
                 _LINEAR_MODE == "kernel" or _streaming_kernel_wins(m, n, k)
                 or (_LINEAR_MODE == "mlp" and getattr(layer, "_is_down_proj", False))):
+            if defer_reduce and _DEFER_REDUCE:
+                part = ops.linear_partials(x, w, bias)
+                if part is not None:
+                    return part
             return ops.linear(x, w, bias)
     return F.linear(x, w, bias)
 
@@ -379,10 +389,12 @@ class RowParallelLinear:
         self.weight = _init_weight(output_size, self.input_size_per_partition, dtype, device, generator)
         self.bias = torch.zeros(output_size, dtype=dtype, device=device) if bias else None
 
-    def __call__(self, x: torch.Tensor):
+    def __call__(self, x: torch.Tensor, defer_reduce: bool = False):
         # bias is added once (rank 0) so the all-reduced sum carries it exactly once
-        y = _apply_linear(self, x, self.bias if self.tp_rank == 0 else None)
-        if self.reduce_results:
+        # defer_reduce (no TP only: an all-reduce needs the 16-bit tensor): the caller hands y to a fused-add RMSNorm
+        defer = defer_reduce and self.tp_size == 1
+        y = _apply_linear(self, x, self.bias if self.tp_rank == 0 else None, defer)
+        if self.reduce_results and self.tp_size > 1:
             y = tensor_model_parallel_all_reduce(y)
         return y, None
 

@@ -338,14 +338,82 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         raise ValueError("weight must be a contiguous [n, k] tensor of x's dtype")
     out = torch.empty(m, n, dtype=x.dtype, device=x.device)
     need = lib.mi_linear_workspace_bytes(m, n, k)
-    ws = _LINEAR_WS.get(x.device)
-    if need and (ws is None or ws.numel() < need):
-        if ws is not None:
-            _LINEAR_WS_RETIRED.append(ws)
-        ws = _LINEAR_WS[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ws = _linear_workspace(x.device, need) if need else None
     check("mi_linear", lib.mi_linear(_p(out), _p(x2), _p(weight), _p(bias), m, n, k, x2.stride(0), out.stride(0),
                                      _p(ws) if need else None, ws.numel() if need else 0, _dt(x.dtype), _stream()))
     return out.view(*x.shape[:-1], n)
+
+
+class SplitKPartials:
+    """fp32 partials [split, m, n] of a split-K ``linear`` whose reduction has been left to the consumer: the fused
+    residual-add + RMSNorm that follows (``fused_add_rms_norm_splitk``) or ``materialize()``.  The partials live in
+    the shared workspace: they must be consumed before the next split-K linear on this device (checked)."""
+
+    __slots__ = ("part", "split", "m", "n", "bias", "dtype", "lead", "device", "_gen")
+
+    def __init__(self, part, split, m, n, bias, dtype, lead, device, gen):
+        self.part, self.split, self.m, self.n, self.bias, self.dtype = part, split, m, n, bias, dtype
+        self.lead, self.device, self._gen = lead, device, gen
+
+    def _live(self) -> None:
+        if _LINEAR_GEN.get(self.device) != self._gen:
+            raise RuntimeError("split-K partials were overwritten by a later linear before they were reduced")
+
+    def materialize(self) -> torch.Tensor:
+        self._live()
+        out = torch.empty(self.m, self.n, dtype=self.dtype, device=self.device)
+        check("mi_linear_reduce", lib.mi_linear_reduce(_p(out), _p(self.part), self.split, _p(self.bias), self.m, self.n,
+                                                       out.stride(0), _dt(self.dtype), _stream()))
+        return out.view(*self.lead, self.n)
+
+
+_LINEAR_GEN: dict = {}
+
+
+def _linear_workspace(device, need: int) -> torch.Tensor:
+    ws = _LINEAR_WS.get(device)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _LINEAR_WS_RETIRED.append(ws)
+        ws = _LINEAR_WS[device] = torch.empty(need, dtype=torch.uint8, device=device)
+    _LINEAR_GEN[device] = _LINEAR_GEN.get(device, 0) + 1
+    return ws
+
+
+def linear_partials(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> Optional[SplitKPartials]:
+    """The streaming kernel of ``linear`` without its reduce launch, or None when this shape's plan has no split-K
+    (nothing to defer).  Reduce with ``fused_add_rms_norm_splitk`` or ``.materialize()``."""
+    _gpu(x, weight, bias)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    m, k = x2.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k or not weight.is_contiguous() or weight.dtype != x.dtype:
+        raise ValueError("weight must be a contiguous [n, k] tensor of x's dtype")
+    need = lib.mi_linear_workspace_bytes(m, n, k)
+    if not need:
+        return None
+    ws = _linear_workspace(x.device, need)
+    split = ctypes.c_int32(0)
+    check("mi_linear_partials", lib.mi_linear_partials(_p(x2), _p(weight), m, n, k, x2.stride(0), _p(ws), ws.numel(),
+                                                       ctypes.byref(split), _dt(x.dtype), _stream()))
+    return SplitKPartials(ws, split.value, m, n, bias, x.dtype, tuple(x.shape[:-1]), x.device, _LINEAR_GEN[x.device])
+
+
+def fused_add_rms_norm_splitk(p: SplitKPartials, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """residual <- rnd(sum of the partials (+ bias)) + residual (in place); returns rmsnorm(residual) * weight — the
+    reduce of a split-K ``linear`` folded into the fused-add RMSNorm behind it, bit-identical to the two apart."""
+    _gpu(residual, weight)
+    p._live()
+    r2 = residual.view(-1, residual.shape[-1])
+    if r2.shape != (p.m, p.n):
+        raise ValueError("residual shape does not match the partials")
+    out = torch.empty(p.m, p.n, dtype=p.dtype, device=p.device)
+    check("mi_fused_add_rms_norm_splitk", lib.mi_fused_add_rms_norm_splitk(
+        _p(out), _p(p.part), p.split, _p(p.bias), _p(r2), _p(weight), float(eps), p.m, p.n, out.stride(0), r2.stride(0),
+        _dt(p.dtype), _stream()))
+    return out.view(*p.lead, p.n)
 
 
 def linear_silu_mul(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:

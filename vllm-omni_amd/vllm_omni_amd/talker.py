@@ -113,12 +113,14 @@ class Qwen2MLP:
         self.down_proj._is_down_proj = True   # VLLM_OMNI_AMD_LINEAR=mlp (policy experiments): both MLP GEMMs on the kernel
         self.act_fn = SiluAndMul()
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, defer_reduce: bool = False):
+        """``defer_reduce``: the caller feeds the result to a fused-add RMSNorm, which may then also do down_proj's
+        split-K reduce (the result is an ``ops.SplitKPartials`` in that case)."""
         act = fused_gate_up_silu(self.gate_up_proj, x)   # one launch where the streaming kernel wins (layers.py)
         if act is None:
             gate_up, _ = self.gate_up_proj(x)
             act = self.act_fn(gate_up)
-        x, _ = self.down_proj(act)
+        x, _ = self.down_proj(act, defer_reduce)
         return x
 
 
@@ -181,7 +183,10 @@ class Qwen2DecoderLayer:
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
 
-    def __call__(self, positions, hidden_states, residual):
+    def __call__(self, positions, hidden_states, residual, defer_reduce: bool = False):
+        """``defer_reduce``: the caller promises to hand the returned hidden states to a fused-add RMSNorm (the next
+        layer's input_layernorm or the final norm); the dense MLP may then return its down_proj as split-K partials
+        for that norm to reduce (``ops.SplitKPartials``) — one launch and one round trip of [T, H] less per layer."""
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
@@ -189,7 +194,10 @@ class Qwen2DecoderLayer:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states)
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-        hidden_states = self.mlp(hidden_states)
+        if defer_reduce and isinstance(self.mlp, Qwen2MLP):
+            hidden_states = self.mlp(hidden_states, True)
+        else:
+            hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
 
@@ -209,7 +217,7 @@ class Qwen2Model:
         hidden_states = inputs_embeds if inputs_embeds is not None else self.embed_input_ids(input_ids)
         residual = None
         for layer in self.layers:
-            hidden_states, residual = layer(positions, hidden_states, residual)
+            hidden_states, residual = layer(positions, hidden_states, residual, True)   # every output meets a fused norm
         hidden_states, _ = self.norm(hidden_states, residual)
         return hidden_states
 
