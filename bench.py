@@ -94,8 +94,8 @@ def plan_label(tp: int, dp: int) -> str:
 # Per-rank step time (ms) of every (tp, dp) plan at the headline shape, measured on ONE MI355X with the
 # collectives stubbed (`bench.py --simulate-shard TP,DP`, profiles/r01_scaling_estimate.md).  Decode sequences are
 # independent, so data parallelism needs no collective; tensor parallelism adds 2 all-reduces per layer.
-COMPUTE_MS = {(1, 1): 15.59, (2, 1): 9.42, (1, 2): 9.51, (4, 1): 6.20, (2, 2): 6.44, (1, 4): 6.66,
-              (4, 2): 4.41, (2, 4): 4.47, (1, 8): 4.95}
+COMPUTE_MS = {(1, 1): 15.35, (2, 1): 9.48, (1, 2): 9.34, (4, 1): 6.16, (2, 2): 6.41, (1, 4): 6.59,
+              (4, 2): 4.42, (2, 4): 4.39, (1, 8): 4.86}
 
 
 def choose_plan(world: int, rank: int, cfg, a, dev, probe: bool = True, backend: str = "nccl"):

@@ -139,6 +139,7 @@ class Qwen2Attention:
         self.scaling = self.head_dim ** -0.5
         self.o_proj = RowParallelLinear(self.total_num_heads * self.head_dim, cfg.hidden_size, bias=False,
                                         dtype=dtype, device=device, generator=generator)
+        self.o_proj._is_o_proj = True   # VLLM_OMNI_AMD_LINEAR=mlp+o (policy experiments)
         rp = {"base": cfg.rope_theta}
         if cfg.mrope_section:
             rp["mrope_section"] = cfg.mrope_section
@@ -152,7 +153,7 @@ class Qwen2Attention:
             self.q_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps, dtype, device)
             self.k_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps, dtype, device)
 
-    def __call__(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
+    def __call__(self, positions: torch.Tensor, hidden_states: torch.Tensor, defer_reduce: bool = False):
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         # rotary_pos_emb(positions, q, k) + attn(q, k, v) of qwen2_old.py:153-154, fused:
@@ -161,7 +162,7 @@ class Qwen2Attention:
             self.rotary_pos_emb, positions, q, k, v,
             q_norm_weight=self.q_norm.weight if self.q_norm else None,
             k_norm_weight=self.k_norm.weight if self.k_norm else None, norm_eps=self.norm_eps)
-        output, _ = self.o_proj(attn_output)
+        output, _ = self.o_proj(attn_output, defer_reduce)   # may be split-K partials for the norm behind (layers.py)
         return output
 
 
@@ -192,7 +193,8 @@ class Qwen2DecoderLayer:
             hidden_states = self.input_layernorm(hidden_states)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states)
+        # o_proj always meets the fused-add post_attention_layernorm: its split-K reduce (if any) may go there
+        hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states, defer_reduce=True)
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         if defer_reduce and isinstance(self.mlp, Qwen2MLP):
             hidden_states = self.mlp(hidden_states, True)
