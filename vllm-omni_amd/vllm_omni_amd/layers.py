@@ -288,7 +288,8 @@ def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
 def _deferred_kernel_wins(m: int, n: int, k: int) -> bool:
     # square-ish projections (o_proj 3584 x 3584) when the split-K reduce rides in the fused-add RMSNorm behind them:
     # level with the library at 256 rows, 1-1.5 % of the step ahead at 32-128 rows (same measurements)
-    return m <= 256 and k >= 2048 and k >= n
+    # (not small ones: the code predictor's 1024 x 2048 o_proj ran 5 % slower per call on the kernel)
+    return m <= 256 and k >= n and n * k >= (1 << 23)
 
 
 def _fused_gate_up_wins(m: int, inter: int, k: int) -> bool:
