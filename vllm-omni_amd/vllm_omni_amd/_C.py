@@ -86,6 +86,11 @@ SIGNATURES = {
 
 
 def _load() -> ctypes.CDLL:
+    # torch first: its wheel carries its own libamdhip64, and the process must end up with ONE HIP runtime — if this
+    # library were loaded before torch it would pull in /opt/rocm's copy, and kernels registered with that runtime
+    # fail to launch on torch's streams ("HIP kernel launch failed"; seen with build() + smoke() in one process)
+    import torch  # noqa: F401
+
     if not os.path.exists(_LIB_PATH):
         raise ImportError(
             f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
