@@ -90,6 +90,23 @@ int mi_rope_neox_and_cache(void* q, void* k, const void* v, const int64_t* posit
                            int64_t k_token_stride, int64_t v_token_stride,
                            int64_t cache_block_stride, int64_t cache_token_stride,
                            int64_t cache_head_stride, int dtype, void* stream);
+/* The same op fed by the fp32 split-K partials [split][T][(nq + 2 nkv) * head_dim]
+ * of qkv_proj (mi_linear_partials) instead of 16-bit q / k / v: a value is
+ * rnd(sum over slices in order (+ qkv_bias)) — what mi_linear_reduce would have
+ * stored — so results equal mi_linear + mi_rope_neox_and_cache bit for bit, one
+ * launch and one round trip of the qkv row less.  q_out [T, q_token_stride]
+ * receives the rotated queries; k and v go to the cache only (required). */
+int mi_rope_neox_and_cache_splitk(void* q_out, const void* partials, int32_t split,
+                                  const void* qkv_bias, const int64_t* positions,
+                                  int64_t positions_row_stride, const int32_t* mrope_section,
+                                  const float* cos_sin_cache, int32_t max_position,
+                                  int32_t rot_dim, const void* q_norm_weight,
+                                  const void* k_norm_weight, float norm_eps, void* k_cache,
+                                  void* v_cache, const int64_t* slot_mapping, int32_t num_tokens,
+                                  int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                  int32_t block_size, int64_t q_token_stride,
+                                  int64_t cache_block_stride, int64_t cache_token_stride,
+                                  int64_t cache_head_stride, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * A5 — paged-attention decode (q_len == 1).

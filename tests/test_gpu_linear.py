@@ -190,3 +190,41 @@ def test_linear_partials_none_without_split():
     x = torch.zeros(256, 3584, device="cuda", dtype=torch.bfloat16)
     w = torch.zeros(37888, 3584, device="cuda", dtype=torch.bfloat16)
     assert ops.linear_partials(x, w) is None      # 237 tiles fill the chip: no split-K, nothing to defer
+
+
+@pytest.mark.parametrize("mrope,qk_norm,bias", [(False, False, True), (True, False, True), (False, True, False)])
+def test_rope_and_cache_from_qkv_partials_is_bit_identical(mrope, qk_norm, bias):
+    """qkv_proj's split-K partials straight into the fused RoPE + KV-write kernel == linear -> rope_neox_and_cache:
+    rotated q, K cache and V cache bit for bit (plain RoPE, M-RoPE, q/k-norm; with and without bias)."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.layers import build_cos_sin_cache
+    T, nq, nkv, d, hid, bs, nb = 48, 28, 4, 128, 3584, 16, 12
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(T, hid, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn((nq + 2 * nkv) * d, hid, device="cuda", generator=g) * hid ** -0.5).to(torch.bfloat16)
+    b = torch.randn((nq + 2 * nkv) * d, device="cuda", generator=g).to(torch.bfloat16) if bias else None
+    csc = build_cos_sin_cache(d, 4096, 1e6, device="cuda")
+    pos = torch.randint(0, 4096, (3, T) if mrope else (T,), device="cuda", generator=g)
+    sec = torch.tensor([16, 24, 24], dtype=torch.int32) if mrope else None
+    qn = (1 + 0.1 * torch.randn(d, device="cuda", generator=g)).to(torch.bfloat16) if qk_norm else None
+    kn = (1 + 0.1 * torch.randn(d, device="cuda", generator=g)).to(torch.bfloat16) if qk_norm else None
+    slots = torch.randperm(nb * bs, device="cuda", generator=g)[:T].to(torch.int64)
+    slots[5] = -1                                            # a padding token: no cache write
+    caches = []
+    for _ in range(2):
+        kc = torch.zeros(nb, bs, nkv, d, device="cuda", dtype=torch.bfloat16)
+        vc = torch.zeros_like(kc)
+        caches.append((kc, vc))
+    # the two-launch form
+    qkv = ops.linear(x, w, b)
+    q, k, v = qkv.split([nq * d, nkv * d, nkv * d], dim=-1)
+    ops.rope_neox_and_cache(q, k, v, pos, csc, d, caches[0][0], caches[0][1], slots, mrope_section=sec,
+                            q_norm_weight=qn, k_norm_weight=kn)
+    # partials straight into the kernel
+    part = ops.linear_partials(x, w, b)
+    assert part is not None
+    q2 = ops.rope_neox_and_cache_splitk(part, nq, nkv, d, pos, csc, caches[1][0], caches[1][1], slots, mrope_section=sec,
+                                        q_norm_weight=qn, k_norm_weight=kn)
+    assert torch.equal(q2, q.contiguous())
+    assert torch.equal(caches[1][0], caches[0][0]) and torch.equal(caches[1][1], caches[0][1])
+    assert caches[0][0].abs().sum() > 0

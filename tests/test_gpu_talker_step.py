@@ -70,6 +70,15 @@ def test_decode_steps_match_oracle(dev, enforce_eager, quant, linear_mode, monke
     monkeypatch.setattr(ops, "linear", lambda *a, **k: (kernel_calls.append(1), real_linear(*a, **k))[1])
     real_fused = ops.linear_silu_mul
     monkeypatch.setattr(ops, "linear_silu_mul", lambda *a, **k: (kernel_calls.append(1), real_fused(*a, **k))[1])
+    real_part = ops.linear_partials   # o_proj / down_proj (/ qkv_proj) whose split-K reduce rides in the next kernel
+
+    def counted_partials(*a, **k):
+        r = real_part(*a, **k)
+        if r is not None:
+            kernel_calls.append(1)
+        return r
+
+    monkeypatch.setattr(ops, "linear_partials", counted_partials)
 
     ctxs = [5, 16, 40, 1]
     # decode positions are 1-D (all three M-RoPE rows equal at decode => plain RoPE)

@@ -57,6 +57,13 @@ struct RopeParams {
   const int64_t* slot_mapping;
   int32_t num_q_heads, num_kv_heads, head_dim, block_size;
   int64_t q_tok, k_tok, v_tok, c_blk, c_tok, c_head;
+  // PART: q/k/v come as the fp32 split-K partials [S][T][part_row] of qkv_proj (skinny_gemm.hip) instead of 16-bit
+  // tensors; a value = rnd(sum over slices in order (+ bias)), the reduce kernel's arithmetic.  q is written to p.q
+  // (a fresh [T, q_tok] tensor), k and v only to the cache.
+  const float* part;
+  const uint16_t* qkv_bias;
+  int32_t S, part_T;
+  int64_t part_row;
 };
 
 template <typename Tag>
@@ -76,7 +83,7 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 
 // One workgroup per token.  A rotate-item = one thread = dims [8j, 8j+8) and their
 // rotate-half partners [rot/2 + 8j, rot/2 + 8j + 8) of one head.
-template <typename Tag, bool MROPE, bool NORM>
+template <typename Tag, bool MROPE, bool NORM, bool PART = false>
 __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -104,25 +111,65 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
   };
   pos0 = clampp(pos0); pos1 = clampp(pos1); pos2 = clampp(pos2);
 
+  // 8 consecutive values of this token's qkv row starting at column `col`, as 16-bit words
+  auto from_partials = [&](int col) -> uint4 {
+    const float* p0 = p.part + (int64_t)t * p.part_row + col;
+    float4 vl[16], vh[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      if (s < p.S) {
+        const float* ps = p0 + (int64_t)s * p.part_T * p.part_row;
+        vl[s] = *reinterpret_cast<const float4*>(ps);
+        vh[s] = *reinterpret_cast<const float4*>(ps + 4);
+      }
+    float4 lo = vl[0], hi = vh[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s)
+      if (s < p.S) {
+        lo.x += vl[s].x; lo.y += vl[s].y; lo.z += vl[s].z; lo.w += vl[s].w;
+        hi.x += vh[s].x; hi.y += vh[s].y; hi.z += vh[s].z; hi.w += vh[s].w;
+      }
+    if (p.qkv_bias) {
+      const uint4 bv = *reinterpret_cast<const uint4*>(p.qkv_bias + col);
+      lo.x += E::lo(bv.x); lo.y += E::hi(bv.x); lo.z += E::lo(bv.y); lo.w += E::hi(bv.y);
+      hi.x += E::lo(bv.z); hi.y += E::hi(bv.z); hi.z += E::lo(bv.w); hi.w += E::hi(bv.w);
+    }
+    return make_uint4(E::pack(lo.x, lo.y), E::pack(lo.z, lo.w), E::pack(hi.x, hi.y), E::pack(hi.z, hi.w));
+  };
+
   for (int it = threadIdx.x; it < n_heads * iph; it += blockDim.x) {
     const int head = it / iph;
     const int j = it % iph;
     const bool is_q = head < p.num_q_heads;
     const int hh = is_q ? head : head - p.num_q_heads;
-    uint16_t* base = is_q ? p.q + t * p.q_tok + (int64_t)hh * HD : p.k + t * p.k_tok + (int64_t)hh * HD;
+    uint16_t* base = is_q ? p.q + t * p.q_tok + (int64_t)hh * HD
+                          : (PART ? nullptr : p.k + t * p.k_tok + (int64_t)hh * HD);   // PART: k lives only in the cache
+    const int col0 = head * HD;   // column of this head in the qkv row: q heads, then k heads (then v heads)
     uint16_t* cdst = (!is_q && slot >= 0)
                          ? p.kc + cblk * p.c_blk + coff * p.c_tok + (int64_t)hh * p.c_head
                          : nullptr;
     if (j >= rot_items) {  // pass-through dims (partial rotary): only the cache copy
+      if (PART && is_q) {    // ... and, from partials, q's own un-rotated tail
+        const int d = p.rot_dim + (j - rot_items) * 8;
+        *reinterpret_cast<uint4*>(base + d) = from_partials(col0 + d);
+      }
       if (cdst) {
         const int d = p.rot_dim + (j - rot_items) * 8;
-        *reinterpret_cast<uint4*>(cdst + d) = *reinterpret_cast<const uint4*>(base + d);
+        uint4 tail;
+        if constexpr (PART) tail = from_partials(col0 + d);
+        else tail = *reinterpret_cast<const uint4*>(base + d);
+        *reinterpret_cast<uint4*>(cdst + d) = tail;
       }
       continue;
     }
     float x[8], y[8];
-    unpack8<Tag>(*reinterpret_cast<const uint4*>(base + 8 * j), x);
-    unpack8<Tag>(*reinterpret_cast<const uint4*>(base + half + 8 * j), y);
+    if constexpr (PART) {
+      unpack8<Tag>(from_partials(col0 + 8 * j), x);
+      unpack8<Tag>(from_partials(col0 + half + 8 * j), y);
+    } else {
+      unpack8<Tag>(*reinterpret_cast<const uint4*>(base + 8 * j), x);
+      unpack8<Tag>(*reinterpret_cast<const uint4*>(base + half + 8 * j), y);
+    }
 
     if constexpr (NORM) {
       // RMSNorm over head_dim (host guarantees rot_dim == head_dim, iph in {4,8}):
@@ -173,8 +220,10 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
       oy[e] = y[e] * cs[e] + x[e] * sn[e];
     }
     const uint4 rx = pack8<Tag>(ox), ry = pack8<Tag>(oy);
-    *reinterpret_cast<uint4*>(base + 8 * j) = rx;
-    *reinterpret_cast<uint4*>(base + half + 8 * j) = ry;
+    if (base) {
+      *reinterpret_cast<uint4*>(base + 8 * j) = rx;
+      *reinterpret_cast<uint4*>(base + half + 8 * j) = ry;
+    }
     if (cdst) {
       *reinterpret_cast<uint4*>(cdst + 8 * j) = rx;
       *reinterpret_cast<uint4*>(cdst + half + 8 * j) = ry;
@@ -186,8 +235,10 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
     const int per_head = HD / 8;
     for (int i = threadIdx.x; i < p.num_kv_heads * per_head; i += blockDim.x) {
       const int h = i / per_head, d = (i % per_head) * 8;
-      *reinterpret_cast<uint4*>(p.vc + cblk * p.c_blk + coff * p.c_tok + (int64_t)h * p.c_head + d) =
-          *reinterpret_cast<const uint4*>(p.v + t * p.v_tok + (int64_t)h * HD + d);
+      uint4 vv;
+      if constexpr (PART) vv = from_partials((p.num_q_heads + p.num_kv_heads + h) * HD + d);
+      else vv = *reinterpret_cast<const uint4*>(p.v + t * p.v_tok + (int64_t)h * HD + d);
+      *reinterpret_cast<uint4*>(p.vc + cblk * p.c_blk + coff * p.c_tok + (int64_t)h * p.c_head + d) = vv;
     }
   }
 }
@@ -195,6 +246,13 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
 template <typename Tag>
 int launch_rope(const RopeParams& p, bool mrope, bool norm, int num_tokens, hipStream_t s) {
   const dim3 grid(num_tokens), block(256);
+  if (p.part) {
+    if (mrope && norm) hipLaunchKernelGGL((rope_cache_kernel<Tag, true, true, true>), grid, block, 0, s, p);
+    else if (mrope) hipLaunchKernelGGL((rope_cache_kernel<Tag, true, false, true>), grid, block, 0, s, p);
+    else if (norm) hipLaunchKernelGGL((rope_cache_kernel<Tag, false, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((rope_cache_kernel<Tag, false, false, true>), grid, block, 0, s, p);
+    return launch_status();
+  }
   if (mrope && norm) hipLaunchKernelGGL((rope_cache_kernel<Tag, true, true>), grid, block, 0, s, p);
   else if (mrope) hipLaunchKernelGGL((rope_cache_kernel<Tag, true, false>), grid, block, 0, s, p);
   else if (norm) hipLaunchKernelGGL((rope_cache_kernel<Tag, false, true>), grid, block, 0, s, p);
@@ -300,6 +358,80 @@ extern "C" int mi_rope_neox_and_cache(
   p.c_blk = cache_block_stride;
   p.c_tok = cache_token_stride;
   p.c_head = cache_head_stride;
+  p.part = nullptr;
+  p.qkv_bias = nullptr;
+  p.S = 0;
+  p.part_T = 0;
+  p.part_row = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MI_DTYPE_BF16)
+    return launch_rope<bf16_tag>(p, mrope_section != nullptr, norm, num_tokens, s);
+  return launch_rope<f16_tag>(p, mrope_section != nullptr, norm, num_tokens, s);
+}
+
+extern "C" int mi_rope_neox_and_cache_splitk(
+    void* q_out, const void* partials, int32_t split, const void* qkv_bias, const int64_t* positions,
+    int64_t positions_row_stride, const int32_t* mrope_section, const float* cos_sin_cache, int32_t max_position,
+    int32_t rot_dim, const void* q_norm_weight, const void* k_norm_weight, float norm_eps, void* k_cache,
+    void* v_cache, const int64_t* slot_mapping, int32_t num_tokens, int32_t num_q_heads, int32_t num_kv_heads,
+    int32_t head_dim, int32_t block_size, int64_t q_token_stride, int64_t cache_block_stride,
+    int64_t cache_token_stride, int64_t cache_head_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!q_out || !partials || !positions || !cos_sin_cache || !k_cache || !v_cache || !slot_mapping)
+    return MI_ERR_INVALID_ARG;
+  if (num_tokens < 0 || num_q_heads <= 0 || num_kv_heads <= 0 || max_position <= 0 || block_size <= 0 || split < 1 ||
+      split > 16)
+    return MI_ERR_INVALID_ARG;
+  if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
+  if (head_dim % 8 || rot_dim % 16 || rot_dim <= 0 || rot_dim > head_dim) return MI_ERR_UNSUPPORTED;
+  if (q_token_stride % 8 || cache_block_stride % 8 || cache_token_stride % 8 || cache_head_stride % 8)
+    return MI_ERR_INVALID_ARG;
+  if (((uintptr_t)q_out | (uintptr_t)partials | (uintptr_t)cos_sin_cache | (uintptr_t)k_cache | (uintptr_t)v_cache |
+       (uintptr_t)qkv_bias) & 15)
+    return MI_ERR_INVALID_ARG;
+  const bool norm = q_norm_weight != nullptr || k_norm_weight != nullptr;
+  if (norm) {
+    if (!q_norm_weight || !k_norm_weight) return MI_ERR_INVALID_ARG;
+    if (rot_dim != head_dim || (head_dim != 64 && head_dim != 128)) return MI_ERR_UNSUPPORTED;
+  }
+  RopeParams p;
+  p.q = reinterpret_cast<uint16_t*>(q_out);
+  p.k = nullptr;
+  p.v = nullptr;
+  p.positions = positions;
+  p.pos_row_stride = positions_row_stride;
+  p.sec0 = 0;
+  p.sec01 = 0;
+  if (mrope_section) {
+    if (mrope_section[0] + mrope_section[1] + mrope_section[2] != rot_dim / 2) return MI_ERR_INVALID_ARG;
+    p.sec0 = mrope_section[0];
+    p.sec01 = mrope_section[0] + mrope_section[1];
+  }
+  p.cos_sin = cos_sin_cache;
+  p.max_position = max_position;
+  p.rot_dim = rot_dim;
+  p.q_norm_w = reinterpret_cast<const uint16_t*>(q_norm_weight);
+  p.k_norm_w = reinterpret_cast<const uint16_t*>(k_norm_weight);
+  p.eps = norm_eps;
+  p.kc = reinterpret_cast<uint16_t*>(k_cache);
+  p.vc = reinterpret_cast<uint16_t*>(v_cache);
+  p.slot_mapping = slot_mapping;
+  p.num_q_heads = num_q_heads;
+  p.num_kv_heads = num_kv_heads;
+  p.head_dim = head_dim;
+  p.block_size = block_size;
+  p.q_tok = q_token_stride;
+  p.k_tok = 0;
+  p.v_tok = 0;
+  p.c_blk = cache_block_stride;
+  p.c_tok = cache_token_stride;
+  p.c_head = cache_head_stride;
+  p.part = reinterpret_cast<const float*>(partials);
+  p.qkv_bias = reinterpret_cast<const uint16_t*>(qkv_bias);
+  p.S = split;
+  p.part_T = num_tokens;
+  p.part_row = (int64_t)(num_q_heads + 2 * num_kv_heads) * head_dim;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == MI_DTYPE_BF16)
     return launch_rope<bf16_tag>(p, mrope_section != nullptr, norm, num_tokens, s);

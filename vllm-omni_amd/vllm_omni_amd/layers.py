@@ -244,6 +244,17 @@ class Attention:
                                 k_norm_weight=k_norm_weight, norm_eps=norm_eps)
         return self._attend(q, md, out)
 
+    def forward_fused_rope_partials(self, rope: RotaryEmbedding, positions: torch.Tensor, qkv: "ops.SplitKPartials",
+                                    q_norm_weight=None, k_norm_weight=None, norm_eps: float = 1e-6) -> torch.Tensor:
+        """``forward_fused_rope`` when qkv_proj handed over split-K partials: their reduction (+ bias) happens inside
+        the RoPE + KV-write launch; same result bit for bit."""
+        md = get_forward_context().attn_metadata
+        q = ops.rope_neox_and_cache_splitk(qkv, self.num_heads, self.num_kv_heads, self.head_size, positions,
+                                           rope.cos_sin_cache, self._kb, self._vb, md.slot_mapping,
+                                           mrope_section=rope._section(positions), q_norm_weight=q_norm_weight,
+                                           k_norm_weight=k_norm_weight, norm_eps=norm_eps)
+        return self._attend(q, md, torch.empty_like(q))
+
 
 # --------------------------------------------------------------------------- linears
 def _init_weight(out_f: int, in_f: int, dtype, device, generator=None, std: float = 0.02) -> torch.Tensor:
@@ -259,6 +270,10 @@ def _init_weight(out_f: int, in_f: int, dtype, device, generator=None, std: floa
 # MLP pair only (policy experiments).
 _LINEAR_MODE = os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
 _DEFER_REDUCE = os.environ.get("VLLM_OMNI_AMD_DEFER_REDUCE", "1") != "0"   # split-K reduce inside the next RMSNorm
+# ... and qkv_proj's inside the RoPE + KV-write kernel (mi_rope_neox_and_cache_splitk): bit-identical and tested, but
+# level with the library GEMM at every batch size measured (15.14 vs 15.15 ms/step at 256 rows, 4.79 vs 4.80 at 32),
+# so it is off unless asked for
+_DEFER_QKV = os.environ.get("VLLM_OMNI_AMD_DEFER_QKV", "0") == "1"
 
 
 def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
@@ -292,6 +307,11 @@ def _deferred_kernel_wins(m: int, n: int, k: int) -> bool:
     return m <= 256 and k >= n and n * k >= (1 << 23)
 
 
+def _deferred_qkv_wins(m: int, n: int, k: int) -> bool:
+    # qkv_proj (4608 x 3584) with its split-K reduce (+ bias) inside the fused RoPE + KV-write kernel behind it
+    return m <= 256 and n * k >= (1 << 23) and _DEFER_QKV
+
+
 def _fused_gate_up_wins(m: int, inter: int, k: int) -> bool:
     # same measurements: ahead at I 18944 and 9472 per rank (>= ~120 tiles in one launch), not at 4736
     return m <= 256 and inter >= 8192
@@ -311,7 +331,8 @@ def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_re
             wins = (_LINEAR_MODE == "kernel" or _streaming_kernel_wins(m, n, k)
                     or (_LINEAR_MODE in ("mlp", "mlp+o") and getattr(layer, "_is_down_proj", False))
                     or (_LINEAR_MODE == "mlp+o" and getattr(layer, "_is_o_proj", False)))
-            if defer_reduce and _DEFER_REDUCE and (wins or _deferred_kernel_wins(m, n, k)):
+            if defer_reduce and _DEFER_REDUCE and (
+                    wins or (_deferred_qkv_wins(m, n, k) if defer_reduce == "rope" else _deferred_kernel_wins(m, n, k))):
                 part = ops.linear_partials(x, w, bias)
                 if part is not None:
                     return part
@@ -345,8 +366,10 @@ class ColumnParallelLinear:
         self.weight = _init_weight(self.output_size_per_partition, input_size, dtype, device, generator)
         self.bias = torch.zeros(self.output_size_per_partition, dtype=dtype, device=device) if bias else None
 
-    def __call__(self, x: torch.Tensor):
-        y = _apply_linear(self, x, self.bias)
+    def __call__(self, x: torch.Tensor, defer_reduce=False):
+        """``defer_reduce="rope"`` (qkv_proj): the caller runs the fused RoPE + KV-write kernel next, which can take the
+        split-K partials of the streaming kernel directly (``ops.rope_neox_and_cache_splitk``)."""
+        y = _apply_linear(self, x, self.bias, defer_reduce if not self.gather_output else False)
         if self.gather_output:
             y = tensor_model_parallel_all_gather(y)
         return y, None

@@ -416,6 +416,40 @@ def fused_add_rms_norm_splitk(p: SplitKPartials, residual: torch.Tensor, weight:
     return out.view(*p.lead, p.n)
 
 
+def rope_neox_and_cache_splitk(part: SplitKPartials, num_q_heads: int, num_kv_heads: int, head_dim: int,
+                               positions: torch.Tensor, cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
+                               v_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                               mrope_section: Optional[torch.Tensor] = None,
+                               q_norm_weight: Optional[torch.Tensor] = None,
+                               k_norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 1e-6) -> torch.Tensor:
+    """``rope_neox_and_cache`` fed by the split-K partials of ``qkv_proj`` (``linear_partials``): returns the rotated
+    q [T, nq*d]; k and v go to the cache only.  Bit-identical to ``linear`` + ``rope_neox_and_cache``."""
+    _gpu(positions, cos_sin_cache, k_cache, v_cache, slot_mapping, q_norm_weight, k_norm_weight)
+    part._live()
+    if part.n != (num_q_heads + 2 * num_kv_heads) * head_dim:
+        raise ValueError("partials row is not [q heads | k heads | v heads]")
+    if positions.dtype != torch.int64 or cos_sin_cache.dtype != torch.float32 or slot_mapping.dtype != torch.int64:
+        raise TypeError("positions / slot_mapping must be int64 and cos_sin_cache float32")
+    max_pos, rot_dim = cos_sin_cache.shape
+    sec = None
+    row_stride = 0
+    if positions.dim() == 2:
+        if mrope_section is None:
+            raise ValueError("positions is [3, T]: mrope_section required")
+        sec = (ctypes.c_int32 * 3)(*[int(x) for x in mrope_section])
+        row_stride = positions.stride(0)
+        if positions.stride(1) != 1:
+            raise ValueError("positions rows must be contiguous")
+    cb, ct, ch = _cache_strides(k_cache, v_cache)
+    q_out = torch.empty(part.m, num_q_heads * head_dim, dtype=part.dtype, device=part.device)
+    check("mi_rope_neox_and_cache_splitk", lib.mi_rope_neox_and_cache_splitk(
+        _p(q_out), _p(part.part), part.split, _p(part.bias), _p(positions), row_stride,
+        ctypes.cast(sec, ctypes.c_void_p) if sec is not None else None, _p(cos_sin_cache), max_pos, rot_dim,
+        _p(q_norm_weight), _p(k_norm_weight), float(norm_eps), _p(k_cache), _p(v_cache), _p(slot_mapping), part.m,
+        num_q_heads, num_kv_heads, head_dim, k_cache.shape[1], q_out.stride(0), cb, ct, ch, _dt(part.dtype), _stream()))
+    return q_out
+
+
 def linear_silu_mul(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """silu(x Wg^T) * (x Wu^T) for a decode batch, weight = [gate rows; up rows] — ``gate_up_proj`` and the
     ``SiluAndMul`` behind it (qwen2_old.py:62-66) in one launch; the [m, 2 I] intermediate never reaches memory."""

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from . import ops
 from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size
 from .layers import (Attention, MergedColumnParallelLinear, QKVParallelLinear, RMSNorm, RowParallelLinear,
-                     SiluAndMul, _init_weight, fused_gate_up_silu, get_rope, shard_column, shard_merged_column,
+                     SiluAndMul, _init_weight, fused_gate_up_silu, get_forward_context, get_rope, shard_column, shard_merged_column,
                      shard_qkv, shard_row)
 from .distributed import tensor_model_parallel_all_gather
 
@@ -154,7 +154,15 @@ class Qwen2Attention:
             self.k_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps, dtype, device)
 
     def __call__(self, positions: torch.Tensor, hidden_states: torch.Tensor, defer_reduce: bool = False):
-        qkv, _ = self.qkv_proj(hidden_states)
+        has_cache = get_forward_context().attn_metadata is not None
+        qkv, _ = self.qkv_proj(hidden_states, "rope" if has_cache else False)
+        if isinstance(qkv, ops.SplitKPartials):   # split-K reduce + bias inside the RoPE + KV-write launch (layers.py)
+            attn_output = self.attn.forward_fused_rope_partials(
+                self.rotary_pos_emb, positions, qkv,
+                q_norm_weight=self.q_norm.weight if self.q_norm else None,
+                k_norm_weight=self.k_norm.weight if self.k_norm else None, norm_eps=self.norm_eps)
+            output, _ = self.o_proj(attn_output, defer_reduce)
+            return output
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         # rotary_pos_emb(positions, q, k) + attn(q, k, v) of qwen2_old.py:153-154, fused:
         # (q/k-norm ->) RoPE -> KV write in one launch, then paged attention.
