@@ -417,7 +417,11 @@ def main():
                    "global_batch": a.batch, "seq_len": a.ctx, "parallelism": plabel,
                    "hipgraph": bool(runner._graphs), "kv_layout": a.kv_layout,
                    "output": "sync" if a.sync_output else "pipelined one step behind (all outputs on the host inside the timed region)",
-                   "decode_partition": runner._decode_part, **({"plan_choice": plan_info} if plan_info else {})},
+                   "decode_partition": runner._decode_part,
+                   "linear": os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
+                   + " (auto: hand-written streaming GEMM where measured faster than the TunableOp-selected library "
+                     "kernel, library GEMM elsewhere; same bf16 inputs, fp32 accumulation)",
+                   **({"plan_choice": plan_info} if plan_info else {})},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
