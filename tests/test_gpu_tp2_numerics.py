@@ -22,12 +22,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_step(tp_rank, tp_size, port, out_path, q):
+def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto"):
     import sys
     for p in (ROOT, os.path.join(ROOT, "vllm-omni_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["VLLM_OMNI_AMD_TP_GRAPH"] = "0"
+    os.environ["VLLM_OMNI_AMD_LINEAR"] = linear_mode   # read when vllm_omni_amd.layers is imported (below)
     try:
         import numpy as np
         from oracle import ref_talker
@@ -88,7 +89,11 @@ def _run_step(tp_rank, tp_size, port, out_path, q):
 
 
 @pytest.mark.timeout(300)
-def test_tp2_matches_tp1(dev):
+@pytest.mark.parametrize("linear_mode", ["auto", "kernel"])
+def test_tp2_matches_tp1(dev, linear_mode):
+    """linear_mode="kernel": every projection on the streaming GEMM — sharded [gate; up] weights through the fused
+    gate_up + SiLU kernel, row-parallel shards with and without the deferred split-K reduce (TP 1 defers, TP 2 must
+    materialise before the all-reduce)."""
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as tmp:
         results = {}
@@ -96,7 +101,7 @@ def test_tp2_matches_tp1(dev):
             q = ctx.Queue()
             port = _free_port()
             path = os.path.join(tmp, f"tp{tp}.pt")
-            procs = [ctx.Process(target=_run_step, args=(r, tp, port, path, q)) for r in range(tp)]
+            procs = [ctx.Process(target=_run_step, args=(r, tp, port, path, q, linear_mode)) for r in range(tp)]
             for p in procs:
                 p.start()
             res = [q.get(timeout=240) for _ in procs]
