@@ -228,3 +228,35 @@ def test_rope_and_cache_from_qkv_partials_is_bit_identical(mrope, qk_norm, bias)
     assert torch.equal(q2, q.contiguous())
     assert torch.equal(caches[1][0], caches[0][0]) and torch.equal(caches[1][1], caches[0][1])
     assert caches[0][0].abs().sum() > 0
+
+
+def test_linear_random_shapes_fuzz():
+    """Random (m, n, k) across every template variant of the kernel (m-tile counts 4/8/16, 128- and 160-row tiles,
+    split-K factors 1-16, tiles hanging over n, ragged m), plain and gated, against float64 references."""
+    from vllm_omni_amd import ops
+    rng = torch.Generator().manual_seed(2024)
+    g = torch.Generator(device="cuda").manual_seed(77)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng))
+
+    for case in range(40):
+        m = ri(1, 256)
+        k = 64 * ri(1, 40)
+        n = 16 * ri(1, 300) if case % 4 else 160 * ri(129, 200)   # every 4th: the 160-row-tile plan
+        x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+        b = torch.randn(n, device="cuda", generator=g).to(torch.bfloat16) if case % 2 else None
+        y = ops.linear(x, w, b)
+        ref = x.double() @ w.double().t() + (b.double() if b is not None else 0)
+        tol = ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().amax(dim=1, keepdim=True).clamp_min(1.0)
+        assert bool(((y.double() - ref).abs() <= tol).all()), (case, m, n, k)
+        if n % 32 == 0:
+            inter = n // 2
+            z = ops.linear_silu_mul(x, w)
+            gu = (x.double() @ w.double().t()).to(torch.bfloat16).float()
+            gt, up = gu[:, :inter], gu[:, inter:]
+            act = gt / (1.0 + torch.exp(-gt))
+            zr = act * up
+            ztol = zr.abs() * 2.0 ** -8 + (up.abs() * 1.1 * gt.abs() + act.abs() * up.abs()) * 2.0 ** -8 + 1e-3
+            assert bool(((z.float() - zr).abs() <= ztol).all()), ("gated", case, m, inter, k)
