@@ -28,6 +28,9 @@
 #ifndef MI_SKINNY_NL5
 #define MI_SKINNY_NL5 2          // loader waves of the 160-row tile (10 consumer waves)
 #endif
+#ifndef MI_SKINNY_MH8
+#define MI_SKINNY_MH8 2          // consumer waves per slab at 65-128 rows (8 m-tiles)
+#endif
 #ifndef MI_SKINNY_LOADER_PRIO
 #define MI_SKINNY_LOADER_PRIO 3  // s_setprio of the loader waves (their issue slots come before the consumers')
 #endif
@@ -360,11 +363,11 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
   do {                                                       \
     if (pl.nslab == 5) {                                     \
       if (pl.mt == 16) MI_SKINNY(TAG, 5, 16, 2, MI_SKINNY_NL5, GATED);   \
-      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, 2, MI_SKINNY_NL5, GATED);\
+      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, MI_SKINNY_MH8, MI_SKINNY_NL5, GATED);\
       else MI_SKINNY(TAG, 5, 4, 1, MI_SKINNY_NL5, GATED);                \
     } else {                                                 \
       if (pl.mt == 16) MI_SKINNY(TAG, 4, 16, 2, 4, GATED);   \
-      else if (pl.mt == 8) MI_SKINNY(TAG, 4, 8, 2, 4, GATED);\
+      else if (pl.mt == 8) MI_SKINNY(TAG, 4, 8, MI_SKINNY_MH8, 4, GATED);\
       else MI_SKINNY(TAG, 4, 4, 1, 4, GATED);                \
     }                                                        \
   } while (0)
