@@ -208,3 +208,22 @@ def test_talker_config_shapes():
     assert bad_word_mask_spec(8448, None, 8294, 8293) == ([], 8293)
     with pytest.raises(ValueError):
         bad_word_mask_spec(8448, 8000, None, 1)
+
+
+def test_linear_routing_policy_matches_the_measurements():
+    """Which GEMM runs which projection of the headline talker (hidden 3584, intermediate 18944, 28/4 heads of 128)
+    per (TP, rows per rank) — DESIGN.md 3.5 / profiles/r01_scaling_estimate.md: the streaming kernel takes the MLP at
+    TP 1 and 2 for every decode batch, o_proj only when its split-K reduce can ride in the next RMSNorm, nothing at TP 4,
+    and no batch above 256 rows."""
+    from vllm_omni_amd import layers as L
+    H, I = 3584, 18944
+    for tp, down, gate_up in [(1, True, True), (2, True, True), (4, False, False), (8, False, False)]:
+        for m in (32, 128, 256):
+            assert L._streaming_kernel_wins(m, H, I // tp) is down, (tp, m)
+            assert L._fused_gate_up_wins(m, I // tp, H) is gate_up, (tp, m)
+    assert not L._streaming_kernel_wins(512, H, I) and not L._fused_gate_up_wins(512, I, H)
+    # qkv_proj / o_proj are not "deep and narrow": the plain policy leaves them on the library ...
+    assert not L._streaming_kernel_wins(256, 4608, H) and not L._streaming_kernel_wins(256, H, H)
+    # ... o_proj joins only with the deferred reduce; the code predictor's 1024 x 2048 o_proj never does
+    assert L._deferred_kernel_wins(256, H, H) and L._deferred_kernel_wins(32, H, H)
+    assert not L._deferred_kernel_wins(256, 1024, 2048) and not L._deferred_kernel_wins(512, H, H)
