@@ -1,24 +1,29 @@
-// Decode-batch linear layer: y[M, N] = x[M, K] . W[N, K]^T (+ bias), M <= 256 rows (one decode step's batch).
+// Decode-batch linear layer: y[M, N] = x[M, K] . W[N, K]^T (+ bias), M <= 256 rows (one decode step's batch), and
+// its gated form silu(x Wg^T) * (x Wu^T) (gate_up_proj + SiluAndMul in one launch).
 //
 // The reference runs these projections (qkv_proj, o_proj, gate_up_proj, down_proj of every decoder layer:
-// vllm_omni/model_executor/models/qwen2_5_omni/qwen2_5_omni_talker.py through vLLM's ColumnParallelLinear /
-// RowParallelLinear) as library GEMMs.  At M = 256 the job is weight streaming: 256 flop per weight byte is under
-// the ~310 flop/B ridge of the chip, so the bound is HBM (the weights, read once) plus the per-CU intake of
-// re-reading x for every weight tile (~68 GB/s per CU from L2: MI355X_MICROARCH.md "Indexed rows").  The library's
-// tiles reach 1.8-3.4 TB/s of weight bytes on these shapes; where N alone does not fill the chip and the library has
-// to fall back to small tiles (down_proj: N 3584, K 18944 -> 1.8 TB/s) this kernel is faster:
+// vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:40-70,104-160 through vLLM's ColumnParallelLinear /
+// RowParallelLinear) as library GEMMs.  For a decode batch the job is weight streaming: at most 256 flop per weight
+// byte, under the ~310 flop/B ridge of the chip, so the bound is HBM (the weights, read once) plus the per-CU intake
+// of re-reading x for every weight tile.  The library's tiles reach 1.8-3.4 TB/s of weight bytes on
+// these shapes; this kernel reaches the HBM rate at <= 64 rows (6.4 TB/s) and 2.7-3.8 TB/s at 256:
 //   * swapped form D = W . x^T on MFMA 16x16x32: a consumer wave owns 32 weight rows x 128 activation rows;
 //   * one 64-wide k block per step; a stage of the LDS ring is ONE image of 128-byte rows — the (<= 256) rows of x, then
 //     the tile's 128 / 160 weight rows — with 16-byte chunk c of row r at c ^ ((r >> 1) & 7): `ds_read_b128`
-//     operand reads are conflict-free.  The k order inside a block is permuted identically for W and x, chosen so
-//     that the two k-groups served by one `ds_read_b128` lane group differ by 6 in chunk index;
-//   * the image is filled by LDS-DMA in 1 KiB pieces by dedicated loader waves; consumer waves only read fragments and
-//     run MFMAs; one raw s_barrier per step; three stages, two steps (~100 KB per CU) in flight;
+//     operand reads are conflict-free (SQ_LDS_BANK_CONFLICT = 0, profiles/r01_pmc_linear_kernel.md).  The k order
+//     inside a block is permuted identically for W and x, chosen so that the two k-groups served by one
+//     `ds_read_b128` lane group differ by 6 in chunk index;
+//   * the image is filled by LDS-DMA in 1 KiB pieces by dedicated loader waves (weight pieces non-temporal, raised
+//     priority); consumer waves only read fragments and run MFMAs; one raw s_barrier per step; three stages, two
+//     steps (~100 KB per CU) in flight;
 //   * split-K where N alone does not fill the chip (down_proj: 28 tiles x 8 slices = 224 workgroups, slice = workgroup
-//     id % 8 so that each XCD's L2 serves one slice of x): fp32 partials to a workspace and a small reduce kernel
-//     (+ bias, convert) — deterministic, no atomics.
-// Measured (tools/bench_skinny_gemm.py): down_proj 51 us against 77 us for the TunableOp-selected
-// library kernel; the other three projections are within +-15 % of the library, which keeps them (layers.py).
+//     id % 8 so that each XCD's L2 serves one slice of x): fp32 partials to a workspace, reduced in slice order by
+//     a small kernel (+ bias, convert) or inside the consumer that follows (mi_fused_add_rms_norm_splitk,
+//     mi_rope_neox_and_cache_splitk) — deterministic, no atomics;
+//   * gated form: a slab is 16 gate rows + the 16 matching up rows, a tile 80 (64) output columns; SiLU and the product
+//     in the epilogue, rounded as the unfused pair rounds.
+// Measured in situ at 256 rows: down_proj 47 us + reduce against 77 us for the TunableOp-selected
+// library kernel, gate_up_proj + SiluAndMul 71 us against 81 + 7 us; which layers use it: layers.py.
 #include "mfma_attn_common.h"
 
 // experiment switches (csrc/Makefile `make variant VARIANT_DEFS=...`); the defaults are the measured best
@@ -83,17 +88,7 @@ __device__ __forceinline__ void lds_read_x8(uint32_t a0, uint32_t a1, u32x4_t (&
       : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 2048), "i"(OFF + 4096), "i"(OFF + 6144)
       : "memory");
 }
-// the wave's own weight fragments: RG row groups x 2 k-steps
-template <int OFF>
-__device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w)[1][2]) {
-  asm volatile(
-      "ds_read_b128 %0, %2 offset:%4\n\t"
-      "ds_read_b128 %1, %3 offset:%4\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(w[0][0]), "=&v"(w[0][1])
-      : "v"(a0), "v"(a1), "i"(OFF)
-      : "memory");
-}
+// the slab's weight fragments: 2 row groups x 2 k-steps
 template <int OFF>
 __device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w)[2][2]) {
   asm volatile(
