@@ -369,7 +369,7 @@ int mi_fused_add_rms_norm_splitk(void* out, const void* partials, int32_t split,
                                  int32_t hidden, int64_t out_token_stride,
                                  int64_t residual_token_stride, int dtype, void* stream);
 /* gate_up_proj and the SiluAndMul behind it in one launch (Qwen2MLP.forward,
- * qwen2_old.py:62-66: act_fn(gate_up_proj(x))): weight [2 * inter, k] with the
+ * qwen2_old.py:65-68: act_fn(gate_up_proj(x))): weight [2 * inter, k] with the
  * gate rows first, then the up rows (MergedColumnParallelLinear layout);
  * out[m, inter] = silu(x . gate^T) * (x . up^T), each GEMM output rounded to
  * the 16-bit type before the activation, as the unfused pair rounds. */

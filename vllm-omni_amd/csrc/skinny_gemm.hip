@@ -2,7 +2,7 @@
 // its gated form silu(x Wg^T) * (x Wu^T) (gate_up_proj + SiluAndMul in one launch).
 //
 // The reference runs these projections (qkv_proj, o_proj, gate_up_proj, down_proj of every decoder layer:
-// vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:40-70,104-160 through vLLM's ColumnParallelLinear /
+// vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:37-69,72-156 through vLLM's ColumnParallelLinear /
 // RowParallelLinear) as library GEMMs.  For a decode batch the job is weight streaming: at most 256 flop per weight
 // byte, under the ~310 flop/B ridge of the chip, so the bound is HBM (the weights, read once) plus the per-CU intake
 // of re-reading x for every weight tile.  The library's tiles reach 1.8-3.4 TB/s of weight bytes on
@@ -104,7 +104,7 @@ __device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w
 
 // NSLAB: 32-row weight slabs per tile (tile = 32 NSLAB rows); MT: 16-row m-tiles (x rows padded to 16 MT);
 // MH: consumer waves per slab, each with MT / MH m-tiles; NL: loader waves.
-// GATED: gate_up_proj with the SiluAndMul that follows it (qwen2_old.py:62-66: act_fn(gate_up_proj(x))) in the epilogue —
+// GATED: gate_up_proj with the SiluAndMul that follows it (qwen2_old.py:65-68: act_fn(gate_up_proj(x))) in the epilogue —
 // a slab is 16 gate rows and the 16 matching up rows, a tile covers 16 NSLAB output columns, and the [M, 2 I]
 // intermediate never goes to memory.
 template <typename Tag, int NSLAB, int MT, int MH, int NL, bool GATED>

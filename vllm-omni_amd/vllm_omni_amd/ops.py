@@ -452,7 +452,7 @@ def rope_neox_and_cache_splitk(part: SplitKPartials, num_q_heads: int, num_kv_he
 
 def linear_silu_mul(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """silu(x Wg^T) * (x Wu^T) for a decode batch, weight = [gate rows; up rows] — ``gate_up_proj`` and the
-    ``SiluAndMul`` behind it (qwen2_old.py:62-66) in one launch; the [m, 2 I] intermediate never reaches memory."""
+    ``SiluAndMul`` behind it (qwen2_old.py:65-68) in one launch; the [m, 2 I] intermediate never reaches memory."""
     _gpu(x, weight)
     x2 = x.reshape(-1, x.shape[-1])
     if x2.stride(-1) != 1:
