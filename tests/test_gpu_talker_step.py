@@ -582,3 +582,126 @@ def test_qwen3_talker_step_with_code_predictor(dev, enforce_eager):
         for r, t in zip(reqs, got_ids.tolist()):
             r.num_computed_tokens += 1
             r.output_token_ids.append(t)
+
+
+def _qwen3_runner(dev, enforce_eager, ctxs, reply_rows=8):
+    """Mini Qwen3-Omni talker + code predictor through the runner, KV pre-filled, requests ready to decode."""
+    from oracle import ref_code_predictor as rcp
+    from vllm_omni_amd.code_predictor import CodePredictorConfig
+    from vllm_omni_amd.kv_cache import KVCacheManager, normalize_layer_kv
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import Request, SamplingParams
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_qwen3_talker")
+    cpc = CodePredictorConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                              head_dim=128, intermediate_size=256, vocab_size=256, num_code_groups=4)
+    bs, nb = 16, 64
+    runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=8, max_model_len=128, max_num_batched_tokens=64,
+                              block_size=bs, enforce_eager=enforce_eager, max_reply_rows=64, seed=0, code_predictor=cpc)
+    runner.load_model()
+    w = ref_talker.random_weights(cfg, seed=3)
+    runner.model.load_weights({k: v.to(dev) for k, v in w.items()})
+    runner.code_predictor.load_weights({k: v.to(dev) for k, v in rcp.random_weights(cpc, seed=4).items()})
+    runner.initialize_kv_cache(nb)
+    g = torch.Generator().manual_seed(5)
+    for kv in runner.kv_caches:
+        init = torch.randn(nb, 2, bs, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
+        kb, vb = normalize_layer_kv(kv)
+        kb.copy_(init[:, 0].to(dev))
+        vb.copy_(init[:, 1].to(dev))
+    mgr = KVCacheManager(nb, bs)
+    reqs = []
+    for i, c in enumerate(ctxs):
+        r = Request(f"r{i}", list(range(c + 1)), SamplingParams(temperature=0.0, seed=100 + i))
+        r.additional_information = {"thinker_reply_part": torch.randn(reply_rows, cfg.embedding_size, generator=g).to(torch.bfloat16)}
+        assert mgr.allocate_slots(r, c + 1) is not None
+        r.num_computed_tokens = c
+        reqs.append(r)
+    return cfg, cpc, runner, mgr, reqs
+
+
+def test_graph_capture_in_the_middle_of_serving_keeps_predictor_state(dev):
+    """the first time a batch size is seen the runner captures its hipGraph by running the
+    live step several times.  With a code predictor a step ADVANCES device state (`last_talker_hidden`); capture
+    must leave that state as the previous step left it.  Five requests decode; two finish after step 2, so the
+    batch drops from the 8-row graph to the 4-row graph, which is captured mid-serving.  Tokens and codes must be
+    identical to the eager run, step by step."""
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SchedulerOutput
+
+    def run(enforce_eager):
+        cfg, cpc, runner, mgr, reqs = _qwen3_runner(dev, enforce_eager, [7, 20, 1, 33, 12])
+        live, trace = list(reqs), []
+        for step in range(6):
+            finished = set()
+            if step == 3:
+                finished = {"r1", "r4"}
+                live = [r for r in live if r.request_id not in finished]
+            sched = {r.request_id: 1 for r in live}
+            if step == 0:
+                so = SchedulerOutput(scheduled_new_reqs=[
+                    NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id),
+                                   r.num_computed_tokens, additional_information=r.additional_information) for r in live],
+                    num_scheduled_tokens=sched, total_num_scheduled_tokens=len(live))
+            else:
+                new_blocks = []
+                for r in live:
+                    nb_ = mgr.allocate_slots(r, 1)
+                    new_blocks.append(nb_.get_block_ids() if nb_.blocks[0] else None)
+                so = SchedulerOutput(scheduled_cached_reqs=CachedRequestData(
+                    req_ids=[r.request_id for r in live], new_block_ids=new_blocks,
+                    num_computed_tokens=[r.num_computed_tokens for r in live], num_output_tokens=[step] * len(live)),
+                    num_scheduled_tokens=sched, total_num_scheduled_tokens=len(live), finished_req_ids=finished)
+            runner.execute_model(so)
+            out = runner.sample_tokens()
+            for r in live:
+                j = out.req_id_to_index[r.request_id]
+                trace.append((step, r.request_id, out.sampled_token_ids[j][0],
+                              out.pooler_output[j]["code_predictor_codes"].tolist()))
+                r.num_computed_tokens += 1
+        return trace, sorted(runner._graphs)
+
+    eager, _ = run(True)
+    graph, sizes = run(False)
+    assert sizes == [4, 8]                 # 5 rows ran in the 8-row graph, 3 rows in the 4-row graph (padded rows inert)
+    assert eager == graph
+
+
+def test_prefill_step_stores_last_hidden_in_the_requests_own_state_rows(dev):
+    """a pure-prefill step — the first step of every request — must store each request's last
+    hidden state in ITS state row (`last_talker_hidden`, qwen3_omni.py:634-640), not in the rows of the previous
+    batch.  A decode-only batch runs first (so the device still holds ITS row mapping), then two new requests
+    prefill alone; their state rows must hold their own last prompt token's hidden state and the other
+    requests' rows must be untouched."""
+    from vllm_omni_amd.sched_output import NewRequestData, Request, SamplingParams, SchedulerOutput
+
+    cfg, cpc, runner, mgr, reqs = _qwen3_runner(dev, True, [7, 20, 5])
+    so = SchedulerOutput(scheduled_new_reqs=[
+        NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id),
+                       r.num_computed_tokens, additional_information=r.additional_information) for r in reqs],
+        num_scheduled_tokens={r.request_id: 1 for r in reqs}, total_num_scheduled_tokens=3)
+    runner.execute_model(so)
+    runner.sample_tokens()
+    before = runner._last_hidden.clone()
+    old_slots = [runner.requests[r.request_id].state_slot for r in reqs]
+    g = torch.Generator().manual_seed(9)
+    news = []
+    for name, n in (("p0", 9), ("p1", 21)):
+        r = Request(name, list(range(1, n + 1)), SamplingParams(temperature=0.0),
+                    prompt_embeds=(torch.randn(n, cfg.embedding_size, generator=g) * 0.5).to(torch.bfloat16))
+        assert mgr.allocate_slots(r, n) is not None
+        news.append(r)
+    # the three decoding requests are NOT scheduled this step: a pure-prefill batch of the two new ones
+    so = SchedulerOutput(scheduled_new_reqs=[
+        NewRequestData(r.request_id, r.prompt_token_ids, r.sampling_params, mgr.get_block_ids(r.request_id), 0,
+                       prompt_embeds=r.prompt_embeds) for r in news],
+        num_scheduled_tokens={r.request_id: len(r.prompt_token_ids) for r in news}, total_num_scheduled_tokens=30)
+    runner.execute_model(so)
+    out = runner.sample_tokens()
+    for r in news:
+        slot = runner.requests[r.request_id].state_slot
+        assert slot not in old_slots
+        last = out.pooler_output[out.req_id_to_index[r.request_id]]["hidden"][-1]
+        assert torch.equal(runner._last_hidden[slot].cpu(), last), r.request_id
+    for s in old_slots:                                        # the waiting requests' state survived the prefill step
+        assert torch.equal(runner._last_hidden[s], before[s])

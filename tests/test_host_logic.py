@@ -227,3 +227,109 @@ def test_linear_routing_policy_matches_the_measurements():
     # ... o_proj joins only with the deferred reduce; the code predictor's 1024 x 2048 o_proj never does
     assert L._deferred_kernel_wins(256, H, H) and L._deferred_kernel_wins(32, H, H)
     assert not L._deferred_kernel_wins(256, 1024, 2048) and not L._deferred_kernel_wins(512, H, H)
+
+
+# ------------------------------------------------------------------------- deferred free while a KV transfer is active
+def test_free_is_deferred_while_kv_transfer_is_active():
+    """omni_ar_scheduler.py:559-605: a finishing request whose KV goes to the next stage keeps its blocks until the
+    runner reports the extraction; block ids in the transfer snapshot are truncated to ceil(seq_len / b)."""
+    from vllm_omni_amd.kv_cache import KVCacheManager
+
+    m = KVCacheManager(num_blocks=16, block_size=4)
+    a, b = _req("a", 11), _req("b", 5)
+    assert m.allocate_slots(a, 11, num_lookahead_tokens=4) is not None       # 4 blocks (lookahead), 3 hold tokens
+    assert m.allocate_slots(b, 5) is not None
+    free0 = m.block_pool.get_num_free_blocks()
+    snap = m.mark_request_for_kv_transfer("a", seq_len=11)
+    assert snap == {"seq_len": 11, "block_ids": m.get_block_ids("a")[0][:3]}
+    m.free(a)                                                                # transfer active: nothing returns
+    assert m.block_pool.get_num_free_blocks() == free0 and m.get_block_ids("a")[0]
+    assert "a" in m.waiting_for_transfer_free
+    m.free(b)                                                                # no transfer: immediate
+    assert m.block_pool.get_num_free_blocks() == free0 + 2
+    assert m.on_kv_extracted(["a", "unknown"]) == ["a"]
+    assert m.block_pool.get_num_free_blocks() == free0 + 2 + 4 and m.get_block_ids("a") == ([],)
+    assert not m.active_kv_transfers and not m.waiting_for_transfer_free
+    # extraction reported BEFORE the request finishes: the later free is immediate
+    c = _req("c", 8)
+    m.allocate_slots(c, 8)
+    m.mark_request_for_kv_transfer("c", 8)
+    assert m.on_kv_extracted(["c"]) == []
+    n = m.block_pool.get_num_free_blocks()
+    m.free(c)
+    assert m.block_pool.get_num_free_blocks() == n + 2
+
+
+# ------------------------------------------------------------------------- thinker_reply_part pool (A11)
+def test_reply_row_allocator_first_fit_and_coalescing():
+    from vllm_omni_amd.model_runner import ReplyRowAllocator
+
+    a = ReplyRowAllocator(10)
+    s0, s1, s2 = a.alloc(3), a.alloc(4), a.alloc(3)
+    assert (s0, s1, s2) == (0, 3, 7) and a.num_free == 0
+    with pytest.raises(RuntimeError, match="pool is full"):
+        a.alloc(1)
+    a.release(s1, 4)
+    assert a.alloc(2) == 3 and a.free == [(5, 2)]
+    a.release(s0, 3)
+    a.release(3, 2)
+    assert a.free == [(0, 7)]                                                # neighbours merged back
+    a.release(s2, 3)
+    assert a.free == [(0, 10)]
+
+
+def test_reply_cursor_survives_unscheduling_and_live_rows_are_never_overwritten():
+    """a request that leaves the batch for a step continues its thinker_reply_part where it stopped
+    (the reference persists the consumed queue, qwen2_5_omni.py:771-774); a full pool raises instead of wrapping
+    over live rows; a finished request's rows are reusable."""
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SamplingParams, SchedulerOutput
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_talker")
+    r = GPUARModelRunner(cfg, torch.device("cpu"), torch.bfloat16, max_num_reqs=4, max_model_len=64,
+                         max_num_batched_tokens=16, block_size=16, enforce_eager=True, max_reply_rows=8)
+    r._reply_pool = torch.zeros(8, cfg.embedding_size, dtype=torch.bfloat16)
+    rp = {n: torch.full((k, cfg.embedding_size), float(i + 1)) for i, (n, k) in enumerate([("a", 3), ("b", 4)])}
+    new = [NewRequestData(n, [1, 2, 3], SamplingParams(), ([1 + i],), 3, additional_information={"thinker_reply_part": rp[n]})
+           for i, n in enumerate(("a", "b"))]
+    r._update_states(SchedulerOutput(scheduled_new_reqs=new, num_scheduled_tokens={"a": 1, "b": 1},
+                                     total_num_scheduled_tokens=2))
+    ib = r.input_batch
+    assert ib.reply_offset[:2].tolist() == [0, 3] and ib.reply_end[:2].tolist() == [3, 7]
+    assert float(r._reply_pool[3, 0]) == 2.0
+    ib.reply_offset[:2] += 2                                                 # two decode steps consumed two rows each
+    # step 3: "a" is not scheduled (preempted / waiting) -> leaves the batch, keeps its cursor
+    cached = CachedRequestData(req_ids=["b"], new_block_ids=[None], num_computed_tokens=[5], num_output_tokens=[2])
+    r._update_states(SchedulerOutput(scheduled_cached_reqs=cached, num_scheduled_tokens={"b": 1}, total_num_scheduled_tokens=1))
+    assert ib.req_ids == ["b"] and r.requests["a"].reply_cursor == 2
+    # step 4: "a" comes back: same pool rows, cursor where it stopped (NOT row 0 again), nothing re-allocated
+    cached = CachedRequestData(req_ids=["a", "b"], new_block_ids=[None, None], num_computed_tokens=[5, 6],
+                               num_output_tokens=[2, 3])
+    r._update_states(SchedulerOutput(scheduled_cached_reqs=cached, num_scheduled_tokens={"a": 1, "b": 1},
+                                     total_num_scheduled_tokens=2))
+    row_a = ib.req_id_to_index["a"]
+    assert (int(ib.reply_offset[row_a]), int(ib.reply_end[row_a])) == (2, 3) and r._reply_alloc.num_free == 1
+    # a third request that does not fit raises; nothing of a / b was touched
+    big = NewRequestData("c", [1], SamplingParams(), ([5],), 1,
+                         additional_information={"thinker_reply_part": torch.ones(2, cfg.embedding_size)})
+    with pytest.raises(RuntimeError, match="pool is full"):
+        r._update_states(SchedulerOutput(scheduled_new_reqs=[big], num_scheduled_tokens={"a": 1, "b": 1, "c": 1},
+                                         total_num_scheduled_tokens=3))
+    assert float(r._reply_pool[0, 0]) == 1.0 and float(r._reply_pool[6, 0]) == 2.0
+    # "b" finishes: its 4 rows return to the pool and "c"'s part now fits into them
+    r.requests.pop("c", None)
+    r.input_batch.remove_request("c")
+    cached = CachedRequestData(req_ids=["a"], new_block_ids=[None], num_computed_tokens=[6], num_output_tokens=[3])
+    r._update_states(SchedulerOutput(scheduled_new_reqs=[big], scheduled_cached_reqs=cached, finished_req_ids={"b"},
+                                     num_scheduled_tokens={"a": 1, "c": 1}, total_num_scheduled_tokens=2))
+    assert r.requests["c"].reply_base == 3 and r._reply_alloc.num_free == 8 - 3 - 2
+
+
+def test_graph_batch_size_ladder():
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.talker import TalkerConfig
+
+    r = GPUARModelRunner(TalkerConfig.from_json("mini_talker"), torch.device("cpu"), max_num_reqs=250, max_model_len=64)
+    assert [r.graph_batch_size(n) for n in (1, 2, 3, 4, 5, 8, 9, 64, 249, 250)] == [1, 2, 4, 4, 8, 8, 16, 64, 250, 250]
+    assert len({r.graph_batch_size(n) for n in range(1, 251)}) <= 250 // 8 + 4

@@ -121,6 +121,10 @@ class KVCacheManager:
         self._events: list[Any] = []
         self._events_on = enable_kv_cache_events
         self._new_block_ids: Optional[list[int]] = [] if track_new_block_ids else None
+        # requests whose KV is being handed to the next stage: their blocks outlive `free` until the runner reports
+        # the extraction (OmniARScheduler.active_kv_transfers / waiting_for_transfer_free, omni_ar_scheduler.py:559-605)
+        self.active_kv_transfers: set[str] = set()
+        self.waiting_for_transfer_free: dict[str, Any] = {}
 
     # -- step hooks -------------------------------------------------------------
     def new_step_starts(self) -> None:
@@ -170,9 +174,41 @@ class KVCacheManager:
         """One list per KV-cache group (the reference takes element 0)."""
         return (list(self.req_to_blocks.get(request_id, [])),)
 
+    def mark_request_for_kv_transfer(self, request_id: str, seq_len: int) -> dict:
+        """A finishing request whose KV goes to the next stage (``_mark_request_for_kv_transfer``,
+        omni_ar_scheduler.py:607-660): snapshot ``{"seq_len", "block_ids"}`` with the ids truncated to
+        ceil(seq_len / block_size), and hold the blocks — ``free`` is deferred until ``on_kv_extracted`` names
+        the request (the runner's ``kv_extracted_req_ids``)."""
+        ids = list(self.req_to_blocks.get(request_id, []))
+        n = cdiv(seq_len, self.block_size)
+        if len(ids) > n:
+            ids = ids[:n]
+        self.active_kv_transfers.add(request_id)
+        return {"seq_len": int(seq_len), "block_ids": ids}
+
+    def on_kv_extracted(self, request_ids: Iterable[str]) -> list[str]:
+        """The runner has copied these requests' KV out of the paged cache (``kv_extracted_req_ids``): their
+        transfers are no longer active, and the ones whose ``free`` was deferred are freed now
+        (omni_ar_scheduler.py:521-539).  Returns the ids actually freed."""
+        freed = []
+        for rid in request_ids or ():
+            self.active_kv_transfers.discard(rid)
+            req = self.waiting_for_transfer_free.pop(rid, None)
+            if req is not None:
+                self._free_now(req)
+                freed.append(rid)
+        return freed
+
     def free(self, request) -> None:
         """Return the request's blocks to the pool tail, LAST block first (so a later request
-        re-uses the tail of a sequence before its head, as upstream's eviction order does)."""
+        re-uses the tail of a sequence before its head, as upstream's eviction order does).  While the request's
+        KV transfer is active the blocks are kept (the extraction reads them) and freed by ``on_kv_extracted``."""
+        if request.request_id in self.active_kv_transfers:
+            self.waiting_for_transfer_free[request.request_id] = request
+            return
+        self._free_now(request)
+
+    def _free_now(self, request) -> None:
         blocks = self.req_to_blocks.pop(request.request_id, None)
         if blocks:
             self.block_pool.free_blocks(list(reversed(blocks)))

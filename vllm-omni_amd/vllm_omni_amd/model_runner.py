@@ -50,6 +50,9 @@ class CachedRequestState:
     sample_seed: int = 0                                  # Philox key of the request's draws
     seen_slot: int = -1                                   # row of the device seen-token bitmap, -1 = none
     state_slot: int = -1                                  # row of the device per-request state (last talker hidden)
+    reply_base: int = -1                                  # first row of the request's thinker_reply_part in the device pool
+    reply_rows: int = 0                                   # rows it owns there
+    reply_cursor: int = 0                                 # rows consumed so far (the reference's `q[1:]` queue, qwen2_5_omni.py:771-774)
 
     @property
     def num_tokens(self) -> int:
@@ -121,6 +124,46 @@ class SamplingState:
                                  top_p=self.top_p.copy_to_gpu(n), rep_penalty=self.rep.copy_to_gpu(n),
                                  seen_bitmap=self.bitmap, seen_row=self.seen_row.copy_to_gpu(n), update_seen=True,
                                  ids=ids[:n])
+
+
+class ReplyRowAllocator:
+    """First-fit free list over the rows of the device-resident ``thinker_reply_part`` pool.  A request owns one
+    contiguous segment from its first scheduling until it finishes; ``alloc`` raises when no segment fits — live
+    rows are never overwritten."""
+
+    def __init__(self, rows: int):
+        self.rows = rows
+        self.free: list[tuple[int, int]] = [(0, rows)] if rows else []   # (start, length), sorted by start
+
+    def alloc(self, n: int) -> int:
+        for i, (start, length) in enumerate(self.free):
+            if length >= n:
+                if length == n:
+                    self.free.pop(i)
+                else:
+                    self.free[i] = (start + n, length - n)
+                return start
+        raise RuntimeError(f"thinker_reply_part pool is full: {n} rows requested, largest free segment "
+                           f"{max((ln for _, ln in self.free), default=0)} of {self.rows} (raise max_reply_rows)")
+
+    def release(self, start: int, n: int) -> None:
+        if n <= 0:
+            return
+        import bisect
+
+        i = bisect.bisect_left(self.free, (start, 0))
+        self.free.insert(i, (start, n))
+        # coalesce with the neighbours
+        if i + 1 < len(self.free) and self.free[i][0] + self.free[i][1] == self.free[i + 1][0]:
+            self.free[i] = (self.free[i][0], self.free[i][1] + self.free[i + 1][1])
+            self.free.pop(i + 1)
+        if i > 0 and self.free[i - 1][0] + self.free[i - 1][1] == self.free[i][0]:
+            self.free[i - 1] = (self.free[i - 1][0], self.free[i - 1][1] + self.free[i][1])
+            self.free.pop(i)
+
+    @property
+    def num_free(self) -> int:
+        return sum(ln for _, ln in self.free)
 
 
 class InputBatch:
@@ -233,7 +276,11 @@ class GPUARModelRunner:
                  max_num_reqs: int = 256, max_model_len: int = 4096, max_num_batched_tokens: int = 8192,
                  block_size: int = 16, kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: bool = False,
                  engine_output_type: str = "latent", max_reply_rows: int = 0, seed: Optional[int] = 0,
-                 quantization: Optional[str] = None, code_predictor=None):
+                 quantization: Optional[str] = None, code_predictor=None, copy_outputs: bool = True):
+        """``copy_outputs``: hand every step's ``pooler_output`` tensors back as caller-owned host tensors, as the
+        reference does (``hidden_states.to("cpu")``, gpu_ar_model_runner.py:835).  False returns VIEWS of the pinned
+        output ring, valid until ``OUT_SLOTS - 1`` further steps have been sampled (what bench.py uses: fresh 1.8 MB
+        host allocations every step were measured to stall the device queues)."""
         from .distributed import get_parallel_state
 
         self.config = config
@@ -263,11 +310,13 @@ class GPUARModelRunner:
         self.execute_model_state: Optional[ExecuteModelState] = None
         self.kv_extracted: dict[str, Any] = {}
         self.kv_payloads: dict[str, torch.Tensor] = {}     # packed wire payloads (1-D uint8, device)
+        self.max_kept_kv = 4 * max_num_reqs                # hand-offs nobody collected: oldest dropped beyond this
         self._graphs: dict[int, tuple[torch.cuda.CUDAGraph, dict]] = {}
-        self._graph_broken = False
+        self._graph_pool = None                            # one memory pool shared by every captured batch size
         self.max_reply_rows = max_reply_rows
         self._reply_pool: Optional[torch.Tensor] = None
-        self._reply_used = 0
+        self._reply_alloc = ReplyRowAllocator(max_reply_rows)
+        self.copy_outputs = copy_outputs
         self._alloc_buffers()
 
     # ------------------------------------------------------------------ buffers
@@ -330,7 +379,8 @@ class GPUARModelRunner:
                                                       seed=(self.seed or 0) + 17)
             n = self.max_num_reqs
             self._state_free = list(range(n - 1, -1, -1))
-            self._last_hidden = torch.zeros(n, self.config.hidden_size, dtype=self.dtype, device=self.device)
+            # + one scratch row: where the padded rows of a bucketed graph replay park their state
+            self._last_hidden = torch.zeros(n + 1, self.config.hidden_size, dtype=self.dtype, device=self.device)
             self._state_rows = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
             self._cp_seed = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
             self._cp_offset = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
@@ -383,6 +433,9 @@ class GPUARModelRunner:
             if self.code_predictor is not None and st is not None and st.state_slot >= 0:
                 self._state_free.append(st.state_slot)
                 st.state_slot = -1
+            if st is not None and st.reply_base >= 0:
+                self._reply_alloc.release(st.reply_base, st.reply_rows)
+                st.reply_base, st.reply_rows = -1, 0
             ib.remove_request(rid)
         if so.new_block_ids_to_zero:
             self._zero_block_ids(so.new_block_ids_to_zero)
@@ -390,6 +443,11 @@ class GPUARModelRunner:
         scheduled = so.num_scheduled_tokens.keys()
         unscheduled = [r for r in ib.req_ids if r not in scheduled or r in cached.resumed_req_ids]
         for rid in unscheduled:
+            # the request keeps its cached state, including how far it has consumed its reply rows
+            # (the reference persists the consumed queue: update_dict["thinker_reply_part"] = q[1:])
+            st, row = self.requests.get(rid), ib.req_id_to_index[rid]
+            if st is not None and st.reply_base >= 0:
+                st.reply_cursor = int(ib.reply_offset[row]) - st.reply_base
             ib.remove_request(rid)
 
         to_add: list[CachedRequestState] = []
@@ -429,21 +487,22 @@ class GPUARModelRunner:
             self._register_reply_part(st, i)
 
     def _register_reply_part(self, st: CachedRequestState, row: int) -> None:
-        """Move a request's ``thinker_reply_part`` rows (one consumed per decode step) into the
-        device-resident pool; the batch rows only keep [offset, end) cursors into it."""
-        info = st.additional_information or {}
-        rp = info.get("thinker_reply_part")
-        if not isinstance(rp, torch.Tensor) or rp.numel() == 0:
-            return
-        if self._reply_pool is None:
-            raise RuntimeError("runner built with max_reply_rows=0 but a request carries thinker_reply_part")
-        n = rp.shape[0]
-        if self._reply_used + n > self._reply_pool.shape[0]:
-            self._reply_used = 0  # ring reuse: rows of finished requests are dead by construction
-        self._reply_pool[self._reply_used:self._reply_used + n].copy_(rp.to(self.dtype), non_blocking=True)
-        self.input_batch.reply_offset[row] = self._reply_used
-        self.input_batch.reply_end[row] = self._reply_used + n
-        self._reply_used += n
+        """Move a request's ``thinker_reply_part`` rows (one consumed per decode step) into the device-resident
+        pool ONCE; the batch rows only keep [offset, end) cursors into it.  A request that left the batch for a
+        step (unscheduled / preempted) and comes back continues where it stopped (``reply_cursor``); its segment is
+        released when it finishes.  A full pool raises — live rows are never overwritten."""
+        if st.reply_base < 0:
+            info = st.additional_information or {}
+            rp = info.get("thinker_reply_part")
+            if not isinstance(rp, torch.Tensor) or rp.numel() == 0:
+                return
+            if self._reply_pool is None:
+                raise RuntimeError("runner built with max_reply_rows=0 but a request carries thinker_reply_part")
+            n = rp.shape[0]
+            st.reply_base, st.reply_rows, st.reply_cursor = self._reply_alloc.alloc(n), n, 0
+            self._reply_pool[st.reply_base:st.reply_base + n].copy_(rp.to(self.dtype), non_blocking=True)
+        self.input_batch.reply_offset[row] = st.reply_base + st.reply_cursor
+        self.input_batch.reply_end[row] = st.reply_base + st.reply_rows
 
     # ----------------------------------------------------------- input preparation
     def _reorder_decodes_first(self, num_sched: np.ndarray) -> np.ndarray:
@@ -496,14 +555,21 @@ class GPUARModelRunner:
         num_decodes = int((num_sched == 1).sum())
         return n, total, num_sched, max_seq_len, num_decodes
 
-    def _commit_inputs(self, n: int, total: int, padded_total: int):
+    def _commit_inputs(self, n: int, total: int, padded: int):
+        """Host -> device copies of the step's index arrays.  ``padded`` > n (graph replay at a bucketed batch size,
+        pure decode): the tail rows [n, padded) are inert — seq_len 0 (the decode kernel writes zeros and dereferences
+        no block-table entry), slot -1 (no KV write), position 0."""
         ib = self.input_batch
-        self.positions.copy_to_gpu(total)
-        self.seq_lens.copy_to_gpu(n)
-        self.query_start_loc.copy_to_gpu(n + 1)
+        if padded > n:
+            self.positions.np[total:padded] = 0
+            self.seq_lens.np[n:padded] = 0
+            self.query_start_loc.np[n + 1:padded + 1] = total + np.arange(1, padded - n + 1)
+        self.positions.copy_to_gpu(max(total, padded))
+        self.seq_lens.copy_to_gpu(max(n, padded))
+        self.query_start_loc.copy_to_gpu(max(n, padded) + 1)
         self.logits_indices.copy_to_gpu(n)
         ib.block_table.commit_block_table(n)
-        ib.block_table.commit_slot_mapping(total, padded_total)
+        ib.block_table.commit_slot_mapping(total, max(total, padded))
 
     def _build_metadata(self, n, total, max_query_len, max_seq_len_bound, num_decodes) -> AttentionMetadata:
         bt = self.input_batch.block_table[0]
@@ -526,8 +592,11 @@ class GPUARModelRunner:
                 self.last_token_ids.np[:nd] = ib.last_token_ids_cpu[:nd]
                 self.last_token_ids.copy_to_gpu(nd)
             self.reply_idx.copy_to_gpu(nd)
-            self._commit_predictor_inputs(n)
-            self._decode_embeds(nd)
+        # every step — a pure-prefill step too — ends by storing hidden[-1] of each request in its state row
+        # (`last_talker_hidden`, qwen3_omni.py:634-640): the rows must belong to THIS step's batch
+        self._commit_predictor_inputs(n)
+        if num_decodes:
+            self._decode_embeds(num_decodes)
         # prefill rows: per-request prompt embeddings (thinker hidden states) or token embeddings
         t0 = num_decodes
         for i in range(num_decodes, n):
@@ -541,8 +610,9 @@ class GPUARModelRunner:
                 self.inputs_embeds[t0:t0 + k] = self.model.embed_input_ids(ids.to(self.device))
             t0 += k
 
-    def _commit_predictor_inputs(self, n: int) -> None:
-        """Per-request state rows, Philox keys and draw bases of the code predictor for this step's batch rows."""
+    def _commit_predictor_inputs(self, n: int, padded: int = 0) -> None:
+        """Per-request state rows, Philox keys and draw bases of the code predictor for this step's batch rows
+        (padded graph rows point at the scratch state row ``max_num_reqs``)."""
         if self.code_predictor is None:
             return
         pending = 1 if (self._last_output is not None and not self._last_output.done) else 0
@@ -551,9 +621,14 @@ class GPUARModelRunner:
             self._state_rows.np[i] = st.state_slot
             self._cp_seed.np[i] = st.sample_seed
             self._cp_offset.np[i] = len(st.output_token_ids) + pending
-        self._state_rows.copy_to_gpu(n)
-        self._cp_seed.copy_to_gpu(n)
-        self._cp_offset.copy_to_gpu(n)
+        m = max(n, padded)
+        if m > n:
+            self._state_rows.np[n:m] = self.max_num_reqs
+            self._cp_seed.np[n:m] = 0
+            self._cp_offset.np[n:m] = 0
+        self._state_rows.copy_to_gpu(m)
+        self._cp_seed.copy_to_gpu(m)
+        self._cp_offset.copy_to_gpu(m)
 
     def _decode_embeds(self, nd: int) -> None:
         if self.code_predictor is not None:
@@ -589,33 +664,60 @@ class GPUARModelRunner:
         return hidden, logits, ids
 
     def _can_use_graph(self, n: int, total: int) -> bool:
-        """Pure-decode batches replay a hipGraph.  With TP > 1 the graph contains the RCCL
-        all-reduces (torch.distributed collectives are capturable; probed on this stack with
-        tools/probe_rccl_graph.py); VLLM_OMNI_AMD_TP_GRAPH=0 keeps TP > 1 eager."""
-        if self.enforce_eager or total != n or torch.device(self.device).type != "cuda" or self._graph_broken:
+        """Pure-decode batches replay a hipGraph.  With TP > 1 the graph contains the all-reduces (RCCL collectives
+        are capturable, probed on this stack with tools/probe_rccl_graph.py; the in-tree two-shot all-reduce is a
+        plain kernel launch); VLLM_OMNI_AMD_TP_GRAPH=0 keeps TP > 1 eager."""
+        if self.enforce_eager or total != n or torch.device(self.device).type != "cuda":
             return False
         return self.parallel.tp_size == 1 or os.environ.get("VLLM_OMNI_AMD_TP_GRAPH", "1") == "1"
 
+    def graph_batch_size(self, n: int) -> int:
+        """Batch size of the graph that runs ``n`` decode rows: 1, 2, 4, then multiples of 8, and ``max_num_reqs``
+        itself (upstream's capture-size ladder) — at most max_num_reqs / 8 + 4 graphs, all in one memory pool,
+        instead of one private pool per distinct batch size."""
+        if n <= 4:
+            b = 1 if n <= 1 else (2 if n <= 2 else 4)
+        else:
+            b = -(-n // 8) * 8
+        return min(b, self.max_num_reqs)
+
     def capture_model(self, batch_sizes: Optional[list[int]] = None) -> None:
-        for b in batch_sizes or []:
-            self._capture(b)
+        """Capture before serving (the worker's ``compile_or_warm_up_model``); sizes are rounded up the ladder."""
+        for b in sorted({self.graph_batch_size(b) for b in (batch_sizes or [])}, reverse=True):
+            if b not in self._graphs:
+                self._capture(b)
 
     def _capture(self, n: int):
-        """Capture the pure-decode step for batch size ``n`` (grid sized for max_model_len)."""
+        """Capture the pure-decode step for batch size ``n`` (grid sized for max_model_len).  The warm-up runs, the
+        capture pass and (TP > 1) the watchdogged first replay all execute the step on whatever the static buffers
+        hold; device state that a step ADVANCES — the code predictor's `last_talker_hidden` rows and codes — is
+        snapshotted before and restored after, so a capture in the middle of serving (first time a batch size is
+        seen) leaves the requests' state exactly as the previous step left it.  Everything else a step writes
+        (KV rows at the step's slots, outputs) is rewritten with the same values by the replay that follows."""
         md = self._build_metadata(n, n, 1, self.max_model_len, n)
+        saved = None
+        if self.code_predictor is not None:
+            saved = (self._last_hidden.clone(), self._cp_codes.clone())
         # warm-up on a side stream (library handles, hipBLASLt heuristics), then capture
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
+                if saved is not None:
+                    self._last_hidden.copy_(saved[0])
                 self._decode_embeds(n)
                 self._forward(n, n, md)
         torch.cuda.current_stream().wait_stream(s)
+        if saved is not None:
+            self._last_hidden.copy_(saved[0])
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
         g = torch.cuda.CUDAGraph()
         # thread_local: another thread's HIP calls (the RCCL watchdog polling events) must not invalidate
         # the capture.  A capture that does fail leaves a sticky HIP error behind, so it is not caught:
         # failing loudly beats limping on (VLLM_OMNI_AMD_TP_GRAPH=0 / enforce_eager avoid capture).
-        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.parallel.tp_size > 1 else "global"):
+        with torch.cuda.graph(g, pool=self._graph_pool,
+                              capture_error_mode="thread_local" if self.parallel.tp_size > 1 else "global"):
             self._decode_embeds(n)
             hidden, logits, ids = self._forward(n, n, md)
         if self.parallel.tp_size > 1:
@@ -630,6 +732,9 @@ class GPUARModelRunner:
                     raise RuntimeError("first replay of the TP hipGraph did not finish within the watchdog "
                                        "window (set VLLM_OMNI_AMD_TP_GRAPH=0 to run TP eagerly)")
                 time.sleep(0.001)
+        if saved is not None:
+            self._last_hidden.copy_(saved[0])
+            self._cp_codes.copy_(saved[1])
         self._graphs[n] = (g, {"hidden": hidden, "logits": logits, "ids": ids})
         return self._graphs[n]
 
@@ -655,25 +760,20 @@ class GPUARModelRunner:
             self._h2d_pending = False
         n, total, num_sched, max_seq_len, num_decodes = self._prepare_inputs(scheduler_output)
         use_graph = self._can_use_graph(n, total)
-        self._commit_inputs(n, total, total)
-        entry = None
         if use_graph:
-            entry = self._graphs.get(n)
-            self._preprocess_host_only(n, num_decodes)
+            b = self.graph_batch_size(n)
+            self._commit_inputs(n, total, b)
+            self._preprocess_host_only(n, b)
+            entry = self._graphs.get(b)
             if entry is None:  # first time at this batch size: capture (static inputs are filled)
-                entry = self._capture(n)
-        if self._h2d_done is not None and use_graph:
+                entry = self._capture(b)
             self._h2d_done.record()
             self._h2d_pending = True
-        if use_graph and entry is not None:
             g, outs = entry
             g.replay()
             hidden, logits, ids = outs["hidden"], outs["logits"], outs["ids"]
-        elif use_graph:  # capture failed: the host-side index copies are done, run the step eagerly
-            self._decode_embeds(n)
-            md = self._build_metadata(n, total, 1, max_seq_len, num_decodes)
-            hidden, logits, ids = self._forward(n, total, md)
         else:
+            self._commit_inputs(n, total, total)
             self._preprocess_embeds(n, total, num_sched, num_decodes)
             if self._h2d_done is not None:
                 self._h2d_done.record()
@@ -694,18 +794,21 @@ class GPUARModelRunner:
             return False
         return all(so.num_scheduled_tokens.get(r) == 1 for r in ib.req_ids)
 
-    def _preprocess_host_only(self, n: int, num_decodes: int) -> None:
-        """Graph path: only the host->device index copies; the gather-add itself is in the graph."""
+    def _preprocess_host_only(self, n: int, padded: int) -> None:
+        """Graph path: only the host->device index copies; the gather-add itself is in the graph.  Rows [n, padded)
+        of a bucketed replay get no reply row; their token id is whatever the buffer holds (any id is a valid
+        embedding lookup, ids outside the table read as a zero row)."""
         ib = self.input_batch
         off = ib.reply_offset[:n]
         has = (off >= 0) & (off < ib.reply_end[:n])
         self.reply_idx.np[:n] = np.where(has, off, -1)
+        self.reply_idx.np[n:padded] = -1
         ib.reply_offset[:n] = np.where(has, off + 1, off)
         if self._ids_on_device_for != tuple(ib.req_ids[:n]):   # else the last sample_tokens left them on the device
             self.last_token_ids.np[:n] = ib.last_token_ids_cpu[:n]
             self.last_token_ids.copy_to_gpu(n)
-        self.reply_idx.copy_to_gpu(n)
-        self._commit_predictor_inputs(n)
+        self.reply_idx.copy_to_gpu(max(n, padded))
+        self._commit_predictor_inputs(n, padded)
 
     @torch.inference_mode()
     def sample_tokens(self, grammar_output=None, async_output: bool = False):
@@ -790,6 +893,8 @@ class GPUARModelRunner:
         if self.engine_output_type != "text":
             q = st.query_start_loc_np
             hidden = self._out_hidden_cpu[slot][:st.num_tokens]   # views of the pinned ring (see __init__)
+            if self.copy_outputs:                                 # caller-owned, as the reference's .to("cpu") is
+                hidden = hidden.clone()
             pooler = [{"hidden": c} for c in torch.split(hidden, np.diff(q).tolist())]
         else:
             pooler = [None] * n
@@ -797,6 +902,8 @@ class GPUARModelRunner:
             # the codes that produced THIS step's talker input (multimodal output `code_predictor_codes`,
             # qwen3_omni.py:480-494), one row of G codes per decode request
             codes = self._out_codes_cpu[slot][:n]
+            if self.copy_outputs:
+                codes = codes.clone()
             pooler = [dict(p_ or {}, code_predictor_codes=codes[i]) for i, p_ in enumerate(pooler)]
         if self._out_inflight[slot] is out:
             self._out_inflight[slot] = None
@@ -830,4 +937,18 @@ class GPUARModelRunner:
                                           "metadata": {"block_size": self.block_size, "num_layers": len(self.kv_caches),
                                                        "dtype": str(self.dtype), "seq_len": seq_len}}
             done.append(rid)
+        # hand-offs nobody collected (take_kv_payload / take_kv_extracted) do not pile up for ever
+        for store in (self.kv_payloads, self.kv_extracted):
+            while len(store) > self.max_kept_kv:
+                store.pop(next(iter(store)))
         return done
+
+    def take_kv_payload(self, req_id: str) -> Optional[torch.Tensor]:
+        """Hand the packed wire payload of a finished request to the connector and forget it (the reference's
+        transfer manager sends and drops: kv_transfer_manager.py:721-784)."""
+        self.kv_extracted.pop(req_id, None)
+        return self.kv_payloads.pop(req_id, None)
+
+    def take_kv_extracted(self, req_id: str) -> Optional[dict]:
+        self.kv_payloads.pop(req_id, None)
+        return self.kv_extracted.pop(req_id, None)
