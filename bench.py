@@ -14,12 +14,14 @@ non-contiguous block tables, every sequence at exactly ``ctx`` tokens and NOT gr
 timed region, so bytes/step are constant.  Inputs are resident in HBM when the
 timed region starts.
 
-Parallelism for N > 1 (`choose_plan`): the global batch is fixed (strong scaling) and decode sequences are
-independent, so every split of N into data-parallel replicas x tensor-parallel ranks is valid (TP <= 4: 28 query
-heads do not divide by 8, vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:91).  At start-up the bench
-times the RCCL all-reduce of each candidate TP size on the node and takes the plan with the smallest
-per-rank-compute (measured table) + 2 x layers x all-reduce estimate; data parallelism has no data-path
-collective.  MI_BENCH_PLAN=tpmax|dp|tpT forces a plan; the chosen plan and the probe results are in the JSON.
+Parallelism for N > 1: the global batch is fixed (strong scaling).  The HEADLINE value is the widest tensor-parallel
+plan the model allows — tp2, tp4, and dp2 x tp4 at 8 GPUs (28 query heads do not divide by 8,
+vllm_omni/model_executor/models/qwen2_5_omni/qwen2_old.py:91): the "TP scaling" line north_star asks for, RCCL
+all-reduces inside the step.  Decode sequences are independent, so pure data parallelism (dpN, no data-path collective)
+is also a valid way to use N GPUs: it is measured in the same run, right after, and reported beside the headline as
+`alt_plans` — nothing is estimated from tables.  MI_BENCH_PLAN=tpT|dp runs only that plan; MI_BENCH_ALT=0 skips the
+alternative.  `python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run on
+127.0.0.1) before anything touches the GPU.
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -65,7 +67,6 @@ def parse_args():
                     help="W8A8 decoder linears (BASELINE config #5 family; NOT the headline: the default line is bf16)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps for per-launch timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-layers", type=int, default=2)
     ap.add_argument("--cpu-baseline-batch", type=int, default=4)
     return ap.parse_args()
 
@@ -91,70 +92,43 @@ def plan_label(tp: int, dp: int) -> str:
     return f"tp{tp}" if dp == 1 else (f"dp{dp}" if tp == 1 else f"dp{dp}xtp{tp}")
 
 
-# Per-rank step time (ms) of every (tp, dp) plan at the headline shape, measured on ONE MI355X with the
-# collectives stubbed (`bench.py --simulate-shard TP,DP`, profiles/r01_scaling_estimate.md).  Decode sequences are
-# independent, so data parallelism needs no collective; tensor parallelism adds 2 all-reduces per layer.
-COMPUTE_MS = {(1, 1): 15.35, (2, 1): 9.48, (1, 2): 9.34, (4, 1): 6.16, (2, 2): 6.41, (1, 4): 6.59,
-              (4, 2): 4.42, (2, 4): 4.39, (1, 8): 4.86}
-
-
-def choose_plan(world: int, rank: int, cfg, a, dev, probe: bool = True, backend: str = "nccl"):
-    """Pick (tp, dp) for N > 1 at the headline shape from MEASURED all-reduce latency on this node:
-    estimate(plan) = per-rank compute (table above) + 2 * layers * all-reduce(batch/dp x hidden, tp ranks).
-    MI_BENCH_PLAN=tpmax | dp | tpT forces a plan.  Returns (tp, dp, label, info)."""
-    tp_max, _, _ = parallel_plan(world, cfg)
+def plans_to_run(world: int, cfg, batch: int) -> list[tuple[int, int, str, str]]:
+    """[(tp, dp, label, role)]: the widest tensor-parallel plan first (role "headline": the TP scaling line), then
+    pure data parallelism (role "alt") when it is a different plan.  MI_BENCH_PLAN=tpT|dp|tpmax runs one plan only."""
+    tp_max, dp_max, label = parallel_plan(world, cfg)
     forced = os.environ.get("MI_BENCH_PLAN", "")
-    if forced == "probe":   # rehearsal of the probing path itself
-        forced, probe = "", True
-    headline = (a.config, a.batch, a.ctx, a.quantization) == ("qwen2_5_omni_talker", 256, 4096, None)
-    if forced == "tpmax" or (not forced and (not headline or not probe)):
-        return tp_max, world // tp_max, plan_label(tp_max, world // tp_max), {"rule": "widest tensor-parallel plan"}
     if forced == "dp":
-        return 1, world, plan_label(1, world), {"rule": "forced data parallel"}
-    if forced.startswith("tp"):
+        return [(1, world, plan_label(1, world), "headline (forced data parallel)")]
+    if forced.startswith("tp") and forced != "tpmax":
         t = int(forced[2:])
-        return t, world // t, plan_label(t, world // t), {"rule": f"forced {forced}"}
-    cands = [(t, world // t) for t in (1, 2, 4, 8) if t <= tp_max and world % t == 0 and (t, world // t) in COMPUTE_MS
-             and a.batch % (world // t) == 0]
-    ar_us: dict[int, float] = {}
-    for t, d in cands:
-        if t == 1:
-            continue
-        try:
-            grp = None
-            for g in range(d):                      # every rank creates every group, in the same order
-                ranks = list(range(g * t, (g + 1) * t))
-                gg = dist.new_group(ranks=ranks, backend=backend)
-                if rank in ranks:
-                    grp = gg
-            x = torch.zeros(a.batch // d, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
-            for _ in range(5):
-                dist.all_reduce(x, group=grp)
-            torch.cuda.synchronize()
-            dist.barrier()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                dist.all_reduce(x, group=grp)
-            e1.record()
-            torch.cuda.synchronize()
-            tt = torch.tensor([e0.elapsed_time(e1) / 20 * 1e3], device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ar_us[t] = float(tt.item())
-        except Exception as e:  # noqa: BLE001 — a plan whose collective cannot even be timed is not a candidate
-            ar_us[t] = float("inf")
-            if rank == 0:
-                print(f"[bench] all-reduce probe for tp={t} failed: {e!r}", file=sys.stderr)
-    est = {(t, d): COMPUTE_MS[(t, d)] + (2 * cfg.num_hidden_layers * ar_us[t] / 1e3 if t > 1 else 0.0) for t, d in cands}
-    # every rank must take the same decision: rank 0's estimate table decides
-    best = min(est, key=est.get)
-    pick = torch.tensor(list(best), device=dev)
-    dist.broadcast(pick, src=0)
-    tp, dp = int(pick[0]), int(pick[1])
-    info = {"rule": "min over plans of measured-compute table + 2*layers*measured all-reduce",
-            "allreduce_us": {f"tp{t}": round(v, 1) for t, v in ar_us.items()},
-            "estimate_ms": {plan_label(t, d): round(v, 2) for (t, d), v in est.items()}}
-    return tp, dp, plan_label(tp, dp), info
+        if world % t or t > tp_max:
+            raise SystemExit(f"MI_BENCH_PLAN={forced}: not a valid tensor-parallel degree for {world} GPUs")
+        return [(t, world // t, plan_label(t, world // t), f"headline (forced {forced})")]
+    out = [(tp_max, dp_max, label, "headline: widest tensor-parallel plan")]
+    if forced != "tpmax" and tp_max > 1 and batch % world == 0 and os.environ.get("MI_BENCH_ALT", "1") == "1":
+        out.append((1, world, plan_label(1, world), "alt: pure data parallel (no data-path collective)"))
+    return out
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run on
+    127.0.0.1 — BEFORE this process has touched the GPU — and pass their exit code on.  Counting devices does not
+    initialise the runtime."""
+    import socket
+    import subprocess
+
+    rehearsal = os.environ.get("MI_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if not rehearsal and have < n:
+        print(f"[bench] --gpus {n} but only {have} GPU(s) are visible: refusing to report a {have}-GPU number as "
+              f"n_gpus={n}", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
 
 
 class SyntheticScheduler:
@@ -241,19 +215,30 @@ def time_decode_launches(runner, steps: int):
     return (float(np.mean(ms)) if ms else float("nan")), len(ms)
 
 
-def cpu_baseline(cfg, batch: int, ctx: int, layers: int, block_size: int):
-    """The oracle (CPU restatement of the reference's decode-step semantics — the reference has no
-    CPU execution path) timed on this box's host cores on a bounded sample."""
+def cpu_baseline(cfg, batch: int, ctx: int, block_size: int, budget_s: float = 20.0):
+    """The oracle (CPU restatement of the reference's decode-step semantics — the reference has no CPU execution
+    path) timed on this box's host cores on a BOUNDED SAMPLE OF THE SAME WORKLOAD: the whole decode step
+    — every one of the model's layers, lm_head, mask, argmax — at the full context length, for ``batch`` sequences
+    instead of 256.  Nothing is extrapolated: value = batch / measured step time.  (All layers run the same
+    random-init weight tensors: 28 distinct fp32 layers would be 26 GB of host memory and a minute of RNG for an
+    identical amount of arithmetic.)"""
     from oracle import ref_ops, ref_talker
 
     threads = max(1, min(os.cpu_count() or 1, 16))
     torch.set_num_threads(threads)
-    w = ref_talker.random_weights(cfg, seed=0, dtype=torch.bfloat16, num_layers=layers)
-    w = {k: v.float() for k, v in w.items()}
+    nl = cfg.num_hidden_layers
+    w1 = {k: v.float() for k, v in ref_talker.random_weights(cfg, seed=0, dtype=torch.bfloat16, num_layers=1).items()}
+    w = dict(w1)
+    p0 = "language_model.model.layers.0."
+    for li in range(1, nl):
+        for k, v in w1.items():
+            if k.startswith(p0):
+                w[f"language_model.model.layers.{li}." + k[len(p0):]] = v
     bps = -(-ctx // block_size)
     nb = batch * bps + 1
     d, nkv = cfg.head_dim, cfg.num_key_value_heads
-    kvs = [(torch.randn(nb, block_size, nkv, d), torch.randn(nb, block_size, nkv, d)) for _ in range(layers)]
+    # every layer has its own KV cache (bf16 values held in fp32, what the oracle's attention reads)
+    kvs = [(torch.randn(nb, block_size, nkv, d), torch.randn(nb, block_size, nkv, d)) for _ in range(nl)]
     table = (torch.randperm(nb - 1)[: batch * bps] + 1).view(batch, bps).to(torch.int32)
     seq_lens = torch.full((batch,), ctx, dtype=torch.int32)
     qsl = torch.arange(batch + 1, dtype=torch.int32)
@@ -263,81 +248,38 @@ def cpu_baseline(cfg, batch: int, ctx: int, layers: int, block_size: int):
     emb = torch.randn(batch, cfg.embedding_size)
 
     def run():
-        h = ref_talker.talker_step(cfg, w, emb, pos, kvs, table, seq_lens, qsl, slots, csc, None, num_layers=layers)
+        h = ref_talker.talker_step(cfg, w, emb, pos, kvs, table, seq_lens, qsl, slots, csc, None)
         return ref_talker.logits_and_greedy(cfg, w, h, None)
 
     run()
     t0 = time.perf_counter()
     reps = 0
-    while reps < 2 or time.perf_counter() - t0 < 8.0:
+    while reps < 2 or time.perf_counter() - t0 < budget_s:
         run()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    # the sample ran `layers` of L layers: scale the per-layer part to the full depth
-    t_head0 = time.perf_counter()
-    ref_talker.logits_and_greedy(cfg, w, torch.randn(batch, cfg.hidden_size), None)
-    t_head = time.perf_counter() - t_head0
-    full = (dt - t_head) * cfg.num_hidden_layers / layers + t_head
-    return {"value": batch / full, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"torch-fp32 oracle of the decode step, {batch} sequences x ctx {ctx}, {layers} of "
-                      f"{cfg.num_hidden_layers} layers + lm_head timed ({dt * 1e3:.0f} ms/step), layer time scaled "
-                      f"to {cfg.num_hidden_layers} layers; CPU restatement of reference semantics, not a reference CPU backend"}
+    return {"value": batch / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"torch-fp32 oracle of the WHOLE decode step ({nl} layers + lm_head + mask + argmax) for {batch} "
+                      f"sequences at ctx {ctx} (the headline batch is 256): {reps} steps timed, {dt * 1e3:.0f} ms/step, "
+                      "no extrapolation; CPU restatement of reference semantics, not a reference CPU backend"}
 
 
-def main():
-    a = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    # rehearsal mode for a 1-GPU box: every rank on cuda:0, collectives over gloo (functional check of
-    # the N>1 code path only; never used by the driver)
-    rehearsal = os.environ.get("MI_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        os.environ["VLLM_OMNI_AMD_TP_GRAPH"] = "0"  # gloo collectives are not capturable
-    dev = torch.device("cuda", 0 if rehearsal else local_rank)
-    torch.cuda.set_device(dev)
-
-    from vllm_omni_amd import ops
+def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bool):
+    """Build the runner of one (tp, dp) plan on this rank, warm up, time EXACTLY ``a.steps`` steps between barriers,
+    return (max-over-ranks seconds, runner, local batch)."""
     from vllm_omni_amd.distributed import init_distributed_environment
     from vllm_omni_amd.model_runner import GPUARModelRunner
-    from vllm_omni_amd.talker import TalkerConfig
 
-    cfg = TalkerConfig.from_json(a.config)
-    tp, dp, plabel = parallel_plan(world, cfg)
-    plan_info = None
-    if a.simulate_shard:
-        if world > 1:
-            raise SystemExit("--simulate-shard runs on one GPU")
-        from vllm_omni_amd.distributed import simulate_tensor_parallel_rank
-
-        tp, dp = (int(x) for x in a.simulate_shard.split(","))
-        plabel = f"SIMULATED rank 0 of dp{dp}xtp{tp}, collectives stubbed"
-        if tp > 1:
-            simulate_tensor_parallel_rank(tp)
-        a.no_cpu_baseline = True
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if not rehearsal:
-            dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
-        elif not dist.is_initialized():
-            dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
-        tp, dp, plabel, plan_info = choose_plan(world, rank, cfg, a, dev, probe=not rehearsal,
-                                                backend="gloo" if rehearsal else "nccl")
         init_distributed_environment(world, rank, tp, backend="gloo" if rehearsal else "nccl",
                                      device=None if rehearsal else dev)
-    if a.batch % dp:
-        raise SystemExit("global batch must divide by the data-parallel degree")
     local_batch = a.batch // dp
-
     max_model_len = a.ctx + a.block_size
     runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=local_batch, max_model_len=max_model_len,
                               max_num_batched_tokens=max(local_batch, 256), block_size=a.block_size,
                               kv_layout=a.kv_layout, enforce_eager=a.eager, seed=0, quantization=a.quantization,
-                              code_predictor=_code_predictor_config() if a.code_predictor else None)
+                              code_predictor=_code_predictor_config() if a.code_predictor else None,
+                              copy_outputs=False)   # views of the pinned output ring (DESIGN.md §4)
     runner.load_model()
     # every rank of a TP group must see the same schedule: seed by data-parallel replica only
     sched = SyntheticScheduler(local_batch, a.ctx, a.block_size, cfg.vocab_size, rank_seed=rank // tp)
@@ -375,16 +317,89 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = elapsed / a.steps * 1e3
-    tokens_per_s = a.batch * a.steps / elapsed
+    return elapsed, runner, local_batch
 
-    # ---- roofline of the dominant kernel (paged-attention decode), this rank ----
+
+def main():
+    a = parse_args()
+    launched = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not launched:
+        # no launcher around us: become one.  Nothing has touched the GPU yet (device_count() does not).
+        raise SystemExit(spawn_ranks(a.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # rehearsal mode for a 1-GPU box: every rank on cuda:0, collectives over gloo (functional check of
+    # the N>1 code path only; never used by the driver)
+    rehearsal = os.environ.get("MI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        os.environ["VLLM_OMNI_AMD_TP_GRAPH"] = "0"  # gloo collectives are not capturable
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
+    torch.cuda.set_device(dev)
+
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json(a.config)
+    plans = [(1, 1, "tp1", "headline")]
+    if a.simulate_shard:
+        if world > 1:
+            raise SystemExit("--simulate-shard runs on one GPU")
+        from vllm_omni_amd.distributed import simulate_tensor_parallel_rank
+
+        tp, dp = (int(x) for x in a.simulate_shard.split(","))
+        plans = [(tp, dp, f"SIMULATED rank 0 of dp{dp}xtp{tp}, collectives stubbed", "simulated")]
+        if tp > 1:
+            simulate_tensor_parallel_rank(tp)
+        a.no_cpu_baseline = True
+    n_ranks_seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not rehearsal:
+            dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        elif not dist.is_initialized():
+            dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+        # n_gpus is what the communicator saw, not what the command line asked for
+        one = torch.ones(1, device=dev if not rehearsal else "cpu")
+        dist.all_reduce(one)
+        n_ranks_seen = int(one.item())
+        plans = plans_to_run(world, cfg, a.batch)
+    for tp, dp, label, _ in plans:
+        if a.batch % dp:
+            raise SystemExit(f"global batch {a.batch} must divide by the data-parallel degree of {label}")
+
+    results = []
+    keep = None
+    for i, (tp, dp, label, role) in enumerate(plans):
+        elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal)
+        ms = elapsed / a.steps * 1e3
+        results.append({"parallelism": label, "role": role, "ms_per_step": round(ms, 3),
+                        "value": round(a.batch * a.steps / elapsed, 1), "hipgraph": bool(runner._graphs),
+                        "decode_partition": runner._decode_part, "tuned_gemm_csv_loaded": bool(getattr(runner, "tuned_gemms", False))})
+        if i == 0:
+            keep = (runner, local_batch, tp, elapsed)
+        else:
+            del runner
+            torch.cuda.empty_cache()
+    runner, local_batch, tp, elapsed = keep
+    head = results[0]
+    ms_per_step, tokens_per_s = head["ms_per_step"], head["value"]
+
+    # ---- roofline of the dominant kernel (paged-attention decode), this rank, headline plan ----
     attn = runner.model.language_model.model.layers[0].self_attn
     # unique KV bytes one launch must read: K+V, local kv heads, head_dim, 2 B, ctx tokens, local batch
     algo_bytes = 2 * attn.num_kv_heads * attn.head_dim * 2 * a.ctx * local_batch
+    if len(plans) > 1 and world > 1:   # the TP groups of the headline plan are the current ones again
+        from vllm_omni_amd.distributed import init_distributed_environment
+
+        init_distributed_environment(world, rank, tp, backend="gloo" if rehearsal else "nccl",
+                                     device=None if rehearsal else dev)
     kern_ms, launches = time_decode_launches(runner, a.roofline_steps)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     prof = os.path.join(ROOT, "profiles", "pmc_decode_bytes_per_launch.json")
     if os.path.exists(prof):
         try:
@@ -392,10 +407,13 @@ def main():
                 pj = json.load(f)
             if pj.get("batch") == local_batch and pj.get("ctx") == a.ctx and pj.get("tp") == tp:
                 traffic = pj.get("hbm_bytes_per_launch")
+                traffic_src = ("NOT measured in this run: rocprofv3 --pmc pass of the same command, "
+                               "profiles/pmc_decode_bytes_per_launch.json (" + str(pj.get("source", "")) + ")")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "mi::decode_mfma_kernel (paged-attention decode)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 4),
                 "launches_timed": launches,
                 "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
@@ -409,23 +427,27 @@ def main():
                    else f"decode tokens/s, {cfg.name}{' int8' if a.quantization else ''}"
                         f"{' + code predictor' if a.code_predictor else ''}, bs={a.batch} ctx={a.ctx} (not the headline shape)"),
         "value": round(tokens_per_s, 1),
-        "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "unit": "tokens/s", "n_gpus": n_ranks_seen, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16" if a.quantization is None else "bf16 (attention, norms, activations) + int8 W8A8 decoder linears",
         "data": "synthetic (random-init weights, N(0,1) KV cache, random non-contiguous block tables, fixed ctx)",
         "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
-                   "global_batch": a.batch, "seq_len": a.ctx, "parallelism": plabel,
-                   "hipgraph": bool(runner._graphs), "kv_layout": a.kv_layout,
+                   "global_batch": a.batch, "seq_len": a.ctx, "parallelism": head["parallelism"],
+                   "plan_role": head["role"],
+                   "hipgraph": head["hipgraph"], "kv_layout": a.kv_layout,
                    "output": "sync" if a.sync_output else "pipelined one step behind (all outputs on the host inside the timed region)",
-                   "decode_partition": runner._decode_part,
+                   "decode_partition": head["decode_partition"],
+                   "tuned_gemm_csv_loaded": head["tuned_gemm_csv_loaded"],
+                   "allreduce": os.environ.get("VLLM_OMNI_AMD_ALLREDUCE", "rccl") if tp > 1 else "none",
                    "linear": os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
                    + " (auto: hand-written streaming GEMM where measured faster than the TunableOp-selected library "
-                     "kernel, library GEMM elsewhere; same bf16 inputs, fp32 accumulation)",
-                   **({"plan_choice": plan_info} if plan_info else {})},
+                     "kernel, library GEMM elsewhere; same bf16 inputs, fp32 accumulation)"},
         "roofline": roofline,
     }
+    if len(results) > 1:
+        out["alt_plans"] = results[1:]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_batch, a.ctx, a.cpu_baseline_layers, a.block_size)
+        out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_batch, a.ctx, a.block_size)
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -22,12 +22,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto"):
+def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto", backend="gloo", graph=False):
     import sys
     for p in (ROOT, os.path.join(ROOT, "vllm-omni_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["VLLM_OMNI_AMD_TP_GRAPH"] = "0"
+    os.environ["VLLM_OMNI_AMD_TP_GRAPH"] = "1" if graph else "0"
     os.environ["VLLM_OMNI_AMD_LINEAR"] = linear_mode   # read when vllm_omni_amd.layers is imported (below)
     try:
         import numpy as np
@@ -38,16 +38,17 @@ def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto"):
         from vllm_omni_amd.sched_output import NewRequestData, Request, SamplingParams, SchedulerOutput
         from vllm_omni_amd.talker import TalkerConfig
 
-        dev = torch.device("cuda:0")
+        dev = torch.device("cuda", tp_rank if backend == "nccl" else 0)   # RCCL: one GPU per rank
         torch.cuda.set_device(dev)
         if tp_size > 1:
-            D.init_distributed_environment(tp_size, tp_rank, tp_size, backend="gloo",
-                                           init_method=f"tcp://127.0.0.1:{port}")
+            D.init_distributed_environment(tp_size, tp_rank, tp_size, backend=backend,
+                                           init_method=f"tcp://127.0.0.1:{port}",
+                                           device=dev if backend == "nccl" else None)
         cfg = TalkerConfig.from_json("mini_talker")
         cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.mrope_section = 128, 4, 2, None
         bs, nb = 16, 24
         runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=4, max_model_len=128,
-                                  max_num_batched_tokens=64, block_size=bs, enforce_eager=True, seed=0)
+                                  max_num_batched_tokens=64, block_size=bs, enforce_eager=not graph, seed=0)
         runner.load_model()
         w = ref_talker.random_weights(cfg, seed=5)           # identical FULL weights on every rank
         runner.model.load_weights({k: v.to(dev) for k, v in w.items()})
@@ -105,6 +106,37 @@ def test_tp2_matches_tp1(dev, linear_mode):
             for p in procs:
                 p.start()
             res = [q.get(timeout=240) for _ in procs]
+            for p in procs:
+                p.join(60)
+            assert sorted(res) == [(r, "ok") for r in range(tp)], res
+            results[tp] = torch.load(path)
+        a, b = results[1], results[2]
+        torch.testing.assert_close(b["hidden"], a["hidden"], rtol=3e-2, atol=3e-2)
+        top2 = a["logits"].topk(2, -1).values
+        conf = (top2[:, 0] - top2[:, 1]) > 0.1
+        for i in range(len(a["ids"])):
+            if conf[i]:
+                assert a["ids"][i] == b["ids"][i]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs on a multi-GPU node only")
+@pytest.mark.parametrize("graph", [False, True])
+def test_tp2_over_rccl_matches_tp1(graph):
+    """The same comparison with the collectives on RCCL over xGMI (backend "nccl"), one GPU per rank — eagerly and
+    with the all-reduces captured inside the decode step's hipGraph (the path bench.py --gpus N runs).  Skipped on
+    the one-GPU boxes; the driver's multi-GPU node runs it."""
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as tmp:
+        results = {}
+        for tp in (1, 2):
+            q = ctx.Queue()
+            port = _free_port()
+            path = os.path.join(tmp, f"tp{tp}.pt")
+            procs = [ctx.Process(target=_run_step, args=(r, tp, port, path, q, "auto", "nccl", graph)) for r in range(tp)]
+            for p in procs:
+                p.start()
+            res = [q.get(timeout=480) for _ in procs]
             for p in procs:
                 p.join(60)
             assert sorted(res) == [(r, "ok") for r in range(tp)], res

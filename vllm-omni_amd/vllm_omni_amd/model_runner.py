@@ -272,17 +272,43 @@ class AsyncOmniModelRunnerOutput:
 class GPUARModelRunner:
     OUT_SLOTS = 4   # ring of pinned output buffers: a step's hidden-state views live for OUT_SLOTS - 1 more steps
 
-    def __init__(self, config: TalkerConfig, device: torch.device, dtype: torch.dtype = torch.bfloat16,
-                 max_num_reqs: int = 256, max_model_len: int = 4096, max_num_batched_tokens: int = 8192,
-                 block_size: int = 16, kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: bool = False,
-                 engine_output_type: str = "latent", max_reply_rows: int = 0, seed: Optional[int] = 0,
-                 quantization: Optional[str] = None, code_predictor=None, copy_outputs: bool = True):
+    def __init__(self, config, device: torch.device, dtype: Optional[torch.dtype] = None,
+                 max_num_reqs: Optional[int] = None, max_model_len: Optional[int] = None,
+                 max_num_batched_tokens: Optional[int] = None, block_size: Optional[int] = None,
+                 kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: Optional[bool] = None,
+                 engine_output_type: Optional[str] = None, max_reply_rows: Optional[int] = None,
+                 seed: Optional[int] = 0, quantization: Optional[str] = None, code_predictor=None,
+                 copy_outputs: bool = True):
         """``copy_outputs``: hand every step's ``pooler_output`` tensors back as caller-owned host tensors, as the
         reference does (``hidden_states.to("cpu")``, gpu_ar_model_runner.py:835).  False returns VIEWS of the pinned
         output ring, valid until ``OUT_SLOTS - 1`` further steps have been sampled (what bench.py uses: fresh 1.8 MB
         host allocations every step were measured to stall the device queues)."""
+        from .compat import is_vllm_config, worker_config_from_vllm_config
         from .distributed import get_parallel_state
 
+        wc = None
+        if is_vllm_config(config):
+            # ``GPUARModelRunner(self.vllm_config, self.device)`` (gpu_ar_worker.py:102): everything else comes
+            # from the config object; explicit keyword arguments still win
+            self.vllm_config = config
+            wc = worker_config_from_vllm_config(config)
+            config = wc.model_config
+            quantization = quantization or wc.quantization
+            seed = wc.seed if seed == 0 else seed
+
+        def pick(explicit, from_cfg, default):
+            return explicit if explicit is not None else (from_cfg if wc is not None else default)
+
+        dtype = pick(dtype, wc and wc.dtype, torch.bfloat16)
+        max_num_reqs = pick(max_num_reqs, wc and wc.max_num_seqs, 256)
+        max_model_len = pick(max_model_len, wc and wc.max_model_len, 4096)
+        max_num_batched_tokens = pick(max_num_batched_tokens, wc and wc.max_num_batched_tokens, 8192)
+        block_size = pick(block_size, wc and wc.block_size, 16)
+        enforce_eager = pick(enforce_eager, wc and wc.enforce_eager, False)
+        engine_output_type = pick(engine_output_type, wc and wc.engine_output_type, "latent")
+        max_reply_rows = pick(max_reply_rows, wc and (wc.max_reply_rows or wc.max_num_seqs * 64), 0)
+        if not isinstance(config, TalkerConfig):
+            raise TypeError(f"GPUARModelRunner needs a VllmConfig-shaped object or a TalkerConfig, got {type(config).__name__}")
         self.config = config
         self.device = device
         self.dtype = dtype
@@ -743,6 +769,10 @@ class GPUARModelRunner:
     def execute_model(self, scheduler_output: SchedulerOutput, intermediate_tensors=None):
         if self.execute_model_state is not None:
             raise RuntimeError("State error: sample_tokens() must be called after execute_model() returns None.")
+        if not isinstance(scheduler_output, SchedulerOutput):   # upstream's / the reference's own type
+            from .compat import normalize_scheduler_output
+
+            scheduler_output = normalize_scheduler_output(scheduler_output)
         # an output whose host part is still pending may stay pending only across a pure steady-state decode step
         # (same requests, same rows, one token each): everything else reads the host-side token state
         if self._last_output is not None and not self._last_output.done and not self._steady_decode(scheduler_output):

@@ -368,34 +368,135 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
                 quantize_int8_(lin)
         self.quantization = "int8"
 
-    def load_weights(self, full: dict[str, torch.Tensor]) -> set[str]:
-        """Copy UNSHARDED weights (fused names as in ``named_weights``) into this rank's shards.  On a quantised
-        model the 16-bit shard of a linear is rebuilt, loaded and quantised again (online quantisation)."""
+    # checkpoint prefix -> parameter prefix: ``hf_to_vllm_mapper`` of the reference's talker classes
+    # (qwen2_5_omni_talker.py:46-56; Qwen3: qwen3_omni_moe_talker.py:83-98), first match wins
+    hf_to_vllm_prefix = (
+        ("talker.codec_head.", "language_model.lm_head."),
+        ("talker.model.", "language_model.model."),
+        ("talker.thinker_to_talker_proj.", "thinker_to_talker_proj."),
+        ("talker.", ""),
+    )
+    skip_prefixes = ("thinker.", "token2wav.", "code2wav.", "code_predictor.", "talker.code_predictor.")
+    # (fused parameter, checkpoint shard, shard id): ``stacked_params_mapping`` of qwen2_old.py:328-336
+    stacked_params_mapping = (
+        ("qkv_proj", "q_proj", "q"), ("qkv_proj", "k_proj", "k"), ("qkv_proj", "v_proj", "v"),
+        ("gate_up_proj", "gate_proj", 0), ("gate_up_proj", "up_proj", 1),
+    )
+
+    def _map_checkpoint_name(self, name: str) -> Optional[str]:
+        if name.startswith(self.skip_prefixes) or "rotary_emb.inv_freq" in name:
+            return None
+        for old, new in self.hf_to_vllm_prefix:
+            if name.startswith(old):
+                name = new + name[len(old):]
+                break
+        if name.startswith("codec_head."):          # Qwen3 keeps it apart; here it IS the LM head
+            name = "language_model.lm_head." + name[len("codec_head."):]
+        return name
+
+    def _shard_rows(self, fused_name: str, shard_id) -> tuple[int, int, int, int]:
+        """(dst row offset, rows, src row offset, src rows) of checkpoint shard ``shard_id`` inside this rank's
+        fused parameter ``fused_name`` — what upstream's per-parameter ``weight_loader(param, w, shard_id)`` does
+        for QKVParallelLinear / MergedColumnParallelLinear (head partition + KV replication, qwen2_old.py:89-102)."""
+        from .distributed import kv_head_for_rank, partition_heads
+
         cfg = self.config
         tp, r = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
-        loaded = set()
+        d = cfg.head_dim
+        if shard_id in ("q", "k", "v"):
+            nq, nkv, _ = partition_heads(cfg.num_attention_heads, cfg.num_key_value_heads, tp)
+            if shard_id == "q":
+                return 0, nq * d, r * nq * d, nq * d
+            kvr = kv_head_for_rank(cfg.num_key_value_heads, tp, r)
+            dst = nq * d + (0 if shard_id == "k" else nkv * d)
+            return dst, nkv * d, kvr.start * d, nkv * d
+        # gate (0) / up (1) halves of a merged column-parallel projection
+        if ".shared_expert." in fused_name:
+            inter, tp_, r_ = cfg.shared_expert_intermediate_size, 1, 0       # MoE weights are replicated
+        else:
+            inter, tp_, r_ = cfg.intermediate_size, tp, r
+        per = inter // tp_
+        return int(shard_id) * per, per, r_ * per, per
+
+    def load_weights(self, weights) -> set[str]:
+        """``load_weights(Iterable[(checkpoint name, tensor)])`` as the reference's model classes take it
+        (qwen2_5_omni_talker.py:183-211 -> qwen2_old.py:328-377): names go through the ``talker.`` prefix mapper,
+        separate ``q_proj`` / ``k_proj`` / ``v_proj`` and ``gate_proj`` / ``up_proj`` tensors are written into this
+        rank's slice of the fused ``qkv_proj`` / ``gate_up_proj`` parameters, every other tensor is TP-sharded by
+        its role; ``thinker.`` / ``token2wav.`` weights and ``rotary_emb.inv_freq`` are skipped.  Per-expert MoE
+        tensors (``mlp.experts.<e>.gate_proj|up_proj|down_proj.weight``) fill the stacked expert parameters.
+        Tensors are consumed one at a time (a safetensors iterator never holds the whole checkpoint).  A dict of
+        UNSHARDED tensors under this package's fused names (``named_weights``) is accepted as well.  On a
+        quantised model the 16-bit shard of a touched linear is rebuilt, loaded and quantised again (online
+        quantisation, int8_config.py:391-418).  Returns the parameter names that received data; a name that maps
+        to no parameter raises ``KeyError`` (the reference's ``params_dict[name]`` does)."""
+        import re
+
+        cfg = self.config
+        tp, r = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        items = weights.items() if isinstance(weights, dict) else weights
+        params = {n: t for n, t in self.named_weights() if t is not None}
         quantised = {n: lin for n, lin in self.linear_layers() if getattr(lin, "qweight", None) is not None}
-        for n, lin in quantised.items():
-            if n in full:
-                lin.weight = torch.empty(lin.qweight.shape, dtype=self.dtype, device=lin.qweight.device)
+        requantise = False
+        loaded: set[str] = set()
+        expert_re = re.compile(r"^(.*\.mlp\.experts)\.(\d+)\.(gate_proj|up_proj|down_proj)\.weight$")
+
+        def param(name: str) -> torch.Tensor:
+            nonlocal requantise
+            lin = quantised.get(name)
+            if lin is not None and lin.qweight is not None:     # first touch: back to a 16-bit shard
+                lin.weight = torch.zeros(lin.qweight.shape, dtype=self.dtype, device=lin.qweight.device)
                 lin.qweight = lin.weight_scale = None
-        for name, dst in self.named_weights():
-            if name not in full or dst is None:
+                params[name] = lin.weight
+                requantise = True
+            if name not in params:
+                raise KeyError(f"checkpoint tensor maps to no parameter of the talker: {name!r}")
+            return params[name]
+
+        for raw_name, w in items:
+            name = self._map_checkpoint_name(raw_name)
+            if name is None:
                 continue
-            w = full[name]
-            if ".mlp.experts." in name or ".mlp.shared_expert" in name or name.endswith(".mlp.gate.weight"):
-                pass   # MoE weights are replicated (tp_size 1)
-            elif name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
-                w = shard_qkv(w, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, tp, r)
-            elif name.endswith("gate_up_proj.weight"):
-                w = shard_merged_column(w, [cfg.intermediate_size] * 2, tp, r)
-            elif name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
-                w = shard_row(w, tp, r)
-            elif name.endswith("lm_head.weight"):
-                w = shard_column(w, tp, r)
-            dst.copy_(w.to(dst.dtype))
-            loaded.add(name)
-        if quantised:
+            if name in params or name in quantised:             # a full (unsharded) tensor under the parameter's own name
+                dst = param(name)
+                if ".mlp.experts." in name or ".mlp.shared_expert" in name or name.endswith(".mlp.gate.weight"):
+                    pass   # MoE weights are replicated (tp_size 1)
+                elif name.endswith("qkv_proj.weight") or name.endswith("qkv_proj.bias"):
+                    w = shard_qkv(w, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, tp, r)
+                elif name.endswith("gate_up_proj.weight"):
+                    w = shard_merged_column(w, [cfg.intermediate_size] * 2, tp, r)
+                elif name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+                    w = shard_row(w, tp, r)
+                elif name.endswith("lm_head.weight"):
+                    w = shard_column(w, tp, r)
+                dst.copy_(w.to(dst.dtype))
+                loaded.add(name)
+                continue
+            m = expert_re.match(name)
+            if m:                                                # per-expert checkpoint tensors -> stacked parameters
+                base, e, kind = m.group(1), int(m.group(2)), m.group(3)
+                if kind == "down_proj":
+                    dst = param(base + ".down_proj")
+                    dst[e].copy_(w.to(dst.dtype))
+                    loaded.add(base + ".down_proj")
+                else:
+                    dst = param(base + ".gate_up_proj")
+                    mi = cfg.moe_intermediate_size
+                    dst[e, (mi if kind == "up_proj" else 0):(2 * mi if kind == "up_proj" else mi)].copy_(w.to(dst.dtype))
+                    loaded.add(base + ".gate_up_proj")
+                continue
+            for param_name, shard_name, shard_id in self.stacked_params_mapping:
+                if shard_name not in name:
+                    continue
+                fused = name.replace(shard_name, param_name)
+                dst = param(fused)
+                d0, rows, s0, srows = self._shard_rows(fused, shard_id)
+                dst[d0:d0 + rows].copy_(w[s0:s0 + srows].to(dst.dtype))
+                loaded.add(fused)
+                break
+            else:
+                raise KeyError(f"checkpoint tensor maps to no parameter of the talker: {raw_name!r} -> {name!r}")
+        if requantise:
             self.quantize_int8()
         return loaded
 

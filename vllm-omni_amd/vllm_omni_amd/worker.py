@@ -36,12 +36,37 @@ class WorkerConfig:
     device_type: str = "cuda"
     distributed_backend: str = "nccl"
     seed: int = 0
+    quantization: Optional[str] = None        # None | "int8" (W8A8 decoder linears, int8_config.py)
+    dp_local_rank: int = 0                    # parallel_config.data_parallel_rank_local (gpu_ar_worker.py:40-60)
+    max_reply_rows: int = 0                   # device pool of thinker_reply_part rows; 0 = max_num_seqs * 64
+    code_predictor: object = None             # CodePredictorConfig for the Qwen3-Omni talker_mtp step
 
 
 class GPUARWorker:
-    def __init__(self, config: WorkerConfig, local_rank: int = 0, rank: int = 0,
-                 distributed_init_method: Optional[str] = None, is_driver_worker: bool = True):
+    """Constructed the way the reference constructs its workers: ``worker_cls(vllm_config=..., local_rank=...,
+    rank=..., distributed_init_method=..., is_driver_worker=...)`` (upstream ``Worker.__init__``; the class is named
+    by string, vllm_omni/engine/stage_init_utils.py:86-101).  ``vllm_config`` is any object with ``model_config``
+    (``hf_config``, dtype, max_model_len, ...), ``cache_config``, ``parallel_config``, ``scheduler_config`` on it
+    (mapped by ``compat.worker_config_from_vllm_config``); this package's own ``WorkerConfig`` is accepted too."""
+
+    def __init__(self, vllm_config=None, local_rank: int = 0, rank: int = 0,
+                 distributed_init_method: Optional[str] = None, is_driver_worker: bool = True, **kwargs):
+        from .compat import is_vllm_config, worker_config_from_vllm_config
+
+        if vllm_config is None:
+            vllm_config = kwargs.pop("config", None)
+        if isinstance(vllm_config, WorkerConfig):
+            config = vllm_config
+            self.vllm_config = None
+        elif is_vllm_config(vllm_config):
+            config = worker_config_from_vllm_config(vllm_config)
+            self.vllm_config = vllm_config
+        else:
+            raise TypeError("GPUARWorker needs a VllmConfig-shaped object (model_config / cache_config / "
+                            f"parallel_config / scheduler_config) or a WorkerConfig, got {type(vllm_config).__name__}")
         self.config = config
+        # DP_LOCAL_RANK * TP_PP_WORLD_SIZE + TP_LOCAL_RANK (gpu_ar_worker.py:40-60)
+        local_rank += config.dp_local_rank * config.tensor_parallel_size
         self.local_rank = local_rank
         self.rank = rank
         self.distributed_init_method = distributed_init_method
@@ -58,6 +83,9 @@ class GPUARWorker:
             raise RuntimeError(f"Not support device type: {self.config.device_type}")
         if not torch.cuda.is_available():
             raise RuntimeError("Not support device type: no ROCm GPU visible (the HIP kernels have no CPU path)")
+        if self.local_rank >= torch.cuda.device_count():
+            raise RuntimeError(f"DP adjusted local rank {self.local_rank} is out of bounds "
+                               f"({torch.cuda.device_count()} visible devices)")
         self.device = torch.device("cuda", self.local_rank)
         torch.cuda.set_device(self.device)
         from .platform import MI355XOmniPlatform
@@ -74,10 +102,17 @@ class GPUARWorker:
             max_model_len=self.config.max_model_len, max_num_batched_tokens=self.config.max_num_batched_tokens,
             block_size=self.config.block_size, kv_layout=self.config.kv_layout,
             enforce_eager=self.config.enforce_eager, engine_output_type=self.config.engine_output_type,
-            seed=self.config.seed)
+            seed=self.config.seed, quantization=self.config.quantization,
+            max_reply_rows=self.config.max_reply_rows or self.config.max_num_seqs * 64,
+            code_predictor=self.config.code_predictor)
 
-    def load_model(self) -> None:
+    def load_model(self, weights=None) -> None:
+        """Build the model on the device; ``weights`` (an iterable of ``(checkpoint name, tensor)``, e.g. a
+        safetensors iterator) is streamed through ``model.load_weights`` — without it the weights are random-init
+        (this package ships no checkpoint loader: upstream's ``get_model_loader`` feeds the same iterable)."""
         self.model_runner.load_model()
+        if weights is not None:
+            self.model_runner.model.load_weights(weights)
 
     def get_model(self):
         return self.model_runner.get_model()
