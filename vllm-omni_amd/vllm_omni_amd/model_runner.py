@@ -581,21 +581,23 @@ class GPUARModelRunner:
         num_decodes = int((num_sched == 1).sum())
         return n, total, num_sched, max_seq_len, num_decodes
 
-    def _commit_inputs(self, n: int, total: int, padded: int):
-        """Host -> device copies of the step's index arrays.  ``padded`` > n (graph replay at a bucketed batch size,
-        pure decode): the tail rows [n, padded) are inert — seq_len 0 (the decode kernel writes zeros and dereferences
-        no block-table entry), slot -1 (no KV write), position 0."""
+    def _commit_inputs(self, n: int, total: int, padded_reqs: int = 0):
+        """Host -> device copies of the step's index arrays.  ``padded_reqs`` > n (graph replay at a bucketed batch
+        size; pure decode, so tokens == requests): the tail rows [n, padded_reqs) are inert — seq_len 0 (the decode
+        kernel writes zeros and dereferences no block-table entry), slot -1 (no KV write), position 0."""
         ib = self.input_batch
-        if padded > n:
-            self.positions.np[total:padded] = 0
-            self.seq_lens.np[n:padded] = 0
-            self.query_start_loc.np[n + 1:padded + 1] = total + np.arange(1, padded - n + 1)
-        self.positions.copy_to_gpu(max(total, padded))
-        self.seq_lens.copy_to_gpu(max(n, padded))
-        self.query_start_loc.copy_to_gpu(max(n, padded) + 1)
+        m = max(n, padded_reqs)
+        if m > n:
+            assert total == n, "only pure-decode batches are padded"
+            self.positions.np[n:m] = 0
+            self.seq_lens.np[n:m] = 0
+            self.query_start_loc.np[n + 1:m + 1] = n + np.arange(1, m - n + 1)
+        self.positions.copy_to_gpu(total + (m - n))
+        self.seq_lens.copy_to_gpu(m)
+        self.query_start_loc.copy_to_gpu(m + 1)
         self.logits_indices.copy_to_gpu(n)
         ib.block_table.commit_block_table(n)
-        ib.block_table.commit_slot_mapping(total, max(total, padded))
+        ib.block_table.commit_slot_mapping(total, total + (m - n))
 
     def _build_metadata(self, n, total, max_query_len, max_seq_len_bound, num_decodes) -> AttentionMetadata:
         bt = self.input_batch.block_table[0]
@@ -803,7 +805,7 @@ class GPUARModelRunner:
             g.replay()
             hidden, logits, ids = outs["hidden"], outs["logits"], outs["ids"]
         else:
-            self._commit_inputs(n, total, total)
+            self._commit_inputs(n, total)
             self._preprocess_embeds(n, total, num_sched, num_decodes)
             if self._h2d_done is not None:
                 self._h2d_done.record()
