@@ -379,6 +379,47 @@ int mi_linear_silu_mul(void* out, const void* x, const void* weight, int32_t m, 
 
 
 /* ------------------------------------------------------------------------
+ * A12 — tensor-parallel all-reduce for decode-sized messages (SURVEY §8b export
+ * list, §8e).  Replaces the all-reduce implicit in upstream `RowParallelLinear`
+ * for o_proj / down_proj (vllm_omni/model_executor/models/qwen2_5_omni/
+ * qwen2_old.py:54-60,118-124) on the group created at
+ * vllm_omni/worker/gpu_ar_worker.py:69-75.  One process per GPU; two-shot
+ * (reduce-scatter + all-gather) over IPC-mapped peer buffers, every rank
+ * reading every peer directly (all xGMI links at once), fp32 accumulation in
+ * RANK ORDER (bit-identical on every rank and run to run), one rounding.  The
+ * launch is in-stream, carries no per-call value and replays from a hipGraph;
+ * every spin is bounded (timeout -> mi_allreduce_status() != MI_OK, no hang).
+ *   mi_allreduce_init             allocates this rank's shared region (flags +
+ *       staging + tmp, uncached device memory sized for max_bytes messages) and
+ *       writes its 64-byte IPC handle to ipc_handle_out.  The HOST exchanges
+ *       the handles (any channel: torch.distributed all_gather, a file, ...).
+ *   mi_allreduce_register_buffer  ipc_handles = world x 64 bytes in rank order
+ *       (this rank's own entry is ignored): opens the peers' regions.  Collective
+ *       in effect: every rank must have called init before any rank runs.
+ *   mi_allreduce_run              out[count] = sum over ranks of in[count]
+ *       (dtype bf16 / f16, count % 8 == 0, 16-byte aligned; out may alias in).
+ *       split > 0: `in` is the fp32 split-K partials [split][count] of
+ *       mi_linear_partials and the value entering the all-reduce is
+ *       rnd(sum over slices in order (+ bias[col], cols = row length)) — what
+ *       mi_linear_reduce would have stored — so a row-parallel projection needs
+ *       no reduce launch of its own.  Every rank must issue the same sequence
+ *       of calls (same count).  MI_ERR_WORKSPACE if the message exceeds max_bytes.
+ *   mi_allreduce_status           host-side, synchronising: MI_ERR_STATE once any
+ *       spin has timed out (sticky).
+ *   mi_allreduce_destroy          closes the peer mappings, frees the region.
+ * ---------------------------------------------------------------------- */
+#define MI_ALLREDUCE_MAX_RANKS 8
+#define MI_ALLREDUCE_HANDLE_BYTES 64
+typedef struct mi_allreduce mi_allreduce;
+int mi_allreduce_init(mi_allreduce** out, int32_t rank, int32_t world, int64_t max_bytes,
+                      int32_t timeout_ms, void* ipc_handle_out);
+int mi_allreduce_register_buffer(mi_allreduce* ar, const void* ipc_handles);
+int mi_allreduce_run(mi_allreduce* ar, void* out, const void* in, int64_t count, int32_t split,
+                     const void* bias, int64_t cols, int dtype, void* stream);
+int mi_allreduce_status(mi_allreduce* ar);
+int mi_allreduce_destroy(mi_allreduce* ar);
+
+/* ------------------------------------------------------------------------
  * A1 — KV block pool (host side, no GPU).  The allocator underneath the
  * `KVCacheManager`-shaped façade the schedulers call
  * (vllm_omni/core/sched/omni_ar_scheduler.py:183-193,480,528,628;

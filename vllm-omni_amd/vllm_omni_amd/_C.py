@@ -21,6 +21,7 @@ ABI_VERSION = 1
 MI_DECODE_PACKED_PV = 1
 MI_DECODE_FORCE_VALU = 2
 MI_DECODE_NONTEMPORAL = 4
+MI_ALLREDUCE_MAX_RANKS, MI_ALLREDUCE_HANDLE_BYTES = 8, 64
 
 # name -> (restype, argtypes); mirrors include/vllm_omni_amd.h declaration by declaration
 _P = c_void_p
@@ -76,6 +77,11 @@ SIGNATURES = {
     "mi_dynamic_int8_quant": (c_int, [_P, _P, _P, c_int32, c_int32, c_int64, c_int, _P]),
     "mi_int8_gemm_dequant": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64,
                                       c_int, _P]),
+    "mi_allreduce_init": (c_int, [POINTER(c_void_p), c_int32, c_int32, c_int64, c_int32, _P]),
+    "mi_allreduce_register_buffer": (c_int, [_P, _P]),
+    "mi_allreduce_run": (c_int, [_P, _P, _P, c_int64, c_int32, _P, c_int64, c_int, _P]),
+    "mi_allreduce_status": (c_int, [_P]),
+    "mi_allreduce_destroy": (c_int, [_P]),
     "mi_blockpool_create": (_P, [c_int32]),
     "mi_blockpool_destroy": (None, [_P]),
     "mi_blockpool_num_free": (c_int32, [_P]),

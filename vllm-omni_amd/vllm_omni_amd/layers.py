@@ -19,8 +19,9 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
-                          tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
+from .distributed import (get_parallel_state, get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                          tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce,
+                          tensor_model_parallel_all_reduce_partials)
 from .kv_cache import normalize_layer_kv
 
 
@@ -424,10 +425,16 @@ class RowParallelLinear:
     def __call__(self, x: torch.Tensor, defer_reduce: bool = False):
         # bias is added once (rank 0) so the all-reduced sum carries it exactly once
         # defer_reduce (no TP only: an all-reduce needs the 16-bit tensor): the caller hands y to a fused-add RMSNorm
-        defer = defer_reduce and self.tp_size == 1
+        # TP > 1 with the in-tree all-reduce: its copy-in phase takes the split-K partials directly (same trick)
+        custom = self.tp_size > 1 and self.reduce_results and get_parallel_state().custom_ar is not None
+        defer = (defer_reduce and self.tp_size == 1) or custom
         y = _apply_linear(self, x, self.bias if self.tp_rank == 0 else None, defer)
         if self.reduce_results and self.tp_size > 1:
-            y = tensor_model_parallel_all_reduce(y)
+            if isinstance(y, ops.SplitKPartials):
+                r = tensor_model_parallel_all_reduce_partials(y)
+                y = r if r is not None else tensor_model_parallel_all_reduce(y.materialize())
+            else:
+                y = tensor_model_parallel_all_reduce(y)
         return y, None
 
 
