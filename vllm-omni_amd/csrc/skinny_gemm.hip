@@ -282,6 +282,269 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   }
 }
 
+// ======================================================================================================= v2 (129-256 rows)
+// Same data layout and LDS image as the kernel above; what changes is WHO does what and how the waves meet:
+//   * 8 consumer waves + 4 loader waves = 3 waves on every SIMD (a workgroup's waves go to the SIMDs cyclically, so
+//     waves c and c + 4 share one): each SIMD runs the same MFMA count per step.  The kernel above ran 10 consumers
+//     + 2 loaders: two SIMDs carried 3 consumers, two carried 2 — its matrix-pipe floor was the 3-consumer SIMDs
+//     (1536 cycles per step on the 160-row tile against 1280 here).
+//   * a consumer owns (a half of the tile's 16-row weight groups) x (a quarter of the 16 m-tiles): 18 fragment reads
+//     for 40 MFMAs per step instead of 20 for 32 (LDS read traffic per CU and step: 144 KB against 200 KB).
+//     Gated form, 160-row tile (5 gate/up pairs): waves 0-3 take 3 pairs, waves 4-7 two — every SIMD gets one of
+//     each, and the SiLU-gate epilogue stays lane-local.
+//   * no s_barrier in the loop.  Per ring slot a FULL word per loader wave and a FREE word per consumer wave, in
+//     LDS, holding step numbers (monotonic, never reset): a loader publishes FULL once its pieces of the step have
+//     landed (counted vmcnt) and refills a slot once every consumer has published FREE for the step that used it; a
+//     consumer publishes FREE as soon as the step's fragments are in registers — before its MFMAs.  Waves drift
+//     apart instead of meeting once per step: one wave's fragment reads overlap its SIMD partner's MFMAs
+//     (MI355X_MICROARCH.md, price list row ring-gemm).  Spins are bounded.
+constexpr int kV2Loaders = 4, kV2Consumers = 8;
+constexpr uint32_t kSpinBound = 1u << 24;
+
+__device__ __forceinline__ u32x4_t lds_poll128(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_store32(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// NW weight fragments (one per 16-row group) + the 4 m-tile fragments of one k-step, and their wait, in ONE statement
+template <int NW>
+__device__ __forceinline__ void lds_read_wx(uint32_t aw, uint32_t ax, u32x4_t (&w)[NW], u32x4_t (&x)[4]);
+#define MI_RD(i, base, off) "ds_read_b128 %" #i ", %" #base " offset:" #off "\n\t"
+template <>
+__device__ __forceinline__ void lds_read_wx<4>(uint32_t aw, uint32_t ax, u32x4_t (&w)[4], u32x4_t (&x)[4]) {
+  asm volatile(MI_RD(0, 8, 0) MI_RD(4, 9, 0) MI_RD(1, 8, 2048) MI_RD(5, 9, 2048) MI_RD(2, 8, 4096) MI_RD(6, 9, 4096)
+               MI_RD(3, 8, 6144) MI_RD(7, 9, 6144) "s_waitcnt lgkmcnt(0)"
+               : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+               : "v"(aw), "v"(ax)
+               : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_wx<5>(uint32_t aw, uint32_t ax, u32x4_t (&w)[5], u32x4_t (&x)[4]) {
+  asm volatile(MI_RD(0, 9, 0) MI_RD(5, 10, 0) MI_RD(1, 9, 2048) MI_RD(6, 10, 2048) MI_RD(2, 9, 4096) MI_RD(7, 10, 4096)
+               MI_RD(3, 9, 6144) MI_RD(8, 10, 6144) MI_RD(4, 9, 8192) "s_waitcnt lgkmcnt(0)"
+               : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]),
+                 "=&v"(x[3])
+               : "v"(aw), "v"(ax)
+               : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_wx<6>(uint32_t aw, uint32_t ax, u32x4_t (&w)[6], u32x4_t (&x)[4]) {
+  asm volatile(MI_RD(0, 10, 0) MI_RD(6, 11, 0) MI_RD(1, 10, 2048) MI_RD(7, 11, 2048) MI_RD(2, 10, 4096) MI_RD(8, 11, 4096)
+               MI_RD(3, 10, 6144) MI_RD(9, 11, 6144) MI_RD(4, 10, 8192) MI_RD(5, 10, 10240) "s_waitcnt lgkmcnt(0)"
+               : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(x[0]), "=&v"(x[1]),
+                 "=&v"(x[2]), "=&v"(x[3])
+               : "v"(aw), "v"(ax)
+               : "memory");
+}
+#undef MI_RD
+
+// G: 16-row weight groups per tile (10 = 160 rows, 8 = 128 rows); G0: groups of consumer waves 0-3 (waves 4-7 take G - G0)
+template <typename Tag, int G, int G0, bool GATED>
+struct V2 {
+  static constexpr int MT = 16;
+  static constexpr int TR = 16 * G;
+  static constexpr int kXBytes = MT * 2048;
+  static constexpr int kStage = kXBytes + TR * 128;
+  static constexpr int NST = 3;
+  static constexpr int XI = MT * 2, PIECES = XI + TR / 8;
+  static constexpr int PPL = PIECES / kV2Loaders;
+  static constexpr int kFlags = NST * kStage;                     // FULL[NST][4] then FREE[NST][8]
+  static constexpr int kLds = kFlags + NST * (4 + 8) * 4;
+  static_assert(PIECES % kV2Loaders == 0 && PPL <= 31, "equal shares; two steps of pieces must fit vmcnt");
+  static_assert(kLds <= 160 * 1024, "the ring must fit the LDS");
+  static_assert(!GATED || (G0 % 2 == 0 && G % 2 == 0), "gate/up pairs are not split between the wave halves");
+
+  // one consumer wave: NG weight groups starting at group g_lo, m-tiles 4 mq .. 4 mq + 3
+  template <int NG>
+  static __device__ __forceinline__ void consume(const SkinnyParams& p, char* smem, int c, int g_lo, int mq, int tile, int s,
+                                                 int n_it) {
+    using E = Elem<Tag>;
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    uint32_t frag[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) frag[u] = lds0 + r16 * 128 + ((kperm(u, kg) ^ (r16 >> 1)) << 4);
+    const uint32_t x_off = mq * (4 * 2048), w_off = kXBytes + g_lo * 2048;
+    const uint32_t full0 = lds0 + kFlags, free0 = lds0 + kFlags + NST * 16;
+    f32x4_t acc[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[g][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int stage = 0;
+    for (int it = 0; it < n_it; ++it) {
+      // FULL: every loader's pieces of step `it` have landed
+      const uint32_t want = (uint32_t)it + 1;
+      for (uint32_t spin = 0; spin < kSpinBound; ++spin) {
+        const u32x4_t f = lds_poll128(full0 + stage * 16);
+        if (f[0] >= want && f[1] >= want && f[2] >= want && f[3] >= want) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!(p.dbg & 2)) {
+        const uint32_t base = stage * kStage;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          u32x4_t a[NG], b[4];
+          lds_read_wx<NG>(frag[u] + base + w_off, frag[u] + base + x_off, a, b);
+          // FREE as soon as the step's last fragment is in registers: the loaders may refill the slot during the MFMAs
+          if (u == 1 && lane == 0) lds_store32(free0 + (stage * 8 + c) * 4, want);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g][i] = mma<Tag>(a[g], b[i], acc[g][i]);
+        }
+      } else if (lane == 0) {
+        lds_store32(free0 + (stage * 8 + c) * 4, want);
+      }
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    }
+    if (p.dbg & 8) return;
+    if constexpr (GATED) {
+      // groups come in (gate, up) pairs of the same 16 output columns: acc[2q] = gate, acc[2q + 1] = up
+      constexpr int CT = 8 * G;   // output columns per tile
+#pragma unroll
+      for (int q = 0; q < NG / 2; ++q) {
+        const int n = tile * CT + 8 * g_lo + 16 * q + 4 * kg;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * (4 * mq + i) + r16;
+          if (m >= p.M) continue;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gt = E::from_bits(E::to_bits(acc[2 * q][i][r])), up = E::from_bits(E::to_bits(acc[2 * q + 1][i][r]));
+            v[r] = gt / (1.f + __expf(-gt)) * up;
+          }
+          uint2 o;
+          o.x = E::pack(v[0], v[1]);
+          o.y = E::pack(v[2], v[3]);
+          *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int n = tile * TR + 16 * (g_lo + g) + 4 * kg;
+        if (n >= p.N) continue;   // N % 16 == 0: a row group is all in or all out
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.S == 1 && p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = E::from_bits(p.bias[n + r]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * (4 * mq + i) + r16;
+          if (m >= p.M) continue;
+          if (p.S == 1) {
+            uint2 o;
+            o.x = E::pack(acc[g][i][0] + bv[0], acc[g][i][1] + bv[1]);
+            o.y = E::pack(acc[g][i][2] + bv[2], acc[g][i][3] + bv[3]);
+            *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = o;
+          } else {
+            *reinterpret_cast<f32x4_t*>(p.part + ((int64_t)s * p.M + m) * p.N + n) = acc[g][i];
+          }
+        }
+      }
+    }
+  }
+};
+
+template <typename Tag, int G, int G0, bool GATED>
+__global__ __launch_bounds__(64 * (kV2Consumers + kV2Loaders)) void skinny_gemm_v2_kernel(const SkinnyParams p) {
+  using C = V2<Tag, G, G0, GATED>;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int s = wg % p.S, tile = wg / p.S;
+  const int nb = p.K >> 6;
+  const int b_lo = (int)((int64_t)s * nb / p.S), b_hi = (int)((int64_t)(s + 1) * nb / p.S);
+  const int n_it = b_hi - b_lo;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+  // the flag words start at zero: before any DMA is in flight, so a plain barrier is harmless here
+  if (tid < C::NST * 12) lds_store32(lds0 + C::kFlags + tid * 4, 0u);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  if (wid >= kV2Consumers) {
+    // ------------------------------------------------------------------ loader
+    const int l = wid - kV2Consumers;
+    if (MI_SKINNY_LOADER_PRIO) __builtin_amdgcn_s_setprio(MI_SKINNY_LOADER_PRIO);
+    const int drow = lane >> 3, dpc = lane & 7;
+    const char* src[C::PPL];
+#pragma unroll
+    for (int i = 0; i < C::PPL; ++i) {
+      const int q = l + kV2Loaders * i;            // piece: image rows 8 q .. 8 q + 7
+      const int row = 8 * q + drow;
+      const int lc = dpc ^ ((row >> 1) & 7);
+      if (q < C::XI) {
+        const int m = row < p.M ? row : p.M - 1;   // rows past M repeat the last one; never stored
+        src[i] = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + 64 * (int64_t)b_lo + 8 * lc);
+      } else {
+        const int r = row - 16 * C::MT;            // row of the weight image
+        int n;
+        if constexpr (GATED) {   // group 2 q = 16 gate rows, group 2 q + 1 = the up rows of the same 16 columns
+          int col = tile * (8 * G) + 16 * (r >> 5) + (r & 15);
+          col = col < p.N ? col : p.N - 1;
+          n = ((r >> 4) & 1) * p.N + col;
+        } else {
+          n = tile * C::TR + r;
+          n = n < p.N ? n : p.N - 1;
+        }
+        src[i] = reinterpret_cast<const char*>(p.w + (int64_t)n * p.K + 64 * (int64_t)b_lo + 8 * lc);
+      }
+    }
+    auto issue = [&](int it, int stage) {
+      char* st = smem + stage * C::kStage;
+#pragma unroll
+      for (int i = 0; i < C::PPL; ++i) {
+        if (l + kV2Loaders * i < C::XI)
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it),
+                                           (lds_void*)(st + (l + kV2Loaders * i) * 1024), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it),
+                                           (lds_void*)(st + (l + kV2Loaders * i) * 1024), 16, 0, MI_SKINNY_W_AUX);
+      }
+    };
+    const uint32_t full0 = lds0 + C::kFlags, free0 = lds0 + C::kFlags + C::NST * 16;
+    if (n_it > 0 && !(p.dbg & 1)) issue(0, 0);
+    if (n_it > 1 && !(p.dbg & 1)) issue(1, 1);
+    int stage = 0;   // stage of step `it`
+    for (int it = 0; it < n_it; ++it) {
+      if (it + 1 < n_it) wait_vmcnt<C::PPL>();   // step `it` landed; step it + 1 may still be in flight
+      else wait_vmcnt<0>();
+      if (lane == 0) lds_store32(full0 + (stage * 4 + l) * 4, (uint32_t)it + 1);
+      if (it + 2 < n_it) {
+        // step it + 2 goes into the slot of step it - 1: every consumer must have its fragments of that step
+        const int st2 = stage == 0 ? C::NST - 1 : stage - 1;
+        if (it >= 1) {
+          const uint32_t want = (uint32_t)it;
+          for (uint32_t spin = 0; spin < kSpinBound; ++spin) {
+            const u32x4_t f0 = lds_poll128(free0 + st2 * 32), f1 = lds_poll128(free0 + st2 * 32 + 16);
+            if (f0[0] >= want && f0[1] >= want && f0[2] >= want && f0[3] >= want && f1[0] >= want && f1[1] >= want &&
+                f1[2] >= want && f1[3] >= want)
+              break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (!(p.dbg & 1)) issue(it + 2, st2);
+      }
+      stage = stage == C::NST - 1 ? 0 : stage + 1;
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- consumer: (half of the groups) x (quarter of the m-tiles)
+  const int c = wid, half = c >> 2, mq = c & 3;
+  if (half == 0) C::template consume<G0>(p, smem, c, 0, mq, tile, s, n_it);
+  else C::template consume<G - G0>(p, smem, c, G0, mq, tile, s, n_it);
+}
+
 template <typename Tag>
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(uint16_t* __restrict__ out, const float* __restrict__ part,
                                                             const uint16_t* __restrict__ bias, int M, int N, int S,
