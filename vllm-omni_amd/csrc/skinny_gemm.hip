@@ -606,7 +606,34 @@ SkinnyPlan skinny_plan(int m, int n, int k, int force_split) {
 namespace mi {
 namespace {
 
+int linear_v2() {   // MI_LINEAR_V2=0: the first-generation kernel at 129-256 rows too (A/B runs; read per call)
+  const char* e = getenv("MI_LINEAR_V2");
+  return e ? atoi(e) : 1;
+}
+
+template <typename Tag, int G, int G0, bool GATED>
+int launch_v2(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
+  using C = V2<Tag, G, G0, GATED>;
+  auto kern = skinny_gemm_v2_kernel<Tag, G, G0, GATED>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
+  if (attr != hipSuccess) return MI_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (kV2Consumers + kV2Loaders)), C::kLds, s, p);
+  return launch_status();
+}
+
 int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int dtype, hipStream_t s) {
+  if (pl.mt == 16 && linear_v2() && (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16)) {
+    const dim3 g2(pl.tiles * pl.split);
+#define MI_V2(TAG)                                                                            \
+    do {                                                                                      \
+      if (pl.nslab == 5) return gated ? launch_v2<TAG, 10, 6, true>(p, g2, s) : launch_v2<TAG, 10, 5, false>(p, g2, s); \
+      return gated ? launch_v2<TAG, 8, 4, true>(p, g2, s) : launch_v2<TAG, 8, 4, false>(p, g2, s);                     \
+    } while (0)
+    if (dtype == MI_DTYPE_BF16) MI_V2(bf16_tag);
+    else MI_V2(f16_tag);
+#undef MI_V2
+  }
   const dim3 grid(pl.tiles * pl.split);
 #define MI_SKINNY(TAG, NSLAB, MT, MH, NL, GATED)                                                                  \
   do {                                                                                                            \
@@ -643,12 +670,9 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
   return launch_status();
 }
 
-int linear_dbg() {   // MI_LINEAR_DBG: timing experiments only (see SkinnyParams::dbg)
-  static const int v = [] {
-    const char* e = getenv("MI_LINEAR_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
+int linear_dbg() {   // MI_LINEAR_DBG: timing experiments only (see SkinnyParams::dbg); read per call
+  const char* e = getenv("MI_LINEAR_DBG");
+  return e ? atoi(e) : 0;
 }
 
 }  // namespace
