@@ -328,6 +328,31 @@ int mi_dynamic_int8_quant(int8_t* xq, float* x_scale, const void* x, int32_t num
 int mi_int8_gemm_dequant(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq,
                          const float* w_scale, const void* bias, int32_t m, int32_t n,
                          int32_t k, int64_t out_row_stride, int dtype, void* stream);
+/* The activation quantisation fused into the op that produces the activation, and its vectorised stand-alone form.
+ * mi_rms_norm_int8: RMSNorm (residual == NULL) or fused residual-add RMSNorm (residual updated in place, x NOT
+ * modified) whose output leaves as int8 [T, hidden] + fp32 scale [T] — bit-identical to mi_rms_norm /
+ * mi_fused_add_rms_norm followed by mi_dynamic_int8_quant (qwen2_old.py:212-216 + int8_config.py:323-342), one
+ * launch.  mi_int8_quant_rows: mi_dynamic_int8_quant with 16-byte loads, rows <= 24576 elements. */
+int mi_rms_norm_int8(int8_t* xq, float* x_scale, const void* x, void* residual, const void* weight, float eps,
+                     int32_t num_tokens, int32_t hidden, int64_t x_token_stride, int64_t residual_token_stride,
+                     int dtype, void* stream);
+int mi_int8_quant_rows(int8_t* xq, float* x_scale, const void* x, int32_t num_tokens, int32_t hidden,
+                       int64_t x_token_stride, int dtype, void* stream);
+/* The tiled W8A8 kernel (csrc/skinny_gemm.hip instantiated on int8 rows: LDS-DMA ring, v_mfma_i32_16x16x64_i8,
+ * dequantisation + bias in the epilogue, ONE launch per linear — two with split-K): out[m, n] =
+ * (sum_k xq[m, k] * wq[n, k]) * x_scale[m] * w_scale[n] (+ bias[n]); int32 sums are exact.  m <= 512,
+ * k % 128 == 0, n % 16 == 0, x_row_stride (bytes == elements) % 16 == 0.  Replaces `Int8LinearMethod.apply`
+ * (vllm_omni/quantization/int8_config.py:323-342).  mi_int8_linear_silu_mul: gate_up_proj + SiluAndMul in one
+ * launch — wq [2 * inter, k] (gate rows, then up rows), w_scale [2 * inter]; each dequantised GEMM output is
+ * rounded to the 16-bit type before the activation, as the unfused pair rounds.  MI_ERR_UNSUPPORTED outside the
+ * envelope (callers use mi_int8_gemm_dequant). */
+int64_t mi_int8_linear_workspace_bytes(int32_t m, int32_t n, int32_t k);
+int mi_int8_linear(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq, const float* w_scale,
+                   const void* bias, int32_t m, int32_t n, int32_t k, int64_t x_row_stride,
+                   int64_t out_row_stride, void* workspace, int64_t workspace_bytes, int dtype, void* stream);
+int mi_int8_linear_silu_mul(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq,
+                            const float* w_scale, int32_t m, int32_t inter, int32_t k, int64_t x_row_stride,
+                            int64_t out_row_stride, int dtype, void* stream);
 /* Dequant epilogue alone, for an int32 accumulator produced by a library int8 GEMM (hipBLASLt through
  * torch._int_mm): out[m, n] = acc[m, n] * x_scale[m] * w_scale[n] (+ bias[n]).  n % 4 == 0. */
 int mi_int8_dequant(void* out, const int32_t* acc, const float* x_scale, const float* w_scale,

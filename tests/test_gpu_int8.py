@@ -92,3 +92,119 @@ def test_int8_linear_library_and_mfma_paths_agree_exactly(dev, M, N, K, bias):
     assert torch.equal(wq.cpu(), eq) and torch.equal(ws.cpu(), es)
     exp = ref_ops.int8_linear(x.float(), eq, es, b)
     torch.testing.assert_close(got.cpu().float(), exp, rtol=1e-2, atol=1e-2)
+
+
+TILED = [
+    # (m, n, k, bias): S-A projections at batch 256 (qkv with bias; down_proj = split-K with exact int32 partials), the
+    # S-B layer at config #5's batch 512 (two row blocks per weight tile), ragged edges
+    (256, 4608, 3584, True), (256, 3584, 3584, False), (256, 3584, 18944, False), (256, 37888, 3584, False),
+    (512, 1280, 1024, True), (512, 1024, 1024, False), (512, 1024, 384, True), (300, 768, 1024, False),
+    (1, 64, 128, True), (17, 96, 256, False), (100, 160, 128, True), (129, 2048, 2048, True), (64, 3584, 18944, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,bias", TILED)
+def test_tiled_int8_kernel_is_exact(dev, M, N, K, bias, dtype):
+    """mi_int8_linear (LDS-DMA ring, v_mfma_i32_16x16x64_i8, dequant epilogue; both kernel generations, split-K with
+    int32 partials, M up to 512) against the exact integer contraction: int32 sums are exact, so the result must
+    equal exact-int32 x scales (+ bias) rounded once — and the simple MFMA kernel bit for bit."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    xq = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int32).to(torch.int8)
+    wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int32).to(torch.int8)
+    xs = torch.rand(M, generator=g) * 0.05 + 1e-3
+    ws = torch.rand(N, generator=g) * 0.01 + 1e-4
+    b = torch.randn(N, generator=g).to(dtype) if bias else None
+    dq = lambda t: None if t is None else t.to(dev)  # noqa: E731
+    got = ops.int8_linear_q(dq(xq), dq(xs), dq(wq), dq(ws), dq(b), dtype).cpu()
+    simple = ops.int8_gemm_dequant(dq(xq), dq(xs), dq(wq), dq(ws), dq(b), dtype).cpu()
+    assert torch.equal(got, simple), f"max diff {(got.float() - simple.float()).abs().max()}"
+    if M * N * K <= 1 << 31:                                   # exact int32 reference on the host where it is cheap
+        acc = xq.to(torch.int32) @ wq.to(torch.int32).t()
+        # the kernels spell the dequantisation as fma(rnd(acc * xs), ws, b) (csrc/common.h dequant_i32): in float64 the
+        # fma is exact up to its single rounding, so this host expression has the same bits except at double-rounding ties
+        t = (acc.float() * xs[:, None]).double() * ws[None, :].double() + (b.double() if bias else 0.0)
+        exp = t.float().to(dtype)
+        ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+        torch.testing.assert_close(got.float(), exp.float(), rtol=ulp, atol=1e-5)
+        assert (got == exp).float().mean() > 0.999
+
+
+@pytest.mark.parametrize("m,inter,k", [(256, 18944, 3584), (512, 384, 1024), (100, 80, 128), (200, 9472, 3584), (32, 1024, 512)])
+def test_tiled_int8_gated_equals_unfused_pair(dev, m, inter, k):
+    """gate_up_proj + SiluAndMul in one W8A8 launch against the int8 GEMM followed by the SiLU-gate kernel: both round
+    each dequantised GEMM output to the 16-bit grid first; the stand-alone kernel also rounds silu(g) before the
+    product (norm_act.hip), the fused epilogue does not — one extra 16-bit rounding, hence one output ulp + the
+    ulp of silu(g) times |u|."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(m + inter)
+    x = (torch.randn(m, k, generator=g) * 2).to(torch.bfloat16).to(dev)
+    w = (torch.randn(2 * inter, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    wq, ws = ops.dynamic_int8_quant(w)
+    fused = ops.int8_linear_silu_mul(x, wq, ws)
+    unfused = ops.silu_and_mul(ops.int8_linear(x, wq, ws))
+    assert fused.shape == (m, inter)
+    gu = ops.int8_linear(x, wq, ws).float()
+    gt, up = gu[:, :inter], gu[:, inter:]
+    act = gt / (1.0 + torch.exp(-gt))
+    tol = (act * up).abs() * 2.0 ** -7 + act.abs() * up.abs() * 2.0 ** -8 + 1e-6
+    assert bool(((fused.float() - unfused.float()).abs() <= tol).all())
+
+
+def test_int8_linear_paths_agree(dev, monkeypatch):
+    """ops.int8_linear: tiled kernel (default), simple MFMA kernel, library contraction + dequant: identical."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(512, 1024, generator=g) * 2).to(torch.bfloat16).to(dev)
+    w = (torch.randn(1280, 1024, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    b = torch.randn(1280, generator=g).to(torch.bfloat16).to(dev)
+    wq, ws = ops.dynamic_int8_quant(w)
+    outs = {}
+    for mode in ("kernel", "simple", "library"):
+        monkeypatch.setenv("VLLM_OMNI_AMD_INT8", mode)
+        outs[mode] = ops.int8_linear(x, wq, ws, b)
+    assert torch.equal(outs["kernel"], outs["simple"]) and torch.equal(outs["kernel"], outs["library"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,H,add", [(256, 3584, True), (256, 3584, False), (512, 1024, True), (5, 512, True), (1, 8192, False)])
+def test_rms_norm_int8_equals_norm_then_quant(dev, T, H, add, dtype):
+    """The activation quantisation fused into the (fused-add) RMSNorm in front of a W8A8 linear: same bits as the
+    two launches apart — int8 row, scale, and the residual update."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(T + H)
+    x = torch.randn(T, H, generator=g).to(dtype).to(dev)
+    r = torch.randn(T, H, generator=g).to(dtype).to(dev) if add else None
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dtype).to(dev)
+    x0 = x.clone()
+    r1 = r.clone() if add else None
+    q = ops.rms_norm_int8(x, w, 1e-6, r1)
+    assert torch.equal(x, x0)                                   # x is not modified by the fused form
+    if add:
+        xa, ra = x0.clone(), r.clone()
+        ops.fused_add_rms_norm(xa, ra, w, 1e-6)
+        assert torch.equal(r1, ra)
+        y = xa
+    else:
+        y = ops.rms_norm(x0, w, 1e-6)
+    eq, es = ops.dynamic_int8_quant(y)
+    assert torch.equal(q.xs, es) and torch.equal(q.xq, eq) and q.lead == (T,) and q.dtype == dtype
+
+
+@pytest.mark.parametrize("T,H", [(256, 18944), (512, 384), (3, 200), (7, 24576)])
+def test_vectorised_quant_equals_the_scalar_kernel(dev, T, H):
+    from vllm_omni_amd import _C, ops
+
+    g = torch.Generator().manual_seed(T * 5 + H)
+    x = (torch.randn(T, H, generator=g) * 3).to(torch.bfloat16).to(dev)
+    xq, xs = ops.dynamic_int8_quant(x)                          # vectorised where the shape allows
+    sq = torch.empty_like(xq)
+    ss = torch.empty_like(xs)
+    _C.check("q", _C.lib.mi_dynamic_int8_quant(sq.data_ptr(), ss.data_ptr(), x.data_ptr(), T, H, x.stride(0),
+                                               _C.MI_DTYPE_BF16, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(xq, sq) and torch.equal(xs, ss)

@@ -156,6 +156,18 @@ __device__ __forceinline__ void scalar_cache_acquire() {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
+// W8A8 dequantisation of one int32 sum, spelled with explicit roundings so that every kernel that dequantises
+// (tiled int8 GEMM, its split-K reduce, the simple MFMA kernel, the stand-alone epilogue) produces the SAME bits:
+// fma(rnd(acc * x_scale), w_scale, bias), rounded to fp32 BEFORE the conversion to the 16-bit output.  Left to the
+// compiler, `a * xs * ws + b` contracts differently per kernel, and with an f16 output hipcc folds the fma and the
+// conversion into one `v_fma_mixlo_f16` (a single rounding) in some kernels and not in others — the empty asm
+// pins the fp32 value.
+__device__ __forceinline__ float dequant_i32(int acc, float xs, float ws, float b) {
+  float r = __fmaf_rn(__fmul_rn((float)acc, xs), ws, b);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+
 // ---- host-side launch check ---------------------------------------------
 inline int launch_status() {
   hipError_t e = hipGetLastError();

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void int8_gemm_dequant_kernel(uint16_t* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = rbase + 4 * g + i;
-      if (row < m) out[row * out_stride + col] = E::to_bits((float)c[i] * x_scale[row] * ws + bv);
+      if (row < m) out[row * out_stride + col] = E::to_bits(dequant_i32(c[i], x_scale[row], ws, bv));
     }
   };
   store(c00, row0, col0);
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void int8_dequant_kernel(uint16_t* __restrict_
       b0 = E::lo(bb.x); b1 = E::hi(bb.x); b2 = E::lo(bb.y); b3 = E::hi(bb.y);
     }
     uint2 r;
-    r.x = E::pack((float)a.x * xs * ws.x + b0, (float)a.y * xs * ws.y + b1);
-    r.y = E::pack((float)a.z * xs * ws.z + b2, (float)a.w * xs * ws.w + b3);
+    r.x = E::pack(dequant_i32(a.x, xs, ws.x, b0), dequant_i32(a.y, xs, ws.y, b1));
+    r.y = E::pack(dequant_i32(a.z, xs, ws.z, b2), dequant_i32(a.w, xs, ws.w, b3));
     *reinterpret_cast<uint2*>(out + row * out_stride + c) = r;
   }
 }

@@ -24,14 +24,39 @@ __device__ __forceinline__ float block_allreduce_sum(float v, float* smem) {
   return r;
 }
 
+__device__ __forceinline__ float block_allreduce_max(float v, float* smem) {
+  v = wave_allreduce_max(v);
+  const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) smem[wid] = v;
+  __syncthreads();
+  float r = smem[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, smem[i]);
+  __syncthreads();
+  return r;
+}
+
+// one value of the W8A8 activation quantisation (int8_config.py:323-342 scheme; same arithmetic as
+// dynamic_int8_quant_kernel: exact division, round-half-to-even, clamp)
+__device__ __forceinline__ int quant1(float v, float scale) {
+  return (int)fminf(fmaxf(rintf(v / scale), -128.f), 127.f);
+}
+__device__ __forceinline__ uint32_t quant4(float a, float b, float c, float d, float scale) {
+  return (uint32_t)(quant1(a, scale) & 255) | ((uint32_t)(quant1(b, scale) & 255) << 8) |
+         ((uint32_t)(quant1(c, scale) & 255) << 16) | ((uint32_t)(quant1(d, scale) & 255) << 24);
+}
+
 // rounding order: z = rnd(x + r); y = rnd(rnd(z * inv_rms) * w)
-template <typename Tag, bool ADD, int MAXC>
+// QUANT: the normalised row leaves as int8 + one fp32 scale (the quantisation that W8A8 linears put in front of
+// their GEMM, fused here: the row is in registers anyway) — bit-identical to this kernel followed by
+// dynamic_int8_quant_kernel; `out` is then the int8 row [T, hidden] and `q_scale` its scale [T].
+template <typename Tag, bool ADD, int MAXC, bool QUANT = false>
 __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ x,
                                                        uint16_t* __restrict__ residual,
                                                        const uint16_t* __restrict__ w, float eps,
                                                        int hidden, int64_t x_stride,
-                                                       int64_t out_stride, int64_t r_stride) {
+                                                       int64_t out_stride, int64_t r_stride,
+                                                       float* __restrict__ q_scale = nullptr) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
   __shared__ float smem[4];
@@ -66,6 +91,7 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ ou
   }
   ss = block_allreduce_sum(ss, smem);
   const float inv = __builtin_amdgcn_rsqf(ss / (float)hidden + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     const int ch = threadIdx.x + k * 256;
@@ -79,8 +105,68 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ ou
         const float nlo = E::from_bits(E::to_bits(E::lo(zs[i]) * inv));
         const float nhi = E::from_bits(E::to_bits(E::hi(zs[i]) * inv));
         o[i] = E::pack(nlo * E::lo(ws[i]), nhi * E::hi(ws[i]));
+        if constexpr (QUANT) amax = fmaxf(amax, fmaxf(fabsf(E::lo(o[i])), fabsf(E::hi(o[i]))));
       }
-      *reinterpret_cast<uint4*>(orow + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+      if constexpr (QUANT) z[k] = make_uint4(o[0], o[1], o[2], o[3]);
+      else *reinterpret_cast<uint4*>(orow + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  if constexpr (QUANT) {
+    amax = block_allreduce_max(amax, smem);
+    const float scale = amax > 0.f ? amax / 127.0f : 1.0f;
+    if (threadIdx.x == 0) q_scale[row] = scale;
+    int8_t* qrow = reinterpret_cast<int8_t*>(out) + (int64_t)row * out_stride;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int ch = threadIdx.x + k * 256;
+      if (ch < nchunk) {
+        const uint32_t os[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
+        uint2 q;
+        q.x = quant4(E::lo(os[0]), E::hi(os[0]), E::lo(os[1]), E::hi(os[1]), scale);
+        q.y = quant4(E::lo(os[2]), E::hi(os[2]), E::lo(os[3]), E::hi(os[3]), scale);
+        *reinterpret_cast<uint2*>(qrow + ch * 8) = q;
+      }
+    }
+  }
+}
+
+// Stand-alone activation quantisation, vectorised (16-byte loads, 8-byte stores), the row kept in registers between
+// the absmax pass and the rounding pass: hidden <= 8 * 256 * MAXC.
+template <typename Tag, int MAXC>
+__global__ __launch_bounds__(256) void int8_quant_rows_kernel(int8_t* __restrict__ xq, float* __restrict__ x_scale,
+                                                              const uint16_t* __restrict__ x, int hidden,
+                                                              int64_t x_stride) {
+  scalar_cache_acquire();
+  using E = Elem<Tag>;
+  __shared__ float smem[4];
+  const int row = blockIdx.x;
+  const int nchunk = hidden / 8;
+  const uint16_t* xr = x + row * x_stride;
+  uint4 z[MAXC];
+  float amax = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = threadIdx.x + k * 256;
+    if (ch < nchunk) {
+      z[k] = *reinterpret_cast<const uint4*>(xr + ch * 8);
+      const uint32_t ws[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fmaxf(fabsf(E::lo(ws[i])), fabsf(E::hi(ws[i]))));
+    }
+  }
+  amax = block_allreduce_max(amax, smem);
+  const float scale = amax > 0.f ? amax / 127.0f : 1.0f;
+  if (threadIdx.x == 0) x_scale[row] = scale;
+  int8_t* qrow = xq + (int64_t)row * hidden;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int ch = threadIdx.x + k * 256;
+    if (ch < nchunk) {
+      const uint32_t os[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
+      uint2 q;
+      q.x = quant4(E::lo(os[0]), E::hi(os[0]), E::lo(os[1]), E::hi(os[1]), scale);
+      q.y = quant4(E::lo(os[2]), E::hi(os[2]), E::lo(os[3]), E::hi(os[3]), scale);
+      *reinterpret_cast<uint2*>(qrow + ch * 8) = q;
     }
   }
 }
@@ -341,8 +427,75 @@ int launch_rms(void* out, const void* x, void* residual, const void* w, float ep
   return launch_status();
 }
 
+template <typename Tag>
+int launch_rms_int8(int8_t* xq, float* q_scale, const void* x, void* residual, const void* w, float eps, int T, int H,
+                    int64_t xs, int64_t rs, hipStream_t s) {
+  auto o = reinterpret_cast<uint16_t*>(xq);
+  auto xx = reinterpret_cast<const uint16_t*>(x);
+  auto rr = reinterpret_cast<uint16_t*>(residual);
+  auto ww = reinterpret_cast<const uint16_t*>(w);
+  if (H % 8 || xs % 8 || rs % 8 || H > 8 * 256 * 4 || (((uintptr_t)xq | (uintptr_t)x | (uintptr_t)residual | (uintptr_t)w) & 15))
+    return MI_ERR_UNSUPPORTED;
+  const int c = (H / 8 + 255) / 256;
+  const dim3 grid(T), block(256);
+#define MI_RMSQ(ADD, C) \
+  hipLaunchKernelGGL((rms_norm_kernel<Tag, ADD, C, true>), grid, block, 0, s, o, xx, rr, ww, eps, H, xs, (int64_t)H, rs, q_scale)
+  if (residual) { if (c <= 1) MI_RMSQ(true, 1); else if (c <= 2) MI_RMSQ(true, 2); else MI_RMSQ(true, 4); }
+  else { if (c <= 1) MI_RMSQ(false, 1); else if (c <= 2) MI_RMSQ(false, 2); else MI_RMSQ(false, 4); }
+#undef MI_RMSQ
+  return launch_status();
+}
+
 }  // namespace
 }  // namespace mi
+
+// RMSNorm (x) / fused residual-add RMSNorm (x, residual -> residual updated in place) whose normalised output leaves
+// as the W8A8 activation: int8 [T, hidden] + fp32 scale [T] — `norm` followed by `mi_dynamic_int8_quant`, one launch,
+// same bits.  x is NOT modified.  hidden % 8 == 0, <= 8192; 16-byte aligned rows.
+extern "C" int mi_rms_norm_int8(int8_t* xq, float* x_scale, const void* x, void* residual, const void* weight, float eps,
+                                int32_t num_tokens, int32_t hidden, int64_t x_token_stride,
+                                int64_t residual_token_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!xq || !x_scale || !x || !weight || num_tokens < 0 || hidden <= 0) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MI_DTYPE_BF16)
+    return launch_rms_int8<bf16_tag>(xq, x_scale, x, residual, weight, eps, num_tokens, hidden, x_token_stride,
+                                     residual_token_stride, s);
+  if (dtype == MI_DTYPE_F16)
+    return launch_rms_int8<f16_tag>(xq, x_scale, x, residual, weight, eps, num_tokens, hidden, x_token_stride,
+                                    residual_token_stride, s);
+  return MI_ERR_UNSUPPORTED;
+}
+
+// Vectorised form of mi_dynamic_int8_quant for rows of up to 24576 elements (hidden % 8 == 0, 16-byte aligned):
+// same results; MI_ERR_UNSUPPORTED otherwise (callers use mi_dynamic_int8_quant).
+extern "C" int mi_int8_quant_rows(int8_t* xq, float* x_scale, const void* x, int32_t num_tokens, int32_t hidden,
+                                  int64_t x_token_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!xq || !x_scale || !x || num_tokens < 0 || hidden <= 0) return MI_ERR_INVALID_ARG;
+  if (hidden % 8 || x_token_stride % 8 || hidden > 8 * 256 * 12 || (((uintptr_t)xq & 7) | ((uintptr_t)x & 15)))
+    return MI_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto xx = reinterpret_cast<const uint16_t*>(x);
+  const int c = (hidden / 8 + 255) / 256;
+  const dim3 grid(num_tokens), block(256);
+#define MI_Q(TAG, C) hipLaunchKernelGGL((int8_quant_rows_kernel<TAG, C>), grid, block, 0, s, xq, x_scale, xx, hidden, x_token_stride)
+#define MI_Q_T(TAG)                    \
+  do {                                 \
+    if (c <= 1) MI_Q(TAG, 1);          \
+    else if (c <= 2) MI_Q(TAG, 2);     \
+    else if (c <= 4) MI_Q(TAG, 4);     \
+    else MI_Q(TAG, 12);                \
+  } while (0)
+  if (dtype == MI_DTYPE_BF16) MI_Q_T(bf16_tag);
+  else if (dtype == MI_DTYPE_F16) MI_Q_T(f16_tag);
+  else return MI_ERR_UNSUPPORTED;
+#undef MI_Q_T
+#undef MI_Q
+  return launch_status();
+}
 
 extern "C" int mi_rms_norm(void* out, const void* x, const void* weight, float eps,
                            int32_t num_tokens, int32_t hidden, int64_t x_token_stride,

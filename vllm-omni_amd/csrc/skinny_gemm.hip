@@ -43,12 +43,25 @@
 namespace mi {
 namespace {
 
+// W8A8 operands (scheme of vllm_omni/quantization/int8_config.py:180-212,323-342): the SAME kernels run on
+// int8 rows — a 128-byte image row is then 128 k values instead of 64, a lane's 16-byte fragment 16 k values of
+// v_mfma_i32_16x16x64_i8, and every byte offset is unchanged (the host passes K and the row strides in 2-byte
+// units).  Sums are int32 (exact); the epilogue dequantises: acc * x_scale[m] * w_scale[n] (+ bias[n]).
+struct i8_tag {};
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+template <typename Tag>
+struct AccOf { using type = f32x4_t; };
+template <>
+struct AccOf<i8_tag> { using type = i32x4_t; };
+
 struct SkinnyParams {
   const uint16_t* x;
   const uint16_t* w;
   const uint16_t* bias;   // may be null
   uint16_t* out;          // S == 1
-  float* part;            // S > 1: [S][M][N]
+  float* part;            // S > 1: [S][M][N] (fp32 sums; int32 sums for int8 operands)
+  const float* xs;        // int8 operands: per-row activation scales [M]
+  const float* ws;        // int8 operands: per-output-channel weight scales [N] (GATED: [2 N], gate then up)
   int32_t M, N, K, S;     // GATED: N = output columns I; the weight has 2 I rows (gate rows, then up rows)
   int32_t dbg;            // MI_LINEAR_DBG (timing experiments only): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no reduce launch, 8 = no output stores
   int64_t ldx, ldo;
@@ -57,11 +70,31 @@ struct SkinnyParams {
 // operands as plain vectors (a HIP `uint4` is a struct: its copies between address spaces become memcpys that keep
 // the staging array in scratch)
 template <typename Tag>
-__device__ __forceinline__ f32x4_t mma(u32x4_t a, u32x4_t b, f32x4_t c) {
+__device__ __forceinline__ typename AccOf<Tag>::type mma(u32x4_t a, u32x4_t b, typename AccOf<Tag>::type c) {
   if constexpr (std::is_same_v<Tag, bf16_tag>)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  else
+  else if constexpr (std::is_same_v<Tag, f16_tag>)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), c, 0, 0, 0);
+}
+
+// One output quad (4 consecutive columns n .. n + 3 of row m) of the epilogue, as fp32 before the output rounding:
+// 16-bit operands: the sums themselves (+ bias); int8 operands: dequantised.
+template <typename Tag>
+__device__ __forceinline__ void finish_quad(const SkinnyParams& p, const typename AccOf<Tag>::type& a, int m, int n_scale,
+                                            const float (&bv)[4], float (&v)[4]) {
+  if constexpr (std::is_same_v<Tag, i8_tag>) {
+    const float xs = p.xs[m];
+    const float4 ws = *reinterpret_cast<const float4*>(p.ws + n_scale);
+    v[0] = dequant_i32(a[0], xs, ws.x, bv[0]);
+    v[1] = dequant_i32(a[1], xs, ws.y, bv[1]);
+    v[2] = dequant_i32(a[2], xs, ws.z, bv[2]);
+    v[3] = dequant_i32(a[3], xs, ws.w, bv[3]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] + bv[r];
+  }
 }
 
 __device__ __forceinline__ int kperm(int u, int kg) {
@@ -107,7 +140,7 @@ __device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w
 // GATED: gate_up_proj with the SiluAndMul that follows it (qwen2_old.py:65-68: act_fn(gate_up_proj(x))) in the epilogue —
 // a slab is 16 gate rows and the 16 matching up rows, a tile covers 16 NSLAB output columns, and the [M, 2 I]
 // intermediate never goes to memory.
-template <typename Tag, int NSLAB, int MT, int MH, int NL, bool GATED>
+template <typename Tag, typename OT, int NSLAB, int MT, int MH, int NL, bool GATED>
 __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(const SkinnyParams p) {
   // One pipeline step = one 64-wide k block.  A stage of the LDS ring is one image of 128-byte rows: the 16 MT rows of
   // x, then the tile's 32 NSLAB weight rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7).  The image is
@@ -127,9 +160,11 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   static_assert(PIECES % NL == 0 && PPL <= 63, "equal shares; one step of pieces must fit vmcnt");
   static_assert(MTW % 4 == 0 && NST * kStage <= 160 * 1024, "m-tiles are read in fours; the ring must fit the LDS");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  using E = Elem<Tag>;
+  using E = Elem<OT>;
+  using acc_t = typename AccOf<Tag>::type;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * (16 * MT);   // more than 16 MT rows (int8 at batch 512): one row block per grid.y
   // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so slice = id % S puts every k slice of x on the
   // XCDs congruent to it (S = 8: one slice per XCD) — its rows are then re-read from ONE L2 by all the tiles
   const int wg = blockIdx.x;
@@ -150,7 +185,7 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
       const int row = 8 * q + drow;
       const int lc = dpc ^ ((row >> 1) & 7);
       if (q < XI) {
-        const int m = row < p.M ? row : p.M - 1;   // rows past M repeat the last one; never stored
+        const int m = m0 + row < p.M ? m0 + row : p.M - 1;   // rows past M repeat the last one; never stored
         src[i] = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + 64 * (int64_t)b_lo + 8 * lc);
       } else {
         const int r = row - 16 * MT;               // row of the weight image
@@ -202,11 +237,11 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   for (int u = 0; u < 2; ++u) frag[u] = lds0 + r16 * 128 + ((kperm(u, kg) ^ (r16 >> 1)) << 4);
   const uint32_t x_off = mh * (MTW * 2048), w_off = kXBytes + slab * 4096;
 
-  f32x4_t acc[2][MTW];
+  acc_t acc[2][MTW];
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int j = 0; j < MTW; ++j) acc[g][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MTW; ++j) acc[g][j] = acc_t{0, 0, 0, 0};
 
   int stage = 0;
   for (int it = 0; it < n_it; ++it) {
@@ -239,14 +274,17 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
     // to the 16-bit grid first, SiLU and the product in fp32, one more rounding (norm_act.hip silu_mul_kernel)
     const int n = tile * (16 * NSLAB) + 16 * slab + 4 * kg;
     if (n >= p.N) return;
+    const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
-      const int m = 16 * (mh * MTW + j) + r16;
+      const int m = m0 + 16 * (mh * MTW + j) + r16;
       if (m >= p.M) continue;
-      float v[4];
+      float v[4], gq[4], uq[4];
+      finish_quad<Tag>(p, acc[0][j], m, n, zero4, gq);
+      finish_quad<Tag>(p, acc[1][j], m, p.N + n, zero4, uq);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float gt = E::from_bits(E::to_bits(acc[0][j][r])), up = E::from_bits(E::to_bits(acc[1][j][r]));
+        const float gt = E::from_bits(E::to_bits(gq[r])), up = E::from_bits(E::to_bits(uq[r]));
         v[r] = gt / (1.f + __expf(-gt)) * up;
       }
       uint2 q;
@@ -268,15 +306,17 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
     }
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
-      const int m = 16 * (mh * MTW + j) + r16;
+      const int m = m0 + 16 * (mh * MTW + j) + r16;
       if (m >= p.M) continue;
       if (p.S == 1) {
+        float v[4];
+        finish_quad<Tag>(p, acc[g][j], m, n, bv, v);
         uint2 q;
-        q.x = E::pack(acc[g][j][0] + bv[0], acc[g][j][1] + bv[1]);
-        q.y = E::pack(acc[g][j][2] + bv[2], acc[g][j][3] + bv[3]);
+        q.x = E::pack(v[0], v[1]);
+        q.y = E::pack(v[2], v[3]);
         *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = q;
-      } else {
-        *reinterpret_cast<f32x4_t*>(p.part + ((int64_t)s * p.M + m) * p.N + n) = acc[g][j];
+      } else {   // fp32 sums, or the exact int32 sums of int8 operands (same 16 bytes)
+        *reinterpret_cast<acc_t*>(p.part + ((int64_t)s * p.M + m) * p.N + n) = acc[g][j];
       }
     }
   }
@@ -343,7 +383,7 @@ __device__ __forceinline__ void lds_read_wx<6>(uint32_t aw, uint32_t ax, u32x4_t
 #undef MI_RD
 
 // G: 16-row weight groups per tile (10 = 160 rows, 8 = 128 rows); G0: groups of consumer waves 0-3 (waves 4-7 take G - G0)
-template <typename Tag, int G, int G0, bool GATED>
+template <typename Tag, typename OT, int G, int G0, bool GATED>
 struct V2 {
   static constexpr int MT = 16;
   static constexpr int TR = 16 * G;
@@ -362,20 +402,22 @@ struct V2 {
   template <int NG>
   static __device__ __forceinline__ void consume(const SkinnyParams& p, char* smem, int c, int g_lo, int mq, int tile, int s,
                                                  int n_it) {
-    using E = Elem<Tag>;
+    using E = Elem<OT>;
+    using acc_t = typename AccOf<Tag>::type;
     const int lane = threadIdx.x & 63;
     const int r16 = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.y * 256;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
     uint32_t frag[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) frag[u] = lds0 + r16 * 128 + ((kperm(u, kg) ^ (r16 >> 1)) << 4);
     const uint32_t x_off = mq * (4 * 2048), w_off = kXBytes + g_lo * 2048;
     const uint32_t full0 = lds0 + kFlags, free0 = lds0 + kFlags + NST * 16;
-    f32x4_t acc[NG][4];
+    acc_t acc[NG][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[g][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) acc[g][i] = acc_t{0, 0, 0, 0};
     int stage = 0;
     for (int it = 0; it < n_it; ++it) {
       // FULL: every loader's pieces of step `it` have landed
@@ -411,14 +453,17 @@ struct V2 {
       for (int q = 0; q < NG / 2; ++q) {
         const int n = tile * CT + 8 * g_lo + 16 * q + 4 * kg;
         if (n >= p.N) continue;
+        const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int m = 16 * (4 * mq + i) + r16;
+          const int m = m0 + 16 * (4 * mq + i) + r16;
           if (m >= p.M) continue;
-          float v[4];
+          float v[4], gq[4], uq[4];
+          finish_quad<Tag>(p, acc[2 * q][i], m, n, zero4, gq);
+          finish_quad<Tag>(p, acc[2 * q + 1][i], m, p.N + n, zero4, uq);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float gt = E::from_bits(E::to_bits(acc[2 * q][i][r])), up = E::from_bits(E::to_bits(acc[2 * q + 1][i][r]));
+            const float gt = E::from_bits(E::to_bits(gq[r])), up = E::from_bits(E::to_bits(uq[r]));
             v[r] = gt / (1.f + __expf(-gt)) * up;
           }
           uint2 o;
@@ -439,15 +484,17 @@ struct V2 {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int m = 16 * (4 * mq + i) + r16;
+          const int m = m0 + 16 * (4 * mq + i) + r16;
           if (m >= p.M) continue;
           if (p.S == 1) {
+            float v[4];
+            finish_quad<Tag>(p, acc[g][i], m, n, bv, v);
             uint2 o;
-            o.x = E::pack(acc[g][i][0] + bv[0], acc[g][i][1] + bv[1]);
-            o.y = E::pack(acc[g][i][2] + bv[2], acc[g][i][3] + bv[3]);
+            o.x = E::pack(v[0], v[1]);
+            o.y = E::pack(v[2], v[3]);
             *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = o;
           } else {
-            *reinterpret_cast<f32x4_t*>(p.part + ((int64_t)s * p.M + m) * p.N + n) = acc[g][i];
+            *reinterpret_cast<acc_t*>(p.part + ((int64_t)s * p.M + m) * p.N + n) = acc[g][i];
           }
         }
       }
@@ -455,9 +502,9 @@ struct V2 {
   }
 };
 
-template <typename Tag, int G, int G0, bool GATED>
+template <typename Tag, typename OT, int G, int G0, bool GATED>
 __global__ __launch_bounds__(64 * (kV2Consumers + kV2Loaders)) void skinny_gemm_v2_kernel(const SkinnyParams p) {
-  using C = V2<Tag, G, G0, GATED>;
+  using C = V2<Tag, OT, G, G0, GATED>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -484,7 +531,8 @@ __global__ __launch_bounds__(64 * (kV2Consumers + kV2Loaders)) void skinny_gemm_
       const int row = 8 * q + drow;
       const int lc = dpc ^ ((row >> 1) & 7);
       if (q < C::XI) {
-        const int m = row < p.M ? row : p.M - 1;   // rows past M repeat the last one; never stored
+        const int m0 = blockIdx.y * 256;
+        const int m = m0 + row < p.M ? m0 + row : p.M - 1;   // rows past M repeat the last one; never stored
         src[i] = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + 64 * (int64_t)b_lo + 8 * lc);
       } else {
         const int r = row - 16 * C::MT;            // row of the weight image
@@ -573,6 +621,40 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(uint16_t* __restrict
   *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o;
 }
 
+// split-K reduce of int8 operands: exact int32 sums over the slices, then the dequantisation (+ bias)
+template <typename OT>
+__global__ __launch_bounds__(256) void skinny_reduce_i8_kernel(uint16_t* __restrict__ out, const int32_t* __restrict__ part,
+                                                               const float* __restrict__ xs, const float* __restrict__ ws,
+                                                               const uint16_t* __restrict__ bias, int M, int N, int S,
+                                                               int64_t ldo) {
+  using E = Elem<OT>;
+  const int64_t quads = (int64_t)M * N / 4;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int m = (int)(q / (N / 4)), n = (int)(q - (int64_t)m * (N / 4)) * 4;
+  i32x4_t v[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+    if (s < S) v[s] = *reinterpret_cast<const i32x4_t*>(part + ((int64_t)s * M + m) * N + n);
+  i32x4_t a = v[0];
+#pragma unroll
+  for (int s = 1; s < 16; ++s)
+    if (s < S) a += v[s];
+  const float x = xs[m];
+  const float4 w = *reinterpret_cast<const float4*>(ws + n);
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = E::from_bits(bias[n + r]);
+  }
+  const float f[4] = {dequant_i32(a[0], x, w.x, bv[0]), dequant_i32(a[1], x, w.y, bv[1]), dequant_i32(a[2], x, w.z, bv[2]),
+                      dequant_i32(a[3], x, w.w, bv[3])};
+  uint2 o;
+  o.x = E::pack(f[0], f[1]);
+  o.y = E::pack(f[2], f[3]);
+  *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o;
+}
+
 struct SkinnyPlan {
   int nslab, mt, tiles, split;
 };
@@ -611,10 +693,10 @@ int linear_v2() {   // MI_LINEAR_V2=0: the first-generation kernel at 129-256 ro
   return e ? atoi(e) : 1;
 }
 
-template <typename Tag, int G, int G0, bool GATED>
+template <typename Tag, typename OT, int G, int G0, bool GATED>
 int launch_v2(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
-  using C = V2<Tag, G, G0, GATED>;
-  auto kern = skinny_gemm_v2_kernel<Tag, G, G0, GATED>;
+  using C = V2<Tag, OT, G, G0, GATED>;
+  auto kern = skinny_gemm_v2_kernel<Tag, OT, G, G0, GATED>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::kLds);
   if (attr != hipSuccess) return MI_ERR_LAUNCH;
@@ -622,49 +704,60 @@ int launch_v2(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
   return launch_status();
 }
 
-int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int dtype, hipStream_t s) {
-  if (pl.mt == 16 && linear_v2() && (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16)) {
-    const dim3 g2(pl.tiles * pl.split);
-#define MI_V2(TAG)                                                                            \
-    do {                                                                                      \
-      if (pl.nslab == 5) return gated ? launch_v2<TAG, 10, 6, true>(p, g2, s) : launch_v2<TAG, 10, 5, false>(p, g2, s); \
-      return gated ? launch_v2<TAG, 8, 4, true>(p, g2, s) : launch_v2<TAG, 8, 4, false>(p, g2, s);                     \
+// `dtype`: the type of the 16-bit OUTPUT (and of the operands, unless `int8`: then x / w are int8 rows and the sums
+// int32).  A launch covers ceil(M / (16 mt)) row blocks (grid.y): M > 256 only arises with int8 operands.
+int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int dtype, hipStream_t s, bool int8 = false) {
+  const dim3 grid(pl.tiles * pl.split, (p.M + 16 * pl.mt - 1) / (16 * pl.mt));
+  if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
+  if (pl.mt == 16 && linear_v2()) {
+#define MI_V2(TAG, OT)                                                                                                   \
+    do {                                                                                                                 \
+      if (pl.nslab == 5) return gated ? launch_v2<TAG, OT, 10, 6, true>(p, grid, s) : launch_v2<TAG, OT, 10, 5, false>(p, grid, s); \
+      return gated ? launch_v2<TAG, OT, 8, 4, true>(p, grid, s) : launch_v2<TAG, OT, 8, 4, false>(p, grid, s);                     \
     } while (0)
-    if (dtype == MI_DTYPE_BF16) MI_V2(bf16_tag);
-    else MI_V2(f16_tag);
+    if (int8) {
+      if (dtype == MI_DTYPE_BF16) MI_V2(i8_tag, bf16_tag);
+      else MI_V2(i8_tag, f16_tag);
+    } else {
+      if (dtype == MI_DTYPE_BF16) MI_V2(bf16_tag, bf16_tag);
+      else MI_V2(f16_tag, f16_tag);
+    }
 #undef MI_V2
   }
-  const dim3 grid(pl.tiles * pl.split);
-#define MI_SKINNY(TAG, NSLAB, MT, MH, NL, GATED)                                                                  \
+#define MI_SKINNY(TAG, OT, NSLAB, MT, MH, NL, GATED)                                                              \
   do {                                                                                                            \
-    auto kern = skinny_gemm_kernel<TAG, NSLAB, MT, MH, NL, GATED>;                                                \
+    auto kern = skinny_gemm_kernel<TAG, OT, NSLAB, MT, MH, NL, GATED>;                                            \
     constexpr int lds = 3 * (MT * 2048 + NSLAB * 4096);                                                           \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
     if (attr != hipSuccess) return MI_ERR_LAUNCH;                                                                 \
     hipLaunchKernelGGL(kern, grid, dim3(64 * (NSLAB * MH + NL)), lds, s, p);                                      \
   } while (0)
-#define MI_SKINNY_T(TAG, GATED)                              \
-  do {                                                       \
-    if (pl.nslab == 5) {                                     \
-      if (pl.mt == 16) MI_SKINNY(TAG, 5, 16, 2, MI_SKINNY_NL5, GATED);   \
-      else if (pl.mt == 8) MI_SKINNY(TAG, 5, 8, MI_SKINNY_MH8, MI_SKINNY_NL5, GATED);\
-      else MI_SKINNY(TAG, 5, 4, 1, MI_SKINNY_NL5, GATED);                \
-    } else {                                                 \
-      if (pl.mt == 16) MI_SKINNY(TAG, 4, 16, 2, 4, GATED);   \
-      else if (pl.mt == 8) MI_SKINNY(TAG, 4, 8, MI_SKINNY_MH8, 4, GATED);\
-      else MI_SKINNY(TAG, 4, 4, 1, 4, GATED);                \
-    }                                                        \
+#define MI_SKINNY_T(TAG, OT, GATED)                              \
+  do {                                                           \
+    if (pl.nslab == 5) {                                         \
+      if (pl.mt == 16) MI_SKINNY(TAG, OT, 5, 16, 2, MI_SKINNY_NL5, GATED);   \
+      else if (pl.mt == 8) MI_SKINNY(TAG, OT, 5, 8, MI_SKINNY_MH8, MI_SKINNY_NL5, GATED);\
+      else MI_SKINNY(TAG, OT, 5, 4, 1, MI_SKINNY_NL5, GATED);                \
+    } else {                                                     \
+      if (pl.mt == 16) MI_SKINNY(TAG, OT, 4, 16, 2, 4, GATED);   \
+      else if (pl.mt == 8) MI_SKINNY(TAG, OT, 4, 8, MI_SKINNY_MH8, 4, GATED);\
+      else MI_SKINNY(TAG, OT, 4, 4, 1, 4, GATED);                \
+    }                                                            \
   } while (0)
-  if (dtype == MI_DTYPE_BF16) {
-    if (gated) MI_SKINNY_T(bf16_tag, true);
-    else MI_SKINNY_T(bf16_tag, false);
-  } else if (dtype == MI_DTYPE_F16) {
-    if (gated) MI_SKINNY_T(f16_tag, true);
-    else MI_SKINNY_T(f16_tag, false);
+#define MI_SKINNY_G(TAG, OT)                  \
+  do {                                        \
+    if (gated) MI_SKINNY_T(TAG, OT, true);    \
+    else MI_SKINNY_T(TAG, OT, false);         \
+  } while (0)
+  if (int8) {
+    if (dtype == MI_DTYPE_BF16) MI_SKINNY_G(i8_tag, bf16_tag);
+    else MI_SKINNY_G(i8_tag, f16_tag);
   } else {
-    return MI_ERR_UNSUPPORTED;
+    if (dtype == MI_DTYPE_BF16) MI_SKINNY_G(bf16_tag, bf16_tag);
+    else MI_SKINNY_G(f16_tag, f16_tag);
   }
+#undef MI_SKINNY_G
 #undef MI_SKINNY_T
 #undef MI_SKINNY
   return launch_status();
@@ -713,6 +806,7 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
   p.bias = reinterpret_cast<const uint16_t*>(bias);
   p.out = reinterpret_cast<uint16_t*>(out);
   p.part = reinterpret_cast<float*>(workspace);
+  p.xs = p.ws = nullptr;
   p.M = m; p.N = n; p.K = k; p.S = pl.split;
   p.dbg = linear_dbg();
   p.ldx = x_row_stride;
@@ -751,6 +845,7 @@ extern "C" int mi_linear_partials(const void* x, const void* weight, int32_t m, 
   p.bias = nullptr;
   p.out = nullptr;
   p.part = reinterpret_cast<float*>(workspace);
+  p.xs = p.ws = nullptr;
   p.M = m; p.N = n; p.K = k; p.S = pl.split;
   p.dbg = linear_dbg();
   p.ldx = x_row_stride;
@@ -801,9 +896,100 @@ extern "C" int mi_linear_silu_mul(void* out, const void* x, const void* weight, 
   p.bias = nullptr;
   p.out = reinterpret_cast<uint16_t*>(out);
   p.part = nullptr;
+  p.xs = p.ws = nullptr;
   p.M = m; p.N = inter; p.K = k; p.S = 1;
   p.dbg = linear_dbg();
   p.ldx = x_row_stride;
   p.ldo = out_row_stride;
   return launch_skinny(p, pl, true, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ W8A8 entry points
+namespace {
+// int8 rows as the kernels see them: K and row strides in 2-byte units
+int int8_shape_ok(int32_t m, int32_t n, int32_t k, int64_t x_row_stride) {
+  if (m > 512 || k % 128 || n % 16 || x_row_stride % 16) return 0;
+  if ((int64_t)m * x_row_stride >= ((int64_t)1 << 31)) return 0;
+  return 1;
+}
+}  // namespace
+
+extern "C" int64_t mi_int8_linear_workspace_bytes(int32_t m, int32_t n, int32_t k) {
+  using namespace mi;
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  const SkinnyPlan pl = skinny_plan(m > 256 ? 256 : m, n, k / 2, forced_split());
+  return pl.split > 1 ? (int64_t)pl.split * m * n * (int64_t)sizeof(int32_t) : 0;
+}
+
+extern "C" int mi_int8_linear(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq, const float* w_scale,
+                              const void* bias, int32_t m, int32_t n, int32_t k, int64_t x_row_stride,
+                              int64_t out_row_stride, void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
+  using namespace mi;
+  if (m == 0 || n == 0) return MI_OK;
+  if (!out || !xq || !x_scale || !wq || !w_scale || m < 0 || n < 0 || k <= 0) return MI_ERR_INVALID_ARG;
+  if (!int8_shape_ok(m, n, k, x_row_stride) || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if ((((uintptr_t)xq | (uintptr_t)wq | (uintptr_t)w_scale) & 15) || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
+  SkinnyPlan pl = skinny_plan(m > 256 ? 256 : m, n, k / 2, forced_split());
+  if (m > 256) {   // two row blocks per weight tile: halve the split so the grid still fits one round
+    pl.split = pl.split > 1 ? (pl.split + 1) / 2 : 1;
+  }
+  if (pl.split > 1 && (!workspace || ((uintptr_t)workspace & 15))) return MI_ERR_INVALID_ARG;
+  if (pl.split > 1 && workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(int32_t)) return MI_ERR_WORKSPACE;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(xq);
+  p.w = reinterpret_cast<const uint16_t*>(wq);
+  p.bias = reinterpret_cast<const uint16_t*>(bias);
+  p.out = reinterpret_cast<uint16_t*>(out);
+  p.part = reinterpret_cast<float*>(workspace);
+  p.xs = x_scale;
+  p.ws = w_scale;
+  p.M = m; p.N = n; p.K = k / 2; p.S = pl.split;
+  p.dbg = linear_dbg();
+  p.ldx = x_row_stride / 2;
+  p.ldo = out_row_stride;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int lrc = launch_skinny(p, pl, false, dtype, s, true);
+  if (lrc != MI_OK) return lrc;
+  if (pl.split > 1) {
+    const int64_t quads = (int64_t)m * n / 4;
+    const dim3 rgrid((unsigned)((quads + 255) / 256));
+    auto o = reinterpret_cast<uint16_t*>(out);
+    auto b = reinterpret_cast<const uint16_t*>(bias);
+    auto pp = reinterpret_cast<const int32_t*>(workspace);
+    if (dtype == MI_DTYPE_BF16)
+      hipLaunchKernelGGL((skinny_reduce_i8_kernel<bf16_tag>), rgrid, dim3(256), 0, s, o, pp, x_scale, w_scale, b, m, n, pl.split, out_row_stride);
+    else
+      hipLaunchKernelGGL((skinny_reduce_i8_kernel<f16_tag>), rgrid, dim3(256), 0, s, o, pp, x_scale, w_scale, b, m, n, pl.split, out_row_stride);
+  }
+  return launch_status();
+}
+
+extern "C" int mi_int8_linear_silu_mul(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq,
+                                       const float* w_scale, int32_t m, int32_t inter, int32_t k, int64_t x_row_stride,
+                                       int64_t out_row_stride, int dtype, void* stream) {
+  using namespace mi;
+  if (m == 0 || inter == 0) return MI_OK;
+  if (!out || !xq || !x_scale || !wq || !w_scale || m < 0 || inter < 0 || k <= 0) return MI_ERR_INVALID_ARG;
+  if (!int8_shape_ok(m, inter, k, x_row_stride) || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if ((((uintptr_t)xq | (uintptr_t)wq | (uintptr_t)w_scale) & 15) || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
+  SkinnyPlan pl;
+  const int mm = m > 256 ? 256 : m;
+  pl.mt = mm <= 64 ? 4 : mm <= 128 ? 8 : 16;
+  const int t80 = (inter + 79) / 80, t64 = (inter + 63) / 64;
+  if (t80 > 128 && t80 <= 256) { pl.nslab = 5; pl.tiles = t80; }
+  else { pl.nslab = 4; pl.tiles = t64; }
+  pl.split = 1;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(xq);
+  p.w = reinterpret_cast<const uint16_t*>(wq);
+  p.bias = nullptr;
+  p.out = reinterpret_cast<uint16_t*>(out);
+  p.part = nullptr;
+  p.xs = x_scale;
+  p.ws = w_scale;
+  p.M = m; p.N = inter; p.K = k / 2; p.S = 1;
+  p.dbg = linear_dbg();
+  p.ldx = x_row_stride / 2;
+  p.ldo = out_row_stride;
+  return launch_skinny(p, pl, true, dtype, reinterpret_cast<hipStream_t>(stream), true);
 }

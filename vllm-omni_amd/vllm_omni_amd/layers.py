@@ -84,11 +84,16 @@ class RMSNorm:
         self.weight = torch.ones(hidden_size, dtype=dtype, device=device)
         self.variance_epsilon = eps
 
-    def __call__(self, x, residual: Optional[torch.Tensor] = None):
+    def __call__(self, x, residual: Optional[torch.Tensor] = None, quant: bool = False):
+        """``quant``: the caller feeds the result to a W8A8 linear — the normalised row leaves as int8 + scale
+        (``ops.QuantizedActs``), the activation quantisation fused into this launch."""
         if isinstance(x, ops.SplitKPartials):   # a row-parallel linear left its split-K reduce to this kernel
-            if residual is not None:
+            if residual is not None and not quant:
                 return ops.fused_add_rms_norm_splitk(x, residual, self.weight, self.variance_epsilon), residual
             x = x.materialize()
+        if quant and x.is_cuda and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192:
+            q = ops.rms_norm_int8(x, self.weight, self.variance_epsilon, residual)
+            return q if residual is None else (q, residual)
         if residual is None:
             return ops.rms_norm(x, self.weight, self.variance_epsilon)
         ops.fused_add_rms_norm(x, residual, self.weight, self.variance_epsilon)
@@ -287,9 +292,20 @@ def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
     """``act_fn(gate_up_proj(x))`` in one launch (``ops.linear_silu_mul``) when the policy picks the streaming kernel
     for this shape, else None (the caller runs the GEMM and ``SiluAndMul`` apart).  Column-parallel, no bias, 16-bit
     weights only; under TP a rank's weight is [gate shard; up shard], the layout the kernel expects."""
-    if _LINEAR_MODE == "library" or not x.is_cuda or getattr(layer, "qweight", None) is not None:
+    if isinstance(x, ops.QuantizedActs):
+        n2, k = layer.qweight.shape
+        if layer.bias is None and n2 % 32 == 0 and ops.int8_linear_supported(x.xq.shape[0], n2 // 2, k):
+            return ops.int8_linear_silu_mul(x, layer.qweight, layer.weight_scale)
         return None
-    if layer.bias is not None or getattr(layer, "gather_output", False):
+    if layer.bias is not None or getattr(layer, "gather_output", False) or not x.is_cuda:
+        return None
+    if getattr(layer, "qweight", None) is not None:   # W8A8: the gated form of the tiled int8 kernel
+        m = x.numel() // x.shape[-1]
+        n2, k = layer.qweight.shape
+        if n2 % 32 == 0 and ops.int8_linear_supported(m, n2 // 2, k) and os.environ.get("VLLM_OMNI_AMD_INT8", "kernel") == "kernel":
+            return ops.int8_linear_silu_mul(x, layer.qweight, layer.weight_scale)
+        return None
+    if _LINEAR_MODE == "library":
         return None
     w = layer.weight
     m = x.numel() // x.shape[-1]

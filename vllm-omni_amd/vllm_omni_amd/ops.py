@@ -7,6 +7,7 @@ Reference call sites these stand in for are cited in include/vllm_omni_amd.h.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -285,13 +286,41 @@ def talker_decode_embeds(out: torch.Tensor, embed_table: torch.Tensor, token_ids
 
 # -------------------------------------------------------------------------- A13
 def dynamic_int8_quant(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Dynamic symmetric per-row int8 quantisation (int8_config.py:323-342): (int8 [rows, hidden], fp32 scale [rows])."""
     _gpu(x)
     x2 = x.view(-1, x.shape[-1])
     xq = torch.empty(x2.shape, dtype=torch.int8, device=x.device)
     xs = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
-    check("mi_dynamic_int8_quant", lib.mi_dynamic_int8_quant(_p(xq), _p(xs), _p(x2), x2.shape[0], x2.shape[1],
-                                                              x2.stride(0), _dt(x.dtype), _stream()))
+    rc = lib.mi_int8_quant_rows(_p(xq), _p(xs), _p(x2), x2.shape[0], x2.shape[1], x2.stride(0), _dt(x.dtype), _stream())
+    if rc == _C.MI_ERR_UNSUPPORTED:   # odd widths / alignments: the scalar kernel
+        rc = lib.mi_dynamic_int8_quant(_p(xq), _p(xs), _p(x2), x2.shape[0], x2.shape[1], x2.stride(0), _dt(x.dtype),
+                                       _stream())
+    check("mi_dynamic_int8_quant", rc)
     return xq, xs
+
+
+class QuantizedActs:
+    """A W8A8 activation on its way into a linear layer: int8 rows + one fp32 scale per row, produced by the op in
+    front of the linear (``rms_norm_int8``) instead of a separate quantisation launch."""
+
+    __slots__ = ("xq", "xs", "lead", "dtype")
+
+    def __init__(self, xq: torch.Tensor, xs: torch.Tensor, lead: tuple, dtype: torch.dtype):
+        self.xq, self.xs, self.lead, self.dtype = xq, xs, lead, dtype
+
+
+def rms_norm_int8(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None) -> QuantizedActs:
+    """RMSNorm (``residual`` None) or fused residual-add RMSNorm (``residual`` updated in place; ``x`` untouched) whose
+    output leaves as the W8A8 activation — same bits as the norm followed by ``dynamic_int8_quant``, one launch."""
+    _gpu(x, weight, residual)
+    x2 = x.view(-1, x.shape[-1])
+    r2 = residual.view(-1, x.shape[-1]) if residual is not None else None
+    xq = torch.empty(x2.shape, dtype=torch.int8, device=x.device)
+    xs = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    check("mi_rms_norm_int8", lib.mi_rms_norm_int8(_p(xq), _p(xs), _p(x2), _p(r2), _p(weight), float(eps), x2.shape[0],
+                                                   x2.shape[1], x2.stride(0), r2.stride(0) if r2 is not None else 0,
+                                                   _dt(x.dtype), _stream()))
+    return QuantizedActs(xq, xs, tuple(x.shape[:-1]), x.dtype)
 
 
 def int8_gemm_dequant(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
@@ -467,27 +496,67 @@ def linear_silu_mul(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return out.view(*x.shape[:-1], inter)
 
 
-# Library int8 GEMM (hipBLASLt behind torch._int_mm) needs M > 16 and K, N multiples of 8; everything else
-# goes through the hand-written MFMA kernel.  VLLM_OMNI_AMD_INT8_GEMM=mfma forces the latter.
-_INT8_FORCE_MFMA = __import__("os").environ.get("VLLM_OMNI_AMD_INT8_GEMM", "") == "mfma"
+
+def int8_linear_supported(m: int, n: int, k: int) -> bool:
+    """Shape envelope of the tiled W8A8 kernel (csrc/skinny_gemm.hip on int8 rows)."""
+    return 0 < m <= 512 and k % 128 == 0 and n % 16 == 0 and k > 0
 
 
 def int8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """W8A8 linear of the reference's scheme (vllm_omni/quantization/int8_config.py:323-342: dynamic symmetric
-    per-token activation scale, per-output-channel weight scale): hand-written per-token quantisation kernel ->
-    int8 x int8 -> int32 contraction -> hand-written dequant epilogue.  The contraction is a plain GEMM and uses
-    the library (measured M = 512: 62-102 us against 286-484 us for the MFMA kernel of csrc/int8_linear.hip,
-    tools/bench_misc_kernels.py); the integer sums are exact either way, so both paths give identical results."""
-    x2 = x.reshape(-1, x.shape[-1])
-    xq, xs = dynamic_int8_quant(x2)
+    per-token activation scale, per-output-channel weight scale): hand-written per-token quantisation kernel, then
+    ONE launch of the tiled int8 kernel — LDS-DMA ring, `v_mfma_i32_16x16x64_i8`, dequantisation + bias in the
+    epilogue (``mi_int8_linear``; split-K shapes add its small reduce launch).  Shapes outside its envelope run the
+    simple MFMA kernel ``mi_int8_gemm_dequant``.  ``VLLM_OMNI_AMD_INT8=library`` routes the contraction to the
+    library instead (``torch._int_mm`` + ``mi_int8_dequant``: cross-check / A-B runs only).  Integer sums are exact
+    on every path, so all three agree bit for bit."""
+    if isinstance(x, QuantizedActs):
+        xq, xs, lead, dtype = x.xq, x.xs, x.lead, x.dtype
+    else:
+        xq, xs = dynamic_int8_quant(x.reshape(-1, x.shape[-1]))
+        lead, dtype = tuple(x.shape[:-1]), x.dtype
     m, k = xq.shape
     n = wq.shape[0]
-    if not _INT8_FORCE_MFMA and m > 16 and k % 8 == 0 and n % 8 == 0:
-        acc = torch._int_mm(xq, wq.t())
-        y = int8_dequant(acc, xs, w_scale, bias, x.dtype)
+    mode = os.environ.get("VLLM_OMNI_AMD_INT8", "kernel")
+    if mode == "library" and m > 16 and k % 8 == 0 and n % 8 == 0:
+        y = int8_dequant(torch._int_mm(xq, wq.t()), xs, w_scale, bias, dtype)
+    elif mode != "simple" and int8_linear_supported(m, n, k):
+        y = int8_linear_q(xq, xs, wq, w_scale, bias, dtype)
     else:
-        y = int8_gemm_dequant(xq, xs, wq, w_scale, bias, x.dtype)
-    return y.view(*x.shape[:-1], n)
+        y = int8_gemm_dequant(xq, xs, wq, w_scale, bias, dtype)
+    return y.view(*lead, n)
+
+
+def int8_linear_q(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
+                  bias: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+    """The tiled W8A8 kernel on already-quantised activations (xq int8 [m, k], xs fp32 [m])."""
+    _gpu(xq, xs, wq, w_scale, bias)
+    m, k = xq.shape
+    n = wq.shape[0]
+    if wq.shape[1] != k or not wq.is_contiguous() or xq.stride(1) != 1:
+        raise ValueError("wq must be a contiguous int8 [n, k] tensor; xq rows must be contiguous")
+    out = torch.empty(m, n, dtype=out_dtype, device=xq.device)
+    need = lib.mi_int8_linear_workspace_bytes(m, n, k)
+    ws = _linear_workspace(xq.device, need) if need else None
+    check("mi_int8_linear", lib.mi_int8_linear(_p(out), _p(xq), _p(xs), _p(wq), _p(w_scale), _p(bias), m, n, k,
+                                               xq.stride(0), out.stride(0), _p(ws) if need else None,
+                                               ws.numel() if need else 0, _dt(out_dtype), _stream()))
+    return out
+
+
+def int8_linear_silu_mul(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
+    """``act_fn(gate_up_proj(x))`` with W8A8 weights in one GEMM launch (+ the activation quantisation in front)."""
+    if isinstance(x, QuantizedActs):
+        xq, xs, lead, dtype = x.xq, x.xs, x.lead, x.dtype
+    else:
+        xq, xs = dynamic_int8_quant(x.reshape(-1, x.shape[-1]))
+        lead, dtype = tuple(x.shape[:-1]), x.dtype
+    m, k = xq.shape
+    inter = wq.shape[0] // 2
+    out = torch.empty(m, inter, dtype=dtype, device=xq.device)
+    check("mi_int8_linear_silu_mul", lib.mi_int8_linear_silu_mul(_p(out), _p(xq), _p(xs), _p(wq), _p(w_scale), m, inter, k,
+                                                                 xq.stride(0), out.stride(0), _dt(dtype), _stream()))
+    return out.view(*lead, inter)
 
 
 # --------------------------------------------------------------------------- N4: fused sparse MoE

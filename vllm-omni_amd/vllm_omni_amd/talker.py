@@ -196,14 +196,17 @@ class Qwen2DecoderLayer:
         """``defer_reduce``: the caller promises to hand the returned hidden states to a fused-add RMSNorm (the next
         layer's input_layernorm or the final norm); the dense MLP may then return its down_proj as split-K partials
         for that norm to reduce (``ops.SplitKPartials``) — one launch and one round trip of [T, H] less per layer."""
+        # W8A8 linears behind a norm: the norm hands them the quantised activation directly (ops.rms_norm_int8)
+        q_attn = getattr(self.self_attn.qkv_proj, "qweight", None) is not None
+        q_mlp = isinstance(self.mlp, Qwen2MLP) and getattr(self.mlp.gate_up_proj, "qweight", None) is not None
         if residual is None:
             residual = hidden_states
-            hidden_states = self.input_layernorm(hidden_states)
+            hidden_states = self.input_layernorm(hidden_states, quant=q_attn)
         else:
-            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+            hidden_states, residual = self.input_layernorm(hidden_states, residual, quant=q_attn)
         # o_proj always meets the fused-add post_attention_layernorm: its split-K reduce (if any) may go there
         hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states, defer_reduce=True)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual, quant=q_mlp)
         if defer_reduce and isinstance(self.mlp, Qwen2MLP):
             hidden_states = self.mlp(hidden_states, True)
         else:
