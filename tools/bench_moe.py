@@ -46,6 +46,17 @@ def main():
         logits = F.linear(x, blk.gate_weight)
         t_layer = timeit(lambda: blk(x))
         t_fused = timeit(lambda: ops.fused_moe(x, logits, blk.gate_up_proj, blk.down_proj, k, False))
+        # the two expert-GEMM kernels x the two tile heights, interleaved rounds in one process
+        arms = [("ring", 32), ("ring", 64), ("direct", 32), ("direct", 64)]
+        res = {a_: [] for a_ in arms}
+        for _ in range(4):
+            for mode, rpt in arms:
+                os.environ["MI_MOE_GEMM"] = mode
+                res[(mode, rpt)].append(timeit(lambda: ops.fused_moe(x, logits, blk.gate_up_proj, blk.down_proj, k, False,
+                                                                     rows_per_tile=rpt), iters=10, warm=2))
+        os.environ.pop("MI_MOE_GEMM", None)
+        print("   expert path by GEMM kernel / rows per tile: " + ", ".join(
+            f"{m_}/{r_}: {sorted(v)[len(v) // 2]:.1f} us" for (m_, r_), v in res.items()))
         ids, w, _ = ops.moe_route(logits, k, False, round_to=torch.bfloat16)
         hit = int(torch.unique(ids).numel())
 

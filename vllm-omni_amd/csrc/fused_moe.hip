@@ -14,7 +14,10 @@
 // swapped form D = W . X^T (A operand = 16 weight rows, B operand = 16 token rows, K-contiguous 16-byte
 // fragments straight from global memory): a lane then owns 4 consecutive output features of one token, so the
 // SiLU-gate epilogue is lane-local (a wave computes the matching gate and up rows) and stores are 8 bytes.
+#include <cstring>
+
 #include "common.h"
+#include "skinny_grouped.h"
 #include "mfma_attn_common.h"
 
 namespace mi {
@@ -303,11 +306,13 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t* __restrict__
 
 extern "C" int32_t mi_moe_rows_per_tile(int32_t num_tokens, int32_t top_k, int32_t num_experts) {
   if (num_tokens <= 0 || top_k <= 0 || num_experts <= 0) return 32;
-  // 64-row tiles halve the tile count once experts average more than a tile, but measured slower at the talker
-  // shape (T = 512: 172 us against 158 us: twice the token fragments per workgroup, half the loads in flight);
-  // with the XCD-aware tile order the second tile of an expert finds the weights in L2 anyway
-  (void)num_tokens; (void)top_k; (void)num_experts;
-  return 32;
+  // The ring kernel (skinny_gemm.hip, grouped form) stages a 64-row image per tile whatever the tile height, and every
+  // tile streams its expert's weights once: 64-row tiles win as soon as experts average more than ~24 rows (measured
+  // at the talker shape, tools/bench_moe.py: T = 512: 105 us against 116 us with 32-row tiles; T = 256: 99 against 88).
+  // The fragments-from-global kernel (MI_MOE_GEMM=direct) is faster with 32-row tiles at every size measured.
+  const char* e = getenv("MI_MOE_GEMM");
+  if (e && strcmp(e, "direct") == 0) return 32;
+  return (int64_t)num_tokens * top_k > 24 * (int64_t)num_experts ? 64 : 32;
 }
 
 extern "C" int64_t mi_moe_max_rows(int32_t num_tokens, int32_t top_k, int32_t num_experts, int32_t rows_per_tile) {
@@ -378,6 +383,24 @@ extern "C" int mi_moe_expert_gemm(void* out, const void* a_rows, const void* wei
   if (rows_per_tile != 32 && rows_per_tile != 64) return MI_ERR_INVALID_ARG;
   if (a_row_stride % 8 || out_row_stride % 4 || weight_expert_stride % 8) return MI_ERR_INVALID_ARG;
   if (((uintptr_t)a_rows | (uintptr_t)weights) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    // default: the decode-batch linear kernel's grouped form (skinny_gemm.hip: row-contiguous LDS-DMA weight images,
+    // `ds_read_b128` fragments, loader / consumer waves); MI_MOE_GEMM=direct keeps the fragments-from-global kernel
+    // below (A/B runs, and shapes outside the ring kernel's envelope)
+    const char* e = getenv("MI_MOE_GEMM");
+    if (!e || strcmp(e, "direct") != 0) {
+      GroupedGemmArgs ga;
+      ga.out = out; ga.a_rows = a_rows; ga.weights = weights;
+      ga.sorted_pairs = sorted_pairs; ga.tile_expert = tile_expert; ga.num_tiles = num_tiles;
+      ga.max_tiles = max_tiles; ga.gated = gated; ga.n_out = n_out; ga.k = k; ga.top_k = top_k;
+      ga.rows_per_tile = rows_per_tile;
+      ga.a_row_stride = a_row_stride; ga.out_row_stride = out_row_stride; ga.weight_expert_stride = weight_expert_stride;
+      ga.dtype = dtype;
+      const int rc = launch_grouped_skinny(ga, s);
+      if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
+  }
   MoeGemmParams p;
   p.a_rows = reinterpret_cast<const uint16_t*>(a_rows);
   p.w = reinterpret_cast<const uint16_t*>(weights);
@@ -391,7 +414,6 @@ extern "C" int mi_moe_expert_gemm(void* out, const void* a_rows, const void* wei
   p.a_stride = a_row_stride;
   p.out_stride = out_row_stride;
   p.w_expert_stride = weight_expert_stride;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((max_tiles + 7) / 8 * 8, gated ? n_out / 64 : n_out / 128), block(256);
 #define MI_MOE_GEMM(TAG, G, M) hipLaunchKernelGGL((moe_gemm_kernel<TAG, G, M>), grid, block, 0, s, p)
 #define MI_MOE_GEMM_T(TAG)                                \

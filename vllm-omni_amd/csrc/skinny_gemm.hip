@@ -25,6 +25,7 @@
 // Measured in situ at 256 rows: down_proj 47 us + reduce against 77 us for the TunableOp-selected
 // library kernel, gate_up_proj + SiluAndMul 71 us against 81 + 7 us; which layers use it: layers.py.
 #include "mfma_attn_common.h"
+#include "skinny_grouped.h"
 
 // experiment switches (csrc/Makefile `make variant VARIANT_DEFS=...`); the defaults are the measured best
 #ifndef MI_SKINNY_W_AUX
@@ -63,6 +64,12 @@ struct SkinnyParams {
   const float* xs;        // int8 operands: per-row activation scales [M]
   const float* ws;        // int8 operands: per-output-channel weight scales [N] (GATED: [2 N], gate then up)
   int32_t M, N, K, S;     // GATED: N = output columns I; the weight has 2 I rows (gate rows, then up rows)
+  // GROUPED (sparse-MoE expert GEMMs, fused_moe.hip): grid.y = one tile of `rpt` token rows that share one expert
+  const int32_t* row_map;      // [max_rows] pair index per row or -1
+  const int32_t* tile_expert;  // [max_tiles]
+  const int32_t* num_tiles;    // [1]
+  int32_t rpt, gather_div;     // rows per tile (32 / 64); gather_div > 0: source row = row_map[r] / gather_div, else r
+  int64_t w_expert_stride;     // elements
   int32_t dbg;            // MI_LINEAR_DBG (timing experiments only): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no reduce launch, 8 = no output stores
   int64_t ldx, ldo;
 };
@@ -140,7 +147,7 @@ __device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w
 // GATED: gate_up_proj with the SiluAndMul that follows it (qwen2_old.py:65-68: act_fn(gate_up_proj(x))) in the epilogue —
 // a slab is 16 gate rows and the 16 matching up rows, a tile covers 16 NSLAB output columns, and the [M, 2 I]
 // intermediate never goes to memory.
-template <typename Tag, typename OT, int NSLAB, int MT, int MH, int NL, bool GATED>
+template <typename Tag, typename OT, int NSLAB, int MT, int MH, int NL, bool GATED, bool GROUPED = false>
 __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(const SkinnyParams p) {
   // One pipeline step = one 64-wide k block.  A stage of the LDS ring is one image of 128-byte rows: the 16 MT rows of
   // x, then the tile's 32 NSLAB weight rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7).  The image is
@@ -164,7 +171,14 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   using acc_t = typename AccOf<Tag>::type;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.y * (16 * MT);   // more than 16 MT rows (int8 at batch 512): one row block per grid.y
+  const int m0 = GROUPED ? 0 : blockIdx.y * (16 * MT);   // more than 16 MT rows (int8 at batch 512): one row block per grid.y
+  const uint16_t* wbase = p.w;
+  if constexpr (GROUPED) {
+    // the maps were written by the alignment kernel just before this launch: keep their reads off a stale scalar cache
+    scalar_cache_acquire();
+    if ((int)blockIdx.y >= p.num_tiles[0]) return;   // whole workgroup, before any barrier
+    wbase += (int64_t)p.tile_expert[blockIdx.y] * p.w_expert_stride;
+  }
   // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so slice = id % S puts every k slice of x on the
   // XCDs congruent to it (S = 8: one slice per XCD) — its rows are then re-read from ONE L2 by all the tiles
   const int wg = blockIdx.x;
@@ -185,7 +199,16 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
       const int row = 8 * q + drow;
       const int lc = dpc ^ ((row >> 1) & 7);
       if (q < XI) {
-        const int m = m0 + row < p.M ? m0 + row : p.M - 1;   // rows past M repeat the last one; never stored
+        int m = m0 + row < p.M ? m0 + row : p.M - 1;   // rows past M repeat the last one; never stored
+        if constexpr (GROUPED) {   // row of the tile -> row of the source matrix (padding rows read some valid row)
+          const int R = blockIdx.y * p.rpt + (row < p.rpt ? row : 0);
+          if (p.gather_div > 0) {
+            const int pr = p.row_map[R];
+            m = (pr < 0 ? 0 : pr) / p.gather_div;
+          } else {
+            m = R;
+          }
+        }
         src[i] = reinterpret_cast<const char*>(p.x + (int64_t)m * p.ldx + 64 * (int64_t)b_lo + 8 * lc);
       } else {
         const int r = row - 16 * MT;               // row of the weight image
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
           n = tile * TR + r;
           n = n < p.N ? n : p.N - 1;               // a tile may hang over N: those row groups are never stored
         }
-        src[i] = reinterpret_cast<const char*>(p.w + (int64_t)n * p.K + 64 * (int64_t)b_lo + 8 * lc);
+        src[i] = reinterpret_cast<const char*>(wbase + (int64_t)n * p.K + 64 * (int64_t)b_lo + 8 * lc);
       }
     }
     auto issue = [&](int it, int stage) {
@@ -277,8 +300,9 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
     const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
-      const int m = m0 + 16 * (mh * MTW + j) + r16;
+      int m = m0 + 16 * (mh * MTW + j) + r16;
       if (m >= p.M) continue;
+      if constexpr (GROUPED) m += blockIdx.y * p.rpt;
       float v[4], gq[4], uq[4];
       finish_quad<Tag>(p, acc[0][j], m, n, zero4, gq);
       finish_quad<Tag>(p, acc[1][j], m, p.N + n, zero4, uq);
@@ -306,8 +330,9 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
     }
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
-      const int m = m0 + 16 * (mh * MTW + j) + r16;
+      int m = m0 + 16 * (mh * MTW + j) + r16;
       if (m >= p.M) continue;
+      if constexpr (GROUPED) m += blockIdx.y * p.rpt;
       if (p.S == 1) {
         float v[4];
         finish_quad<Tag>(p, acc[g][j], m, n, bv, v);
@@ -763,6 +788,17 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
   return launch_status();
 }
 
+template <typename Tag, bool GATED>
+int launch_grouped_t(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
+  auto kern = skinny_gemm_kernel<Tag, Tag, 4, 4, 1, 4, GATED, true>;
+  constexpr int lds = 3 * (4 * 2048 + 4 * 4096);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != hipSuccess) return MI_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (4 + 4)), lds, s, p);
+  return launch_status();
+}
+
 int linear_dbg() {   // MI_LINEAR_DBG: timing experiments only (see SkinnyParams::dbg); read per call
   const char* e = getenv("MI_LINEAR_DBG");
   return e ? atoi(e) : 0;
@@ -993,3 +1029,35 @@ extern "C" int mi_int8_linear_silu_mul(void* out, const int8_t* xq, const float*
   p.ldo = out_row_stride;
   return launch_skinny(p, pl, true, dtype, reinterpret_cast<hipStream_t>(stream), true);
 }
+
+// ---------------------------------------------------------------------------------- grouped form (sparse-MoE experts)
+namespace mi {
+int launch_grouped_skinny(const GroupedGemmArgs& a, hipStream_t s) {
+  if (a.k % 64 || a.n_out % (a.gated ? 64 : 128) || a.rows_per_tile > 64 || a.rows_per_tile <= 0) return MI_ERR_UNSUPPORTED;
+  if (a.dtype != MI_DTYPE_BF16 && a.dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
+  if (a.a_row_stride % 8 || a.out_row_stride % 4 || a.weight_expert_stride % 8) return MI_ERR_UNSUPPORTED;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(a.a_rows);
+  p.w = reinterpret_cast<const uint16_t*>(a.weights);
+  p.bias = nullptr;
+  p.out = reinterpret_cast<uint16_t*>(a.out);
+  p.part = nullptr;
+  p.xs = p.ws = nullptr;
+  p.M = a.rows_per_tile;   // valid rows of a tile (the image holds 64: the rest repeat a valid row, never stored)
+  p.N = a.n_out;
+  p.K = a.k;
+  p.S = 1;
+  p.row_map = a.sorted_pairs;
+  p.tile_expert = a.tile_expert;
+  p.num_tiles = a.num_tiles;
+  p.rpt = a.rows_per_tile;
+  p.gather_div = a.gated ? a.top_k : 0;
+  p.w_expert_stride = a.weight_expert_stride;
+  p.dbg = 0;
+  p.ldx = a.a_row_stride;
+  p.ldo = a.out_row_stride;
+  const dim3 grid(a.gated ? a.n_out / 64 : a.n_out / 128, a.max_tiles);
+  if (a.dtype == MI_DTYPE_BF16) return a.gated ? launch_grouped_t<bf16_tag, true>(p, grid, s) : launch_grouped_t<bf16_tag, false>(p, grid, s);
+  return a.gated ? launch_grouped_t<f16_tag, true>(p, grid, s) : launch_grouped_t<f16_tag, false>(p, grid, s);
+}
+}  // namespace mi
