@@ -954,6 +954,7 @@ extern "C" int64_t mi_int8_linear_workspace_bytes(int32_t m, int32_t n, int32_t 
   using namespace mi;
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   const SkinnyPlan pl = skinny_plan(m > 256 ? 256 : m, n, k / 2, forced_split());
+  if ((int64_t)n * k < ((int64_t)8 << 20)) return 0;
   return pl.split > 1 ? (int64_t)pl.split * m * n * (int64_t)sizeof(int32_t) : 0;
 }
 
@@ -969,6 +970,8 @@ extern "C" int mi_int8_linear(void* out, const int8_t* xq, const float* x_scale,
   if (m > 256) {   // two row blocks per weight tile: halve the split so the grid still fits one round
     pl.split = pl.split > 1 ? (pl.split + 1) / 2 : 1;
   }
+  // a few MB of weights stream in microseconds on a fraction of the chip: a split-K reduce launch costs more than it saves
+  if ((int64_t)n * k < ((int64_t)8 << 20)) pl.split = 1;
   if (pl.split > 1 && (!workspace || ((uintptr_t)workspace & 15))) return MI_ERR_INVALID_ARG;
   if (pl.split > 1 && workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(int32_t)) return MI_ERR_WORKSPACE;
   SkinnyParams p;
