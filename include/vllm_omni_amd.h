@@ -350,6 +350,16 @@ int64_t mi_int8_linear_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int mi_int8_linear(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq, const float* w_scale,
                    const void* bias, int32_t m, int32_t n, int32_t k, int64_t x_row_stride,
                    int64_t out_row_stride, void* workspace, int64_t workspace_bytes, int dtype, void* stream);
+/* The split-K W8A8 projection without its reduce launch (exact int32 partials [split][m][n] in `workspace`), and the
+ * fused residual-add RMSNorm that consumes them: x = rnd(dequant(sum over slices) (+ bias)), residual <- x + residual,
+ * out = norm(residual) * weight as 16-bit rows (q_scale == NULL) or as the next W8A8 linear's int8 rows + q_scale —
+ * bit-identical to mi_int8_linear -> mi_fused_add_rms_norm (-> mi_dynamic_int8_quant), two launches fewer. */
+int mi_int8_linear_partials(const int8_t* xq, const int8_t* wq, int32_t m, int32_t n, int32_t k, int64_t x_row_stride,
+                            void* workspace, int64_t workspace_bytes, int32_t* split_out, void* stream);
+int mi_fused_add_rms_norm_splitk_int8(void* out, float* q_scale, const void* partials, int32_t split,
+                                      const float* x_scale, const float* w_scale, const void* bias, void* residual,
+                                      const void* weight, float eps, int32_t num_tokens, int32_t hidden,
+                                      int64_t out_token_stride, int64_t residual_token_stride, int dtype, void* stream);
 int mi_int8_linear_silu_mul(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq,
                             const float* w_scale, int32_t m, int32_t inter, int32_t k, int64_t x_row_stride,
                             int64_t out_row_stride, int dtype, void* stream);

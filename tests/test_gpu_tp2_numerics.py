@@ -22,13 +22,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto", backend="gloo", graph=False):
+def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto", backend="gloo", graph=False, allreduce="rccl"):
     import sys
     for p in (ROOT, os.path.join(ROOT, "vllm-omni_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["VLLM_OMNI_AMD_TP_GRAPH"] = "1" if graph else "0"
     os.environ["VLLM_OMNI_AMD_LINEAR"] = linear_mode   # read when vllm_omni_amd.layers is imported (below)
+    os.environ["VLLM_OMNI_AMD_ALLREDUCE"] = allreduce   # "custom": the in-tree two-shot all-reduce over IPC buffers
     try:
         import numpy as np
         from oracle import ref_talker
@@ -82,6 +83,9 @@ def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto", backend="
         if tp_rank == 0:
             torch.save({"hidden": hidden, "ids": ids, "logits": logits}, out_path)
         if tp_size > 1:
+            if allreduce == "custom":
+                assert D.get_parallel_state().custom_ar is not None
+                D.get_parallel_state().custom_ar.check()      # no spin timed out
             D.destroy_distributed_environment()
         q.put((tp_rank, "ok"))
     except Exception as e:  # noqa: BLE001
@@ -90,11 +94,14 @@ def _run_step(tp_rank, tp_size, port, out_path, q, linear_mode="auto", backend="
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("linear_mode", ["auto", "kernel"])
-def test_tp2_matches_tp1(dev, linear_mode):
+@pytest.mark.parametrize("linear_mode,allreduce", [("auto", "rccl"), ("kernel", "rccl"), ("kernel", "custom")])
+def test_tp2_matches_tp1(dev, linear_mode, allreduce):
     """linear_mode="kernel": every projection on the streaming GEMM — sharded [gate; up] weights through the fused
     gate_up + SiLU kernel, row-parallel shards with and without the deferred split-K reduce (TP 1 defers, TP 2 must
-    materialise before the all-reduce)."""
+    materialise before the all-reduce).  allreduce="custom": the 2 x layers all-reduces of the step run the in-tree
+    two-shot kernel through each other's IPC-mapped buffers (csrc/allreduce.hip) — with linear_mode="kernel" the
+    row-parallel projections hand it their split-K partials directly (copy-in = reduce); the group itself and the
+    vocab all-gather stay on gloo here (two ranks on one card)."""
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as tmp:
         results = {}
@@ -102,7 +109,8 @@ def test_tp2_matches_tp1(dev, linear_mode):
             q = ctx.Queue()
             port = _free_port()
             path = os.path.join(tmp, f"tp{tp}.pt")
-            procs = [ctx.Process(target=_run_step, args=(r, tp, port, path, q, linear_mode)) for r in range(tp)]
+            procs = [ctx.Process(target=_run_step, args=(r, tp, port, path, q, linear_mode, "gloo", False, allreduce))
+                     for r in range(tp)]
             for p in procs:
                 p.start()
             res = [q.get(timeout=240) for _ in procs]

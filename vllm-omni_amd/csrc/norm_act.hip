@@ -175,12 +175,18 @@ __global__ __launch_bounds__(256) void int8_quant_rows_kernel(int8_t* __restrict
 // 16-bit x: x = rnd(sum_s part[s] (+ bias)) — the reduce kernel's arithmetic, slice order and rounding — then exactly
 // the ADD path above.  Saves the reduce launch and the round trip of x through memory (down_proj -> next layer's
 // input_layernorm; qwen2_old.py:212-216).
-template <typename Tag, int MAXC>
+// I8: the partials are the exact int32 sums of a W8A8 projection (mi_int8_linear_partials): x = rnd(dequant(sum over
+// slices)) with the dequantisation of skinny_reduce_i8_kernel (dequant_i32).  QUANT: the normalised row leaves as int8 +
+// scale for the W8A8 linear behind the norm (as rms_norm_kernel<…, QUANT>).
+template <typename Tag, int MAXC, bool I8 = false, bool QUANT = false>
 __global__ __launch_bounds__(256) void rms_norm_splitk_kernel(uint16_t* __restrict__ out, const float* __restrict__ part,
                                                               int S, const uint16_t* __restrict__ bias,
                                                               uint16_t* __restrict__ residual,
                                                               const uint16_t* __restrict__ w, float eps, int T, int hidden,
-                                                              int64_t out_stride, int64_t r_stride) {
+                                                              int64_t out_stride, int64_t r_stride,
+                                                              const float* __restrict__ p_xs = nullptr,
+                                                              const float* __restrict__ p_ws = nullptr,
+                                                              float* __restrict__ q_scale = nullptr) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
   __shared__ float smem[4];
@@ -204,17 +210,42 @@ __global__ __launch_bounds__(256) void rms_norm_splitk_kernel(uint16_t* __restri
           vl[s] = *reinterpret_cast<const float4*>(ps);
           vh[s] = *reinterpret_cast<const float4*>(ps + 4);
         }
-      float4 lo = vl[0], hi = vh[0];
+      float4 lo, hi;
+      if constexpr (I8) {
+        int4 il = __builtin_bit_cast(int4, vl[0]), ih = __builtin_bit_cast(int4, vh[0]);
 #pragma unroll
-      for (int s = 1; s < 16; ++s)
-        if (s < S) {
-          lo.x += vl[s].x; lo.y += vl[s].y; lo.z += vl[s].z; lo.w += vl[s].w;
-          hi.x += vh[s].x; hi.y += vh[s].y; hi.z += vh[s].z; hi.w += vh[s].w;
+        for (int s = 1; s < 16; ++s)
+          if (s < S) {
+            const int4 a = __builtin_bit_cast(int4, vl[s]), b = __builtin_bit_cast(int4, vh[s]);
+            il.x += a.x; il.y += a.y; il.z += a.z; il.w += a.w;
+            ih.x += b.x; ih.y += b.y; ih.z += b.z; ih.w += b.w;
+          }
+        float bl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+          const uint4 bv = *reinterpret_cast<const uint4*>(bias + ch * 8);
+          bl[0] = E::lo(bv.x); bl[1] = E::hi(bv.x); bl[2] = E::lo(bv.y); bl[3] = E::hi(bv.y);
+          bl[4] = E::lo(bv.z); bl[5] = E::hi(bv.z); bl[6] = E::lo(bv.w); bl[7] = E::hi(bv.w);
         }
-      if (bias) {
-        const uint4 bv = *reinterpret_cast<const uint4*>(bias + ch * 8);
-        lo.x += E::lo(bv.x); lo.y += E::hi(bv.x); lo.z += E::lo(bv.y); lo.w += E::hi(bv.y);
-        hi.x += E::lo(bv.z); hi.y += E::hi(bv.z); hi.z += E::lo(bv.w); hi.w += E::hi(bv.w);
+        const float xs = p_xs[row];
+        const float4 w0 = *reinterpret_cast<const float4*>(p_ws + ch * 8), w1 = *reinterpret_cast<const float4*>(p_ws + ch * 8 + 4);
+        lo = make_float4(dequant_i32(il.x, xs, w0.x, bl[0]), dequant_i32(il.y, xs, w0.y, bl[1]),
+                         dequant_i32(il.z, xs, w0.z, bl[2]), dequant_i32(il.w, xs, w0.w, bl[3]));
+        hi = make_float4(dequant_i32(ih.x, xs, w1.x, bl[4]), dequant_i32(ih.y, xs, w1.y, bl[5]),
+                         dequant_i32(ih.z, xs, w1.z, bl[6]), dequant_i32(ih.w, xs, w1.w, bl[7]));
+      } else {
+        lo = vl[0];
+        hi = vh[0];
+#pragma unroll
+        for (int s = 1; s < 16; ++s)
+          if (s < S) {
+            lo.x += vl[s].x; lo.y += vl[s].y; lo.z += vl[s].z; lo.w += vl[s].w;
+            hi.x += vh[s].x; hi.y += vh[s].y; hi.z += vh[s].z; hi.w += vh[s].w;
+          }
+        if (bias) {
+          const uint4 bv = *reinterpret_cast<const uint4*>(bias + ch * 8);
+          lo.x += E::lo(bv.x); lo.y += E::hi(bv.x); lo.z += E::lo(bv.y); lo.w += E::hi(bv.y);
+          hi.x += E::lo(bv.z); hi.y += E::hi(bv.z); hi.z += E::lo(bv.w); hi.w += E::hi(bv.w);
+        }
       }
       uint4 a = make_uint4(E::pack(lo.x, lo.y), E::pack(lo.z, lo.w), E::pack(hi.x, hi.y), E::pack(hi.z, hi.w));
       const uint4 b = *reinterpret_cast<const uint4*>(rr + ch * 8);
@@ -234,6 +265,7 @@ __global__ __launch_bounds__(256) void rms_norm_splitk_kernel(uint16_t* __restri
   }
   ss = block_allreduce_sum(ss, smem);
   const float inv = __builtin_amdgcn_rsqf(ss / (float)hidden + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     const int ch = threadIdx.x + k * 256;
@@ -247,8 +279,27 @@ __global__ __launch_bounds__(256) void rms_norm_splitk_kernel(uint16_t* __restri
         const float nlo = E::from_bits(E::to_bits(E::lo(zs[i]) * inv));
         const float nhi = E::from_bits(E::to_bits(E::hi(zs[i]) * inv));
         o[i] = E::pack(nlo * E::lo(ws[i]), nhi * E::hi(ws[i]));
+        if constexpr (QUANT) amax = fmaxf(amax, fmaxf(fabsf(E::lo(o[i])), fabsf(E::hi(o[i]))));
       }
-      *reinterpret_cast<uint4*>(orow + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+      if constexpr (QUANT) z[k] = make_uint4(o[0], o[1], o[2], o[3]);
+      else *reinterpret_cast<uint4*>(orow + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  if constexpr (QUANT) {
+    amax = block_allreduce_max(amax, smem);
+    const float scale = amax > 0.f ? amax / 127.0f : 1.0f;
+    if (threadIdx.x == 0) q_scale[row] = scale;
+    int8_t* qrow = reinterpret_cast<int8_t*>(out) + (int64_t)row * out_stride;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      const int ch = threadIdx.x + k * 256;
+      if (ch < nchunk) {
+        const uint32_t os[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
+        uint2 q;
+        q.x = quant4(E::lo(os[0]), E::hi(os[0]), E::lo(os[1]), E::hi(os[1]), scale);
+        q.y = quant4(E::lo(os[2]), E::hi(os[2]), E::lo(os[3]), E::hi(os[3]), scale);
+        *reinterpret_cast<uint2*>(qrow + ch * 8) = q;
+      }
     }
   }
 }
@@ -562,6 +613,53 @@ extern "C" int mi_fused_add_rms_norm_splitk(void* out, const void* partials, int
   else return MI_ERR_UNSUPPORTED;
 #undef MI_RMS_SK_T
 #undef MI_RMS_SK
+  return launch_status();
+}
+
+// The fused-add RMSNorm fed by the exact int32 split-K partials of a W8A8 projection (mi_int8_linear_partials):
+// x = rnd(dequant(sum over slices) (+ bias)), residual <- x + residual, then the norm — the int8 reduce launch and one
+// round trip of [T, H] saved.  q_scale == NULL: 16-bit output `out` [T, out_stride]; else the normalised row leaves as
+// int8 `out` [T, hidden] + q_scale [T] for the W8A8 linear behind the norm.  Bit-identical to mi_int8_linear (with its
+// reduce) followed by mi_fused_add_rms_norm (followed by mi_dynamic_int8_quant).
+extern "C" int mi_fused_add_rms_norm_splitk_int8(void* out, float* q_scale, const void* partials, int32_t split,
+                                                 const float* x_scale, const float* w_scale, const void* bias,
+                                                 void* residual, const void* weight, float eps, int32_t num_tokens,
+                                                 int32_t hidden, int64_t out_token_stride, int64_t residual_token_stride,
+                                                 int dtype, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!out || !partials || !x_scale || !w_scale || !residual || !weight || num_tokens < 0 || hidden <= 0 || split < 1 ||
+      split > 16)
+    return MI_ERR_INVALID_ARG;
+  if (hidden % 8 || residual_token_stride % 8 || hidden > 8 * 256 * 4 || (!q_scale && out_token_stride % 8))
+    return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)out | (uintptr_t)partials | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)w_scale) & 15)
+    return MI_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto o = reinterpret_cast<uint16_t*>(out);
+  auto pp = reinterpret_cast<const float*>(partials);
+  auto bb = reinterpret_cast<const uint16_t*>(bias);
+  auto rr = reinterpret_cast<uint16_t*>(residual);
+  auto ww = reinterpret_cast<const uint16_t*>(weight);
+  const int c = (hidden / 8 + 255) / 256;
+  const dim3 grid(num_tokens), block(256);
+  const int64_t os = q_scale ? (int64_t)hidden : out_token_stride;
+#define MI_RMS_SKI(TAG, C, Q)                                                                                            \
+  hipLaunchKernelGGL((rms_norm_splitk_kernel<TAG, C, true, Q>), grid, block, 0, s, o, pp, split, bb, rr, ww, eps, num_tokens, \
+                     hidden, os, residual_token_stride, x_scale, w_scale, q_scale)
+#define MI_RMS_SKI_T(TAG)                                                        \
+  do {                                                                           \
+    if (q_scale) {                                                               \
+      if (c <= 1) MI_RMS_SKI(TAG, 1, true); else if (c <= 2) MI_RMS_SKI(TAG, 2, true); else MI_RMS_SKI(TAG, 4, true);    \
+    } else {                                                                     \
+      if (c <= 1) MI_RMS_SKI(TAG, 1, false); else if (c <= 2) MI_RMS_SKI(TAG, 2, false); else MI_RMS_SKI(TAG, 4, false); \
+    }                                                                            \
+  } while (0)
+  if (dtype == MI_DTYPE_BF16) MI_RMS_SKI_T(bf16_tag);
+  else if (dtype == MI_DTYPE_F16) MI_RMS_SKI_T(f16_tag);
+  else return MI_ERR_UNSUPPORTED;
+#undef MI_RMS_SKI_T
+#undef MI_RMS_SKI
   return launch_status();
 }
 

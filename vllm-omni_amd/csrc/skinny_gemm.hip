@@ -1003,6 +1003,37 @@ extern "C" int mi_int8_linear(void* out, const int8_t* xq, const float* x_scale,
   return launch_status();
 }
 
+// The W8A8 kernel without its reduce launch: exact int32 partials [split][m][n] in `workspace` for a consumer that
+// folds the reduction + dequantisation in (mi_fused_add_rms_norm_splitk_int8).  MI_ERR_UNSUPPORTED when the shape's
+// plan has no split (use mi_int8_linear).
+extern "C" int mi_int8_linear_partials(const int8_t* xq, const int8_t* wq, int32_t m, int32_t n, int32_t k,
+                                       int64_t x_row_stride, void* workspace, int64_t workspace_bytes, int32_t* split_out,
+                                       void* stream) {
+  using namespace mi;
+  if (!xq || !wq || !split_out || m <= 0 || n <= 0 || k <= 0) return MI_ERR_INVALID_ARG;
+  if (!int8_shape_ok(m, n, k, x_row_stride)) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)xq | (uintptr_t)wq) & 15) return MI_ERR_INVALID_ARG;
+  SkinnyPlan pl = skinny_plan(m > 256 ? 256 : m, n, k / 2, forced_split());
+  if (m > 256) pl.split = pl.split > 1 ? (pl.split + 1) / 2 : 1;
+  if ((int64_t)n * k < ((int64_t)8 << 20)) pl.split = 1;
+  if (pl.split <= 1) return MI_ERR_UNSUPPORTED;
+  if (!workspace || ((uintptr_t)workspace & 15)) return MI_ERR_INVALID_ARG;
+  if (workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(int32_t)) return MI_ERR_WORKSPACE;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(xq);
+  p.w = reinterpret_cast<const uint16_t*>(wq);
+  p.bias = nullptr;
+  p.out = nullptr;
+  p.part = reinterpret_cast<float*>(workspace);
+  p.xs = p.ws = nullptr;
+  p.M = m; p.N = n; p.K = k / 2; p.S = pl.split;
+  p.dbg = linear_dbg();
+  p.ldx = x_row_stride / 2;
+  p.ldo = 0;
+  *split_out = pl.split;
+  return launch_skinny(p, pl, false, MI_DTYPE_BF16, reinterpret_cast<hipStream_t>(stream), true);
+}
+
 extern "C" int mi_int8_linear_silu_mul(void* out, const int8_t* xq, const float* x_scale, const int8_t* wq,
                                        const float* w_scale, int32_t m, int32_t inter, int32_t k, int64_t x_row_stride,
                                        int64_t out_row_stride, int dtype, void* stream) {

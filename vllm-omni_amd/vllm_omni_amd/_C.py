@@ -81,6 +81,9 @@ SIGNATURES = {
     "mi_int8_quant_rows": (c_int, [_P, _P, _P, c_int32, c_int32, c_int64, c_int, _P]),
     "mi_int8_linear_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "mi_int8_linear": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, _P, c_int64, c_int, _P]),
+    "mi_int8_linear_partials": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int64, _P, c_int64, POINTER(c_int32), _P]),
+    "mi_fused_add_rms_norm_splitk_int8": (c_int, [_P, _P, _P, c_int32, _P, _P, _P, _P, _P, c_float, c_int32, c_int32, c_int64,
+                                                  c_int64, c_int, _P]),
     "mi_int8_linear_silu_mul": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_allreduce_init": (c_int, [POINTER(c_void_p), c_int32, c_int32, c_int64, c_int32, _P]),
     "mi_allreduce_register_buffer": (c_int, [_P, _P]),

@@ -87,6 +87,10 @@ class RMSNorm:
     def __call__(self, x, residual: Optional[torch.Tensor] = None, quant: bool = False):
         """``quant``: the caller feeds the result to a W8A8 linear — the normalised row leaves as int8 + scale
         (``ops.QuantizedActs``), the activation quantisation fused into this launch."""
+        if isinstance(x, ops.Int8SplitKPartials):   # a W8A8 row-parallel linear: int32 reduce + dequant folded in here
+            if residual is not None:
+                return ops.fused_add_rms_norm_splitk_int8(x, residual, self.weight, self.variance_epsilon, quant), residual
+            x = x.materialize()
         if isinstance(x, ops.SplitKPartials):   # a row-parallel linear left its split-K reduce to this kernel
             if residual is not None and not quant:
                 return ops.fused_add_rms_norm_splitk(x, residual, self.weight, self.variance_epsilon), residual
@@ -339,6 +343,10 @@ def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_re
     on the layer.  ``defer_reduce``: when the streaming kernel runs split-K, return its partials
     (``ops.SplitKPartials``) for the fused-add RMSNorm behind the layer to reduce."""
     if getattr(layer, "qweight", None) is not None:
+        if defer_reduce is True and _DEFER_REDUCE and os.environ.get("VLLM_OMNI_AMD_INT8", "kernel") == "kernel":
+            part = ops.int8_linear_partials(x, layer.qweight, layer.weight_scale, bias)   # None: no split-K plan
+            if part is not None:
+                return part
         return ops.int8_linear(x, layer.qweight, layer.weight_scale, bias)
     w = layer.weight
     if _LINEAR_MODE != "library" and x.is_cuda:
@@ -446,7 +454,9 @@ class RowParallelLinear:
         defer = (defer_reduce and self.tp_size == 1) or custom
         y = _apply_linear(self, x, self.bias if self.tp_rank == 0 else None, defer)
         if self.reduce_results and self.tp_size > 1:
-            if isinstance(y, ops.SplitKPartials):
+            if isinstance(y, ops.Int8SplitKPartials):
+                y = tensor_model_parallel_all_reduce(y.materialize())
+            elif isinstance(y, ops.SplitKPartials):
                 r = tensor_model_parallel_all_reduce_partials(y)
                 y = r if r is not None else tensor_model_parallel_all_reduce(y.materialize())
             else:

@@ -544,6 +544,77 @@ def int8_linear_q(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, w_scale:
     return out
 
 
+class Int8SplitKPartials:
+    """Exact int32 partials [split, m, n] of a split-K W8A8 projection whose reduction + dequantisation has been left
+    to the fused-add RMSNorm behind it (``fused_add_rms_norm_splitk_int8``) or ``materialize()``; same workspace
+    discipline as ``SplitKPartials``."""
+
+    __slots__ = ("part", "split", "m", "n", "xs", "ws", "bias", "dtype", "lead", "device", "_gen")
+
+    def __init__(self, part, split, m, n, xs, ws, bias, dtype, lead, device, gen):
+        self.part, self.split, self.m, self.n, self.xs, self.ws = part, split, m, n, xs, ws
+        self.bias, self.dtype, self.lead, self.device, self._gen = bias, dtype, lead, device, gen
+
+    def _live(self) -> None:
+        if _LINEAR_GEN.get(self.device) != self._gen:
+            raise RuntimeError("split-K partials were overwritten by a later linear before they were reduced")
+
+    def materialize(self) -> torch.Tensor:
+        """The 16-bit projection output (what mi_int8_linear would have returned): reduce + dequant on the device."""
+        self._live()
+        z = torch.zeros(self.m, self.n, dtype=self.dtype, device=self.device)      # residual = 0: x + 0 = x exactly
+        one = torch.ones(self.n, dtype=self.dtype, device=self.device)
+        check("mi_fused_add_rms_norm_splitk_int8", lib.mi_fused_add_rms_norm_splitk_int8(
+            _p(torch.empty_like(z)), None, _p(self.part), self.split, _p(self.xs), _p(self.ws), _p(self.bias), _p(z),
+            _p(one), 1e-6, self.m, self.n, z.stride(0), z.stride(0), _dt(self.dtype), _stream()))
+        return z.view(*self.lead, self.n)
+
+
+def int8_linear_partials(x, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor]) -> Optional[Int8SplitKPartials]:
+    """The split-K W8A8 kernel without its reduce launch, or None when this shape has no split-K plan."""
+    if isinstance(x, QuantizedActs):
+        xq, xs, lead, dtype = x.xq, x.xs, x.lead, x.dtype
+    else:
+        xq, xs = dynamic_int8_quant(x.reshape(-1, x.shape[-1]))
+        lead, dtype = tuple(x.shape[:-1]), x.dtype
+    m, k = xq.shape
+    n = wq.shape[0]
+    if not int8_linear_supported(m, n, k):
+        return None
+    need = lib.mi_int8_linear_workspace_bytes(m, n, k)
+    if not need:
+        return None
+    ws = _linear_workspace(xq.device, need)
+    split = ctypes.c_int32(0)
+    check("mi_int8_linear_partials", lib.mi_int8_linear_partials(_p(xq), _p(wq), m, n, k, xq.stride(0), _p(ws), ws.numel(),
+                                                                 ctypes.byref(split), _stream()))
+    return Int8SplitKPartials(ws, split.value, m, n, xs, w_scale, bias, dtype, lead, xq.device, _LINEAR_GEN[xq.device])
+
+
+def fused_add_rms_norm_splitk_int8(p: Int8SplitKPartials, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                                   quant: bool = False):
+    """residual <- rnd(dequant(sum of the int32 partials) (+ bias)) + residual (in place); returns
+    rmsnorm(residual) * weight — as a 16-bit tensor, or (quant) as the next W8A8 linear's ``QuantizedActs``."""
+    _gpu(residual, weight)
+    p._live()
+    r2 = residual.view(-1, residual.shape[-1])
+    if r2.shape != (p.m, p.n):
+        raise ValueError("residual shape does not match the partials")
+    dev = residual.device
+    if quant:
+        out = torch.empty(p.m, p.n, dtype=torch.int8, device=dev)
+        qs = torch.empty(p.m, dtype=torch.float32, device=dev)
+    else:
+        out = torch.empty(p.m, p.n, dtype=p.dtype, device=dev)
+        qs = None
+    check("mi_fused_add_rms_norm_splitk_int8", lib.mi_fused_add_rms_norm_splitk_int8(
+        _p(out), _p(qs), _p(p.part), p.split, _p(p.xs), _p(p.ws), _p(p.bias), _p(r2), _p(weight), float(eps), p.m, p.n,
+        out.stride(0), r2.stride(0), _dt(p.dtype), _stream()))
+    if quant:
+        return QuantizedActs(out, qs, p.lead, p.dtype)
+    return out.view(*p.lead, p.n)
+
+
 def int8_linear_silu_mul(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
     """``act_fn(gate_up_proj(x))`` with W8A8 weights in one GEMM launch (+ the activation quantisation in front)."""
     if isinstance(x, QuantizedActs):
