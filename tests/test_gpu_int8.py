@@ -208,3 +208,38 @@ def test_vectorised_quant_equals_the_scalar_kernel(dev, T, H):
     _C.check("q", _C.lib.mi_dynamic_int8_quant(sq.data_ptr(), ss.data_ptr(), x.data_ptr(), T, H, x.stride(0),
                                                _C.MI_DTYPE_BF16, torch.cuda.current_stream().cuda_stream))
     assert torch.equal(xq, sq) and torch.equal(xs, ss)
+
+
+@pytest.mark.parametrize("quant", [False, True])
+@pytest.mark.parametrize("m,n,k,bias", [(256, 3584, 18944, False), (256, 3584, 3584, True), (64, 3584, 18944, True)])
+def test_int8_splitk_reduce_folded_into_the_norm_is_bit_identical(dev, m, n, k, bias, quant):
+    """A split-K W8A8 projection whose int32 reduce + dequantisation rides in the fused-add RMSNorm behind it
+    (o_proj / down_proj -> post_attention / next input layernorm), optionally leaving as the next linear's int8
+    activation: same bits as mi_int8_linear (with its reduce launch) -> mi_fused_add_rms_norm (-> quantisation)."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * 2).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    b = torch.randn(n, generator=g).to(torch.bfloat16).to(dev) if bias else None
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16).to(dev)
+    nw = (1 + 0.1 * torch.randn(n, generator=g)).to(torch.bfloat16).to(dev)
+    wq, ws = ops.dynamic_int8_quant(w)
+    xq, xs = ops.dynamic_int8_quant(x)
+    # unfused
+    y = ops.int8_linear_q(xq, xs, wq, ws, b, torch.bfloat16)
+    r_ref = res.clone()
+    ops.fused_add_rms_norm(y, r_ref, nw, 1e-6)
+    # fused
+    part = ops.int8_linear_partials(ops.QuantizedActs(xq, xs, (m,), torch.bfloat16), wq, ws, b)
+    assert part is not None and part.split > 1
+    assert torch.equal(part.materialize(), ops.int8_linear_q(xq, xs, wq, ws, b, torch.bfloat16))
+    part = ops.int8_linear_partials(ops.QuantizedActs(xq, xs, (m,), torch.bfloat16), wq, ws, b)   # (materialize ran a linear)
+    r_got = res.clone()
+    out = ops.fused_add_rms_norm_splitk_int8(part, r_got, nw, 1e-6, quant=quant)
+    assert torch.equal(r_got, r_ref)
+    if quant:
+        eq, es = ops.dynamic_int8_quant(y)
+        assert torch.equal(out.xq, eq) and torch.equal(out.xs, es)
+    else:
+        assert torch.equal(out, y)
