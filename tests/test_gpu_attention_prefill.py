@@ -123,3 +123,50 @@ def test_prefill_rejects_unsupported(dev):
                                torch.tensor([5], dtype=torch.int32, device=dev),
                                torch.tensor([0, 5], dtype=torch.int32, device=dev), 5, 1.0)
     assert ei.value.code == _C.MI_ERR_UNSUPPORTED   # only head_dim 64 / 128 are built
+
+
+@pytest.mark.parametrize("d", [128, 64])
+def test_prefill_running_max_jumps_late(dev, d):
+    """The kernel keeps a per-column REFERENCE maximum and raises it only when a score outgrows it by more than a
+    threshold (deferred rescale, csrc/paged_attn_prefill.hip): a rare, data-dependent branch that bounded random data
+    never takes (programming guide §5.4 rule 26).  Keys planted late in the context score far above everything before
+    them for SOME query rows of a tile (and not for the others), several times in one tile: everything accumulated at
+    the old reference must be rescaled exactly once.  Full-tensor comparison with the oracle; also a tile whose FIRST
+    step already holds the spike, and growth just under / over the threshold."""
+    from vllm_omni_amd import ops
+
+    nq, nkv, bs = 8, 2, 16
+    g = torch.Generator().manual_seed(31 + d)
+    ctx, chunk = 500, 96
+    n = ctx + chunk
+    max_blocks = (n + bs - 1) // bs
+    nb = max_blocks + 3
+    kv = torch.randn(nb, 2, bs, nkv, d, generator=g).to(torch.bfloat16)
+    table = (torch.randperm(nb - 1, generator=g)[:max_blocks] + 1).view(1, max_blocks).to(torch.int32)
+    q = torch.randn(chunk, nq, d, generator=g).to(torch.bfloat16)
+
+    def plant(tok, qrow, head, gain):
+        blk, off = int(table[0, tok // bs]), tok % bs
+        kv[blk, 0, off, head // (nq // nkv)] = (q[qrow, head].float() * gain).to(torch.bfloat16)
+
+    plant(3, 5, 0, 2.5)          # inside the first step of the tile: the textbook path
+    plant(300, 5, 0, 3.0)        # later and larger: the reference must move (scale ~ 3 |q|^2 d^-0.5 >> threshold)
+    plant(450, 5, 0, 4.0)        # and again
+    plant(320, 40, 3, 3.0)       # another tile (rows 32-63), another head
+    plant(510, 70, 7, 3.5)       # inside the chunk itself (causal region), third tile
+    plant(200, 17, 1, 0.33)      # growth of the order of the threshold
+    plant(260, 17, 1, 0.36)
+    qsl = torch.tensor([0, chunk], dtype=torch.int32)
+    seq_lens = torch.tensor([n], dtype=torch.int32)
+    ref = ref_ops.paged_attention_prefill(q, kv[:, 0], kv[:, 1], table, seq_lens, qsl, d ** -0.5)
+    kvg = kv.to(dev)
+    out = torch.full((chunk, nq * d), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.paged_attn_prefill(out, q.view(chunk, -1).to(dev), kvg[:, 0], kvg[:, 1], table.to(dev), seq_lens.to(dev),
+                           qsl.to(dev), chunk, d ** -0.5)
+    torch.cuda.synchronize()
+    got = out.cpu().float().view(chunk, nq, d)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, ref, rtol=4e-3, atol=8e-3)
+    # the planted rows really are dominated by their spike (the branch was exercised, not skipped)
+    blk, off = int(table[0, 450 // bs]), 450 % bs
+    torch.testing.assert_close(got[5, 0], kv[blk, 1, off, 0].float(), rtol=2e-2, atol=2e-2)

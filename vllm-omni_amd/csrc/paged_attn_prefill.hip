@@ -202,21 +202,34 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     }
   };
 
-  float m[NC], l[NC];
+  // Online softmax with the running maximum OFF the critical path (round 2; the step was VALU-issue-bound on the
+  // softmax: profiles/r01_pmc_prefill_kernel.md, ~100 VALU + 16 v_exp per 32 MFMAs).  mu[c] is a per-column reference
+  // maximum in UNSCALED score units.  The score accumulators START at -mu (the MFMA's C input), so S' = K.Q^T - mu
+  // leaves the matrix pipe ready for p = exp2(S' * scale): no subtraction, no per-step max reduction in front of the
+  // exponentials.  mu is the reference of the PREVIOUS steps (the guide's deferred-max rule, T13): a step whose
+  // scores stay within kThr (log2 units) above it keeps it — p may then exceed 1 by at most 2^kThr, harmless for a
+  // bf16 / f16 P and fp32 accumulators — and only a step where some score of the wave grows past the threshold (a
+  // lane-local test + one ballot) takes the slow path AFTER its P.V: row maximum across the four lane rows, mu raised,
+  // acc and l rescaled by exp2(-growth).  Everything at the old reference is scaled exactly once: P of the step was
+  // exponentiated against the old mu and has been multiplied into acc before the rescale.  The first step of a tile
+  // has no reference yet: it runs the textbook order (scores with C = 0, row maximum, then the exponentials).
+  constexpr float kThr = 6.0f;
+  float mu[NC], l[NC];
   f32x4_t acc[NC][NT];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    m[c] = -3.0e38f;
+    mu[c] = 0.f;
     l[c] = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[c][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  // One 32-key step.  Order chosen for overlap inside the wave: all QK^T MFMAs are issued first, the V
-  // reads are issued (and land) behind them, the softmax VALU of column tile 0 runs while the MFMAs of
-  // tile 1 still occupy the matrix pipe, the PV MFMAs follow back to back.
-  auto compute = [&](int t, auto stc) {
+  // One 32-key step.  Order chosen for overlap inside the wave: all QK^T MFMAs are issued first, the V reads are
+  // issued (and land) behind them, the exponentials of column tile 0 run while the MFMAs of tile 1 still occupy the
+  // matrix pipe, the PV MFMAs follow back to back.
+  auto compute = [&](int t, auto stc, auto firstc) {
     constexpr int ST = decltype(stc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
     constexpr int SB = ST * STAGE;
     if (!active) return;
     u32x4_t k0[KS], k1[KS];
@@ -225,8 +238,9 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     f32x4_t s0[NC], s1[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      s0[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      s1[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const float ci = FIRST ? 0.f : -mu[c];
+      s0[c] = f32x4_t{ci, ci, ci, ci};
+      s1[c] = f32x4_t{ci, ci, ci, ci};
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         s0[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k0[s]), qf[c][s], s0[c]);
@@ -238,40 +252,34 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     for (int nb = 0; nb < NT / 4; ++nb) lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[4 * nb], a0[nb], a1[nb]);
 
     uint4 pb[NC];  // P^T operand per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
+    float grow[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       // lane: query column `col` of tile c, keys t*32 + 4g + r (s0[r]) and t*32 + 16 + 4g + r (s1[r])
-      f32x2_t v[4] = {{s0[c][0], s0[c][1]}, {s0[c][2], s0[c][3]}, {s1[c][0], s1[c][1]}, {s1[c][2], s1[c][3]}};
+      float v[8] = {s0[c][0], s0[c][1], s0[c][2], s0[c][3], s1[c][0], s1[c][1], s1[c][2], s1[c][3]};
       const int qpos = qpos0 + kColTile * c;
       if ((t + 1) * kStep > ctx_off + tile0 + kColTile * c + 1) {  // the step reaches past the tile's first diagonal key
         const int kb = t * kStep + 4 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (kb + r > qpos) v[r >> 1][r & 1] = -INFINITY;
-          if (kb + 16 + r > qpos) v[2 + (r >> 1)][r & 1] = -INFINITY;
+          if (kb + r > qpos) v[r] = -INFINITY;
+          if (kb + 16 + r > qpos) v[4 + r] = -INFINITY;
         }
       }
-      float mx = max3f(max3f(v[0][0], v[0][1], v[1][0]), max3f(v[1][1], v[2][0], v[2][1]), max2f(v[3][0], v[3][1]));
-      mx = rows_allreduce_max(mx);
-      const float m_new = max2f(m[c], mx * p.scale_log2e);  // scale > 0: max commutes with it
-      if (__any(m_new != m[c])) {
-        const float alpha = fast_exp2(m[c] - m_new);
-        m[c] = m_new;
-        l[c] *= alpha;
+      float mx = max3f(max3f(v[0], v[1], v[2]), max3f(v[3], v[4], v[5]), max2f(v[6], v[7]));
+      if constexpr (FIRST) {   // no reference yet: textbook order
+        mx = rows_allreduce_max(mx);
+        mu[c] = mx;            // key 0 is visible to every column of a tile: finite
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[c][n] *= alpha;
+        for (int i = 0; i < 8; ++i) v[i] -= mx;
+        grow[c] = 0.f;
+      } else {
+        grow[c] = mx;          // S' = s - mu: growth of the row maximum over the reference, unscaled
       }
-      const f32x2_t sc = {p.scale_log2e, p.scale_log2e}, nm = {-m[c], -m[c]};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {  // packed fma (v_pk_fma_f32), then the quarter-rate exp per element
-        v[i] = __builtin_elementwise_fma(v[i], sc, nm);
-        v[i][0] = fast_exp2(v[i][0]);
-        v[i][1] = fast_exp2(v[i][1]);
-      }
-      const f32x2_t ls = (v[0] + v[1]) + (v[2] + v[3]);
-      l[c] += ls[0] + ls[1];
-      pb[c] = make_uint4(E::pack(v[0][0], v[0][1]), E::pack(v[1][0], v[1][1]), E::pack(v[2][0], v[2][1]),
-                         E::pack(v[3][0], v[3][1]));
+      for (int i = 0; i < 8; ++i) v[i] = fast_exp2(v[i] * p.scale_log2e);
+      l[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      pb[c] = make_uint4(E::pack(v[0], v[1]), E::pack(v[2], v[3]), E::pack(v[4], v[5]), E::pack(v[6], v[7]));
     }
 #pragma unroll
     for (int nb = 0; nb < NT / 4; ++nb) {
@@ -280,6 +288,23 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
         const uint4 a = make_uint4(a0[nb][n][0], a0[nb][n][1], a1[nb][n][0], a1[nb][n][1]);
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
+      }
+    }
+    if constexpr (!FIRST) {
+      // rare path: some row maximum of this wave outgrew its reference by more than the threshold
+      bool any_grow = false;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) any_grow |= grow[c] * p.scale_log2e > kThr;
+      if (__any(any_grow)) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float gr = max2f(rows_allreduce_max(grow[c]), 0.f);   // per column, the same in its four lane rows
+          const float alpha = fast_exp2(-gr * p.scale_log2e);
+          mu[c] += gr;
+          l[c] *= alpha;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[c][n] *= alpha;
+        }
       }
     }
   };
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   unsigned long long tacc[4] = {0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
 #endif
-  auto step = [&](int t, auto stc) {
+  auto step = [&](int t, auto stc, auto firstc) {
     constexpr int ST = decltype(stc)::value;
     if (t + 1 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
     MI_TICK(0);
@@ -303,15 +328,17 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     MI_TICK(1);
     if (t + 2 < t_end) issue(t + 2, (ST + 2) % NSTAGE);
     MI_TICK(2);
-    compute(t, stc);
+    compute(t, stc, firstc);
     MI_TICK(3);
   };
   issue(0, 0);
   if (1 < t_end) issue(1, 1);
-  for (int t = 0; t < t_end; t += 3) {
-    step(t, S0{});
-    if (t + 1 < t_end) step(t + 1, S1{});
-    if (t + 2 < t_end) step(t + 2, S2{});
+  // step 0 (the only one without a reference maximum) is peeled; the ring position continues at stage 1
+  step(0, S0{}, std::true_type{});
+  for (int t = 1; t < t_end; t += 3) {
+    step(t, S1{}, std::false_type{});
+    if (t + 1 < t_end) step(t + 1, S2{}, std::false_type{});
+    if (t + 2 < t_end) step(t + 2, S0{}, std::false_type{});
   }
 
 #ifdef MI_PREFILL_TIMING
