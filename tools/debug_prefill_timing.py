@@ -11,7 +11,7 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "vllm-omni_amd", "build", "libvllm_omni_amd_timing.so"))
+lib = ctypes.CDLL(os.environ.get("MI_TIMING_LIB") or os.path.join(ROOT, "vllm-omni_amd", "build", "libvllm_omni_amd_timing.so"))
 lib.mi_paged_attn_prefill.restype = ctypes.c_int
 lib.mi_paged_attn_prefill.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int32] * 8 + [ctypes.c_float] + [ctypes.c_int64] * 5 + [
     ctypes.c_int, ctypes.c_void_p]
@@ -55,7 +55,8 @@ def main():
             continue
         tot = sum(row[:4])
         print(f"wave {w}: steps={steps} total={tot * 10 / 1e3:.1f} us | " +
-              " ".join(f"{n}={row[i] * 10 / steps:.0f}ns" for i, n in enumerate(names)))
+              " ".join(f"{n}={row[i] * 10 / steps:.0f}ns" for i, n in enumerate(names)) +
+              (f" | shader clock {row[4] / (row[5] * 10e-9) / 1e9:.2f} GHz" if row[5] else ""))
 
 
 if __name__ == "__main__":

@@ -46,6 +46,9 @@ struct PrefillParams {
 };
 
 constexpr int kColTile = 16;  // query tokens per MFMA column tile
+#ifndef MI_PREFILL_STAGGER
+#define MI_PREFILL_STAGGER 1   // waves 4.. run half a step behind their SIMD partners (A/B: make variant VARIANT_DEFS=-DMI_PREFILL_STAGGER=0)
+#endif
 
 // Phase timing for tools/debug_prefill_timing.py: compiled only with -DMI_PREFILL_TIMING (`make dbg`
 // builds a separate library), never in the product library.  Workgroup (0,0,0) — the longest tile —
@@ -224,21 +227,26 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     for (int n = 0; n < NT; ++n) acc[c][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  // One 32-key step.  Order chosen for overlap inside the wave: all QK^T MFMAs are issued first, the V reads are
-  // issued (and land) behind them, the exponentials of column tile 0 run while the MFMAs of tile 1 still occupy the
-  // matrix pipe, the PV MFMAs follow back to back.
-  auto compute = [&](int t, auto stc, auto firstc) {
+  // One 32-key step in two halves.  h1: K fragment reads, the QK^T MFMAs (accumulators start at -mu), V fragment reads.
+  // h2: exponentials, row sums, the PV MFMAs, the rare reference raise.  The scores and the V fragments live in
+  // registers between the two.  Waves 0-3 run h1(t), h2(t) behind barrier t; waves 4-6(7) — the SIMD partners of
+  // waves 0-2(3): a workgroup's waves go to the SIMDs cyclically — run h2(t - 1), h1(t): after every barrier one wave
+  // of a SIMD is in its matrix-heavy half while its partner is in the VALU-heavy one, instead of both competing for
+  // the matrix pipe and then both for the vector issue slots (MI355X_MICROARCH.md, two waves per SIMD, item 9: the
+  // stagger; same barrier count, same ring: a staggered wave has read everything it needs from stage t - 1 in
+  // h1(t - 1), before barrier t lets the loaders refill it).
+  f32x4_t s0[NC], s1[NC];
+  u32x2_t a0[NT / 4][4], a1[NT / 4][4];
+  auto h1 = [&](int t, auto stc) {
     constexpr int ST = decltype(stc)::value;
-    constexpr bool FIRST = decltype(firstc)::value;
     constexpr int SB = ST * STAGE;
     if (!active) return;
     u32x4_t k0[KS], k1[KS];
     if constexpr (KS == 4) lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
     else lds_read_rows4<SB, SB + 16 * ROWB>(k_rd, k0, k1);
-    f32x4_t s0[NC], s1[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const float ci = FIRST ? 0.f : -mu[c];
+      const float ci = t == 0 ? 0.f : -mu[c];
       s0[c] = f32x4_t{ci, ci, ci, ci};
       s1[c] = f32x4_t{ci, ci, ci, ci};
 #pragma unroll
@@ -247,10 +255,12 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
         s1[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k1[s]), qf[c][s], s1[c]);
       }
     }
-    u32x2_t a0[NT / 4][4], a1[NT / 4][4];
 #pragma unroll
     for (int nb = 0; nb < NT / 4; ++nb) lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[4 * nb], a0[nb], a1[nb]);
-
+  };
+  auto h2 = [&](int t) {
+    if (!active) return;
+    const bool first = t == 0;   // wave-uniform
     uint4 pb[NC];  // P^T operand per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
     float grow[NC];
 #pragma unroll
@@ -267,14 +277,13 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
         }
       }
       float mx = max3f(max3f(v[0], v[1], v[2]), max3f(v[3], v[4], v[5]), max2f(v[6], v[7]));
-      if constexpr (FIRST) {   // no reference yet: textbook order
+      grow[c] = mx;            // S' = s - mu: growth of the row maximum over the reference, unscaled
+      if (first) {             // no reference yet: textbook order
         mx = rows_allreduce_max(mx);
         mu[c] = mx;            // key 0 is visible to every column of a tile: finite
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] -= mx;
         grow[c] = 0.f;
-      } else {
-        grow[c] = mx;          // S' = s - mu: growth of the row maximum over the reference, unscaled
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = fast_exp2(v[i] * p.scale_log2e);
@@ -290,28 +299,26 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
         for (int c = 0; c < NC; ++c) acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
       }
     }
-    if constexpr (!FIRST) {
-      // rare path: some row maximum of this wave outgrew its reference by more than the threshold
-      bool any_grow = false;
+    // rare path: some row maximum of this wave outgrew its reference by more than the threshold
+    bool any_grow = false;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) any_grow |= grow[c] * p.scale_log2e > kThr;
-      if (__any(any_grow)) {
+    for (int c = 0; c < NC; ++c) any_grow |= grow[c] * p.scale_log2e > kThr;
+    if (__any(any_grow)) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const float gr = max2f(rows_allreduce_max(grow[c]), 0.f);   // per column, the same in its four lane rows
-          const float alpha = fast_exp2(-gr * p.scale_log2e);
-          mu[c] += gr;
-          l[c] *= alpha;
+      for (int c = 0; c < NC; ++c) {
+        const float gr = max2f(rows_allreduce_max(grow[c]), 0.f);   // per column, the same in its four lane rows
+        const float alpha = fast_exp2(-gr * p.scale_log2e);
+        mu[c] += gr;
+        l[c] *= alpha;
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[c][n] *= alpha;
-        }
+        for (int n = 0; n < NT; ++n) acc[c][n] *= alpha;
       }
     }
   };
 
   // ---- pipeline: ring of three stages, one barrier per step.  Per step t:
   //      [my DMAs of stage t landed] barrier (=> stage t complete, stage t-1 consumed by every wave)
-  //      [issue stage t+2 over stage t-1] [compute t].  The issuing waves' only vector-memory
+  //      [issue stage t+2 over stage t-1] [compute].  The issuing waves' only vector-memory
   //      operations are their SHARE DMA instructions per stage, retired in order.
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -319,8 +326,10 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
 #ifdef MI_PREFILL_TIMING
   unsigned long long tacc[4] = {0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = tprev;   // shader clock vs the 100 MHz counter
 #endif
-  auto step = [&](int t, auto stc, auto firstc) {
+  const bool stag = wid >= 4 && MI_PREFILL_STAGGER;   // wave-uniform (wid went through readfirstlane)
+  auto step = [&](int t, auto stc, auto stagc) {
     constexpr int ST = decltype(stc)::value;
     if (t + 1 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
     MI_TICK(0);
@@ -328,23 +337,40 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     MI_TICK(1);
     if (t + 2 < t_end) issue(t + 2, (ST + 2) % NSTAGE);
     MI_TICK(2);
-    compute(t, stc, firstc);
+    if constexpr (!decltype(stagc)::value) {
+      h1(t, stc);
+      h2(t);
+    } else {
+      if (t > 0) h2(t - 1);
+      h1(t, stc);
+    }
     MI_TICK(3);
   };
   issue(0, 0);
   if (1 < t_end) issue(1, 1);
-  // step 0 (the only one without a reference maximum) is peeled; the ring position continues at stage 1
-  step(0, S0{}, std::true_type{});
-  for (int t = 1; t < t_end; t += 3) {
-    step(t, S1{}, std::false_type{});
-    if (t + 1 < t_end) step(t + 1, S2{}, std::false_type{});
-    if (t + 2 < t_end) step(t + 2, S0{}, std::false_type{});
+  // the loop is written out once per role: with the role as a run-time branch inside one loop the scores and V
+  // fragments become loop-carried on both paths and the allocator spills
+  if (!stag) {
+    for (int t = 0; t < t_end; t += 3) {
+      step(t, S0{}, std::false_type{});
+      if (t + 1 < t_end) step(t + 1, S1{}, std::false_type{});
+      if (t + 2 < t_end) step(t + 2, S2{}, std::false_type{});
+    }
+  } else {
+    for (int t = 0; t < t_end; t += 3) {
+      step(t, S0{}, std::true_type{});
+      if (t + 1 < t_end) step(t + 1, S1{}, std::true_type{});
+      if (t + 2 < t_end) step(t + 2, S2{}, std::true_type{});
+    }
+    h2(t_end - 1);
   }
 
 #ifdef MI_PREFILL_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) mi_prefill_ticks[wid][i] = tacc[i];
+    mi_prefill_ticks[wid][4] = __builtin_amdgcn_s_memtime() - clk0;
+    mi_prefill_ticks[wid][5] = __builtin_amdgcn_s_memrealtime() - rt0;
     mi_prefill_ticks[wid][7] = (unsigned long long)t_end;
   }
 #endif
