@@ -94,6 +94,34 @@ __device__ __forceinline__ void lds_read_tr8(const uint32_t* addr, u32x2_t (&a0)
       : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(IMM0), "i"(IMM1)
       : "memory");
 }
+// 16 transposed reads (eight d-tiles x two sub-tiles: head_dim 128) and ONE wait: one exposed LDS latency per V tile.
+template <int IMM0, int IMM1>
+__device__ __forceinline__ void lds_read_tr16(const uint32_t* addr, u32x2_t (&a0)[4], u32x2_t (&a1)[4], u32x2_t (&b0)[4],
+                                              u32x2_t (&b1)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %4, %16 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %1, %17 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %5, %17 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %2, %18 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %6, %18 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %3, %19 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %7, %19 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %8, %20 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %12, %20 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %9, %21 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %13, %21 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %10, %22 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %14, %22 offset:%25\n\t"
+      "ds_read_b64_tr_b16 %11, %23 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %15, %23 offset:%25\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0[0]), "=&v"(a0[1]), "=&v"(a0[2]), "=&v"(a0[3]), "=&v"(a1[0]), "=&v"(a1[1]), "=&v"(a1[2]), "=&v"(a1[3]),
+        "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3]), "=&v"(b1[0]), "=&v"(b1[1]), "=&v"(b1[2]), "=&v"(b1[3])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
+        "i"(IMM0), "i"(IMM1)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");

@@ -46,6 +46,10 @@ struct PrefillParams {
 };
 
 constexpr int kColTile = 16;  // query tokens per MFMA column tile
+#ifndef MI_PREFILL_ABLATE
+#define MI_PREFILL_ABLATE 0   // experiments only (wrong results): 1 no softmax arithmetic, 2 no MFMAs, 4 no LDS fragment reads,
+                              // 8 barrier on even steps only (an upper bound for a 64-key step)
+#endif
 #ifndef MI_PREFILL_STAGGER
 #define MI_PREFILL_STAGGER 1   // waves 4.. run half a step behind their SIMD partners (A/B: make variant VARIANT_DEFS=-DMI_PREFILL_STAGGER=0)
 #endif
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   constexpr int IPS = 16 / RPI;      // DMA instructions per 16-row sub-tile: 4 / 2
   constexpr int IMG = kStep * ROWB;  // 8 KiB
   constexpr int STAGE = 2 * IMG;
-  constexpr int NSTAGE = 3;
+  constexpr int NSTAGE = 4;
   constexpr int DMA_PER_STAGE = 4 * IPS;        // 16 wave-instructions fill one stage
   constexpr int SHARE = DMA_PER_STAGE / NI;      // per issuing wave
   __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
@@ -168,6 +172,11 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
       my_off[u][ii] = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
     }
   }
+  // The block id of a sub-tile is fetched one call AHEAD (issue() is called for t = 0, 1, 2, ... in order): the scalar
+  // load's latency sat in front of the DMA instructions of every step otherwise (180 ns per step on the issuing waves).
+  int32_t bt_next[SUBS];
+#pragma unroll
+  for (int u = 0; u < SUBS; ++u) bt_next[u] = wid < NI ? bt_row[min((16 * ((wid * SUBS + u) & 1)) >> p.bs_log2, last_blk)] : 0;
   auto issue = [&](int t, int st) {  // my share of the stage (waves >= NI issue nothing)
     if (wid >= NI) return;
     const bool tail = (t + 1) * kStep > limit;  // wave-uniform: some rows of the step are past `limit`
@@ -179,10 +188,11 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
       char* dst = smem + st * STAGE + (is_v ? IMG : 0) + 16 * j * ROWB;
       const char* const img = is_v ? vbase_b : kbase_b;
       const int tok0 = t * kStep + 16 * j;
+      const int32_t blk_id = bt_next[u];
+      bt_next[u] = bt_row[min((tok0 + kStep) >> p.bs_log2, last_blk)];
       if (!(tail && is_v)) {
         // K rows past `limit` may hold anything: their scores are replaced by -inf, never multiplied
-        const int blk = min(tok0 >> p.bs_log2, last_blk);
-        const char* src = img + (uint64_t)(uint32_t)bt_row[blk] * blk_bytes + (uint32_t)(tok0 & bs_mask) * tok_bytes;
+        const char* src = img + (uint64_t)(uint32_t)blk_id * blk_bytes + (uint32_t)(tok0 & bs_mask) * tok_bytes;
 #pragma unroll
         for (int ii = 0; ii < IPS; ++ii) {
           __builtin_amdgcn_global_load_lds((gbl_void*)(src + my_off[u][ii]), (lds_void*)(dst + RPI * ii * ROWB), 16, 0, 0);
@@ -206,123 +216,172 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   };
 
   // Online softmax with the running maximum OFF the critical path (round 2; the step was VALU-issue-bound on the
-  // softmax: profiles/r01_pmc_prefill_kernel.md, ~100 VALU + 16 v_exp per 32 MFMAs).  mu[c] is a per-column reference
-  // maximum in UNSCALED score units.  The score accumulators START at -mu (the MFMA's C input), so S' = K.Q^T - mu
-  // leaves the matrix pipe ready for p = exp2(S' * scale): no subtraction, no per-step max reduction in front of the
-  // exponentials.  mu is the reference of the PREVIOUS steps (the guide's deferred-max rule, T13): a step whose
-  // scores stay within kThr (log2 units) above it keeps it — p may then exceed 1 by at most 2^kThr, harmless for a
-  // bf16 / f16 P and fp32 accumulators — and only a step where some score of the wave grows past the threshold (a
-  // lane-local test + one ballot) takes the slow path AFTER its P.V: row maximum across the four lane rows, mu raised,
-  // acc and l rescaled by exp2(-growth).  Everything at the old reference is scaled exactly once: P of the step was
-  // exponentiated against the old mu and has been multiplied into acc before the rescale.  The first step of a tile
-  // has no reference yet: it runs the textbook order (scores with C = 0, row maximum, then the exponentials).
+  // softmax: profiles/r01_pmc_prefill_kernel.md).  mu[c] is a per-column reference maximum in UNSCALED score units.
+  // p = exp2(fma(s, scale, -mu * scale)): the subtraction rides in the multiply every exponent needs anyway, and there
+  // is no cross-lane maximum in front of the exponentials (issue costs: v_exp 8 cycles, every other vector instruction
+  // 4, an MFMA 8 of its 16 — MI355X_MICROARCH.md constants table; the step is bound by that port).  mu is the reference
+  // of the PREVIOUS steps (the guide's deferred-max rule, T13): a step whose scores stay within kThr (log2 units)
+  // above it keeps it — p may then exceed 1 by at most 2^kThr, harmless for a bf16 / f16 P and fp32 accumulators —
+  // and only a step where some score of the wave grows past the threshold (a lane-local test + one ballot) takes the
+  // slow path BEFORE its exponentials: row maximum across the four lane rows, mu raised, acc and l (which hold exactly
+  // the steps before this one) rescaled by exp2(-growth).  The first step of a tile has no reference yet and always
+  // takes that path.
   constexpr float kThr = 6.0f;
-  float mu[NC], l[NC];
+  const float thr_raw = kThr / p.scale_log2e;   // the threshold in unscaled score units
+  float mu[NC], nms[NC], mu_thr[NC], l[NC];     // reference, -mu * scale (the exponent's addend), mu + threshold
   f32x4_t acc[NC][NT];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     mu[c] = 0.f;
+    nms[c] = 0.f;
+    mu_thr[c] = 0.f;
     l[c] = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[c][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  // One 32-key step in two halves.  h1: K fragment reads, the QK^T MFMAs (accumulators start at -mu), V fragment reads.
-  // h2: exponentials, row sums, the PV MFMAs, the rare reference raise.  The scores and the V fragments live in
-  // registers between the two.  Waves 0-3 run h1(t), h2(t) behind barrier t; waves 4-6(7) — the SIMD partners of
-  // waves 0-2(3): a workgroup's waves go to the SIMDs cyclically — run h2(t - 1), h1(t): after every barrier one wave
-  // of a SIMD is in its matrix-heavy half while its partner is in the VALU-heavy one, instead of both competing for
-  // the matrix pipe and then both for the vector issue slots (MI355X_MICROARCH.md, two waves per SIMD, item 9: the
-  // stagger; same barrier count, same ring: a staggered wave has read everything it needs from stage t - 1 in
-  // h1(t - 1), before barrier t lets the loaders refill it).
+  // A 32-key step is a MATRIX phase and a VECTOR phase (two waves per SIMD, MI355X_MICROARCH.md item 9: ping-pong):
+  //   qk(t):  K(t) fragments from the ring, 16 MFMAs: s = K.Q^T
+  //   pv(t'): V(t') fragments from the ring, 16 MFMAs: acc += V^T.P(t')        — one step BEHIND the scores
+  //   sm(t):  masks, lane-local maximum, exponentials, row sums, P(t) packed for the next matrix phase
+  // Waves 0-3 run  qk(t) pv(t-1) sm(t)  behind barrier t; their SIMD partners, waves 4-7, run  sm(t-1) qk(t) pv(t-1):
+  // one wave of a SIMD feeds the matrix pipe 32 back-to-back MFMAs while the other owns the vector issue slots, and
+  // inside a wave the softmax no longer sits between two dependent groups of MFMAs.  P (8 registers) or the scores
+  // (16) cross the barrier; V(t-1) is read during step t, so the ring has FOUR stages: after barrier t the loaders
+  // refill stage t-2, last read (V) during step t-1.
   f32x4_t s0[NC], s1[NC];
-  u32x2_t a0[NT / 4][4], a1[NT / 4][4];
-  auto h1 = [&](int t, auto stc) {
-    constexpr int ST = decltype(stc)::value;
-    constexpr int SB = ST * STAGE;
+  uint4 pb[NC];  // P^T operand per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
+  auto qk = [&](int t, auto stc) {
+    constexpr int SB = decltype(stc)::value * STAGE;
     if (!active) return;
     u32x4_t k0[KS], k1[KS];
-    if constexpr (KS == 4) lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
+    if constexpr (MI_PREFILL_ABLATE & 4) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        k0[s] = u32x4_t{k_rd[s], (uint32_t)t, k_rd[s], (uint32_t)t};
+        k1[s] = k0[s];
+        asm volatile("" : "+v"(k0[s]), "+v"(k1[s]));
+      }
+    } else if constexpr (KS == 4) lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
     else lds_read_rows4<SB, SB + 16 * ROWB>(k_rd, k0, k1);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const float ci = t == 0 ? 0.f : -mu[c];
-      s0[c] = f32x4_t{ci, ci, ci, ci};
-      s1[c] = f32x4_t{ci, ci, ci, ci};
+      s0[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      s1[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        s0[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k0[s]), qf[c][s], s0[c]);
-        s1[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k1[s]), qf[c][s], s1[c]);
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < NT / 4; ++nb) lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[4 * nb], a0[nb], a1[nb]);
-  };
-  auto h2 = [&](int t) {
-    if (!active) return;
-    const bool first = t == 0;   // wave-uniform
-    uint4 pb[NC];  // P^T operand per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
-    float grow[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      // lane: query column `col` of tile c, keys t*32 + 4g + r (s0[r]) and t*32 + 16 + 4g + r (s1[r])
-      float v[8] = {s0[c][0], s0[c][1], s0[c][2], s0[c][3], s1[c][0], s1[c][1], s1[c][2], s1[c][3]};
-      const int qpos = qpos0 + kColTile * c;
-      if ((t + 1) * kStep > ctx_off + tile0 + kColTile * c + 1) {  // the step reaches past the tile's first diagonal key
-        const int kb = t * kStep + 4 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (kb + r > qpos) v[r] = -INFINITY;
-          if (kb + 16 + r > qpos) v[4 + r] = -INFINITY;
+        if constexpr (MI_PREFILL_ABLATE & 2) {
+          s0[c][s & 3] += __builtin_bit_cast(float, k0[s][c]) * 1e-30f;
+          s1[c][s & 3] += __builtin_bit_cast(float, k1[s][c]) * 1e-30f;
+        } else {
+          s0[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k0[s]), qf[c][s], s0[c]);
+          s1[c] = mfma16<Tag>(__builtin_bit_cast(uint4, k1[s]), qf[c][s], s1[c]);
         }
       }
-      float mx = max3f(max3f(v[0], v[1], v[2]), max3f(v[3], v[4], v[5]), max2f(v[6], v[7]));
-      grow[c] = mx;            // S' = s - mu: growth of the row maximum over the reference, unscaled
-      if (first) {             // no reference yet: textbook order
-        mx = rows_allreduce_max(mx);
-        mu[c] = mx;            // key 0 is visible to every column of a tile: finite
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] -= mx;
-        grow[c] = 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fast_exp2(v[i] * p.scale_log2e);
-      l[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      pb[c] = make_uint4(E::pack(v[0], v[1]), E::pack(v[2], v[3]), E::pack(v[4], v[5]), E::pack(v[6], v[7]));
     }
+  };
+  auto pv = [&](auto stc) {
+    constexpr int SB = decltype(stc)::value * STAGE;
+    if (!active) return;
+    u32x2_t a0[NT / 4][4], a1[NT / 4][4];
+    if constexpr (MI_PREFILL_ABLATE & 4) {
+#pragma unroll
+      for (int nb = 0; nb < NT / 4; ++nb)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          a0[nb][n] = u32x2_t{v_rd[4 * nb + n], pb[0].x};
+          a1[nb][n] = a0[nb][n];
+          asm volatile("" : "+v"(a0[nb][n]), "+v"(a1[nb][n]));
+        }
+    } else if constexpr (NT == 8) lds_read_tr16<SB, SB + 16 * ROWB>(v_rd, a0[0], a1[0], a0[1], a1[1]);
+    else lds_read_tr8<SB, SB + 16 * ROWB>(v_rd, a0[0], a1[0]);
 #pragma unroll
     for (int nb = 0; nb < NT / 4; ++nb) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {  // two transposed reads == one K = 32 A operand
         const uint4 a = make_uint4(a0[nb][n][0], a0[nb][n][1], a1[nb][n][0], a1[nb][n][1]);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
-      }
-    }
-    // rare path: some row maximum of this wave outgrew its reference by more than the threshold
-    bool any_grow = false;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) any_grow |= grow[c] * p.scale_log2e > kThr;
-    if (__any(any_grow)) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const float gr = max2f(rows_allreduce_max(grow[c]), 0.f);   // per column, the same in its four lane rows
-        const float alpha = fast_exp2(-gr * p.scale_log2e);
-        mu[c] += gr;
-        l[c] *= alpha;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[c][n] *= alpha;
+        for (int c = 0; c < NC; ++c) {
+          if constexpr (MI_PREFILL_ABLATE & 2) acc[c][4 * nb + n][0] += __builtin_bit_cast(float, a.x ^ pb[c].x) * 1e-30f;
+          else acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
+        }
       }
     }
   };
+  auto pv_rt = [&](int st) {  // stage known only at run time: the step after the loop
+    if (st == 0) pv(std::integral_constant<int, 0>{});
+    else if (st == 1) pv(std::integral_constant<int, 1>{});
+    else if (st == 2) pv(std::integral_constant<int, 2>{});
+    else pv(std::integral_constant<int, 3>{});
+  };
+  auto sm = [&](int t) {
+    if (!active) return;
+    if constexpr (MI_PREFILL_ABLATE & 1) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        pb[c] = make_uint4(__builtin_bit_cast(uint32_t, s0[c][0]), __builtin_bit_cast(uint32_t, s0[c][1]),
+                           __builtin_bit_cast(uint32_t, s1[c][2]), __builtin_bit_cast(uint32_t, s1[c][3]));
+        l[c] += s0[c][2];
+      }
+      return;
+    }
+    const bool first = t == 0;   // wave-uniform
+    bool raise = first;
+    float mx[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      // lane: query column `col` of tile c, keys t*32 + 4g + r (s0[r]) and t*32 + 16 + 4g + r (s1[r]); masked in place
+      const int qpos = qpos0 + kColTile * c;
+      if ((t + 1) * kStep > ctx_off + tile0 + kColTile * c + 1) {  // the step reaches past the tile's first diagonal key
+        const int kb = t * kStep + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kb + r > qpos) s0[c][r] = -INFINITY;
+          if (kb + 16 + r > qpos) s1[c][r] = -INFINITY;
+        }
+      }
+      mx[c] = max3f(max3f(s0[c][0], s0[c][1], s0[c][2]), max3f(s0[c][3], s1[c][0], s1[c][1]), max2f(s1[c][2], s1[c][3]));
+      raise |= mx[c] > mu_thr[c];
+    }
+    if (__any(raise)) {  // rare after the first steps of a tile
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float m = rows_allreduce_max(mx[c]);   // per column, the same in its four lane rows
+        if (first) {
+          mu[c] = m;                   // key 0 is visible to every column of a tile: finite; acc and l are still zero
+        } else {
+          const float gr = max2f(m - mu[c], 0.f);
+          const float alpha = fast_exp2(-gr * p.scale_log2e);
+          mu[c] += gr;
+          l[c] *= alpha;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[c][n] *= alpha;
+        }
+        nms[c] = -mu[c] * p.scale_log2e;
+        mu_thr[c] = mu[c] + thr_raw;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = fast_exp2(__builtin_fmaf(s0[c][r], p.scale_log2e, nms[c]));
+        v[4 + r] = fast_exp2(__builtin_fmaf(s1[c][r], p.scale_log2e, nms[c]));
+      }
+      l[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      pb[c] = make_uint4(E::pack(v[0], v[1]), E::pack(v[2], v[3]), E::pack(v[4], v[5]), E::pack(v[6], v[7]));
+    }
+  };
 
-  // ---- pipeline: ring of three stages, one barrier per step.  Per step t:
-  //      [my DMAs of stage t landed] barrier (=> stage t complete, stage t-1 consumed by every wave)
-  //      [issue stage t+2 over stage t-1] [compute].  The issuing waves' only vector-memory
+  // ---- pipeline: ring of four stages, one barrier per step.  Per step t:
+  //      [my DMAs of stage t landed] barrier (=> stage t complete, every wave is done with step t-1)
+  //      [issue stage t+2 over stage t-2] [matrix / vector phases].  The issuing waves' only vector-memory
   //      operations are their SHARE DMA instructions per stage, retired in order.
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
 #ifdef MI_PREFILL_TIMING
   unsigned long long tacc[4] = {0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
@@ -331,39 +390,45 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const bool stag = wid >= 4 && MI_PREFILL_STAGGER;   // wave-uniform (wid went through readfirstlane)
   auto step = [&](int t, auto stc, auto stagc) {
     constexpr int ST = decltype(stc)::value;
+    using PREV = std::integral_constant<int, (ST + NSTAGE - 1) % NSTAGE>;
     if (t + 1 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
     MI_TICK(0);
-    __builtin_amdgcn_s_barrier();
+    if (!(MI_PREFILL_ABLATE & 8) || !(t & 1)) __builtin_amdgcn_s_barrier();
     MI_TICK(1);
     if (t + 2 < t_end) issue(t + 2, (ST + 2) % NSTAGE);
     MI_TICK(2);
     if constexpr (!decltype(stagc)::value) {
-      h1(t, stc);
-      h2(t);
+      qk(t, stc);
+      if (t > 0) pv(PREV{});
+      sm(t);
     } else {
-      if (t > 0) h2(t - 1);
-      h1(t, stc);
+      if (t > 0) sm(t - 1);
+      qk(t, stc);
+      if (t > 0) pv(PREV{});
     }
     MI_TICK(3);
   };
   issue(0, 0);
   if (1 < t_end) issue(1, 1);
-  // the loop is written out once per role: with the role as a run-time branch inside one loop the scores and V
-  // fragments become loop-carried on both paths and the allocator spills
+  // the loop is written out once per role: with the role as a run-time branch inside one loop the values that cross
+  // the barrier become loop-carried on both paths and the allocator spills
   if (!stag) {
-    for (int t = 0; t < t_end; t += 3) {
+    for (int t = 0; t < t_end; t += 4) {
       step(t, S0{}, std::false_type{});
       if (t + 1 < t_end) step(t + 1, S1{}, std::false_type{});
       if (t + 2 < t_end) step(t + 2, S2{}, std::false_type{});
+      if (t + 3 < t_end) step(t + 3, S3{}, std::false_type{});
     }
   } else {
-    for (int t = 0; t < t_end; t += 3) {
+    for (int t = 0; t < t_end; t += 4) {
       step(t, S0{}, std::true_type{});
       if (t + 1 < t_end) step(t + 1, S1{}, std::true_type{});
       if (t + 2 < t_end) step(t + 2, S2{}, std::true_type{});
+      if (t + 3 < t_end) step(t + 3, S3{}, std::true_type{});
     }
-    h2(t_end - 1);
+    sm(t_end - 1);
   }
+  pv_rt((t_end - 1) % NSTAGE);   // no stage is refilled after the last barrier
 
 #ifdef MI_PREFILL_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
