@@ -44,19 +44,19 @@ def main():
     run()
     e1.record()
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 128)()
+    buf = (ctypes.c_ulonglong * 256)()
     assert lib.mi_debug_prefill_ticks(buf) == 0
     print(f"kernel {e0.elapsed_time(e1) * 1e3:.1f} us")
-    names = ["vmcnt wait", "barrier", "dma issue", "compute"]
+    names = ["vmcnt", "barrier", "dma issue", "masks/max", "K read", "QK+exp", "V read", "PV"]
     for w in range(8):
-        row = [buf[w * 8 + i] for i in range(8)]
-        steps = row[7]
+        row = [buf[w * 16 + i] for i in range(16)]
+        steps = row[10]
         if not steps:
             continue
-        tot = sum(row[:4])
+        tot = sum(row[:8])
         print(f"wave {w}: steps={steps} total={tot * 10 / 1e3:.1f} us | " +
               " ".join(f"{n}={row[i] * 10 / steps:.0f}ns" for i, n in enumerate(names)) +
-              (f" | shader clock {row[4] / (row[5] * 10e-9) / 1e9:.2f} GHz" if row[5] else ""))
+              (f" | shader clock {row[8] / (row[9] * 10e-9) / 1e9:.2f} GHz" if row[9] else ""))
 
 
 if __name__ == "__main__":
