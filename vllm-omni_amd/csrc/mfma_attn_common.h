@@ -29,6 +29,21 @@ __device__ __forceinline__ f32x4_t mfma16<f16_tag>(const uint4& a, const uint4& 
                                                 __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
+// 32x32x16: A lane l = row l % 32, k = 8 * (l / 32) + j; B lane l = column l % 32, same k; C register i of lane l =
+// row 8 * (i / 4) + 4 * (l / 32) + i % 4, column l % 32.  The MFMA holds the SIMD's vector issue port for 8 of its 32
+// cycles (16x16x32: 8 of 16), which is what leaves room for a softmax beside it.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <typename Tag>
+__device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c);
+template <>
+__device__ __forceinline__ f32x16_t mfma32<bf16_tag>(const uint4& a, const uint4& b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16_t mfma32<f16_tag>(const uint4& a, const uint4& b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
 // K = 16 form: A and B fragments are 4 elements (one 64-bit register pair) per lane, lane l holds
 // k = 4*(l>>4) + j — exactly what one `ds_read_b64_tr_b16` delivers, so a transposed read IS an operand.
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
@@ -120,6 +135,50 @@ __device__ __forceinline__ void lds_read_tr16(const uint32_t* addr, u32x2_t (&a0
         "=&v"(b0[0]), "=&v"(b0[1]), "=&v"(b0[2]), "=&v"(b0[3]), "=&v"(b1[0]), "=&v"(b1[1]), "=&v"(b1[2]), "=&v"(b1[3])
       : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
         "i"(IMM0), "i"(IMM1)
+      : "memory");
+}
+// 8 row reads at 8 addresses, one immediate, one wait (the 32-row K tile of the 32x32x16 formulation).
+template <int IMM>
+__device__ __forceinline__ void lds_read_b128x8(const uint32_t (&addr)[8], u32x4_t (&r)[8]) {
+  asm volatile(
+      "ds_read_b128 %0, %8 offset:%16\n\t"
+      "ds_read_b128 %1, %9 offset:%16\n\t"
+      "ds_read_b128 %2, %10 offset:%16\n\t"
+      "ds_read_b128 %3, %11 offset:%16\n\t"
+      "ds_read_b128 %4, %12 offset:%16\n\t"
+      "ds_read_b128 %5, %13 offset:%16\n\t"
+      "ds_read_b128 %6, %14 offset:%16\n\t"
+      "ds_read_b128 %7, %15 offset:%16\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
+        "i"(IMM)
+      : "memory");
+}
+// 16 transposed reads at 4 addresses x 4 immediates, one wait: o[4 * n + q] = address n, immediate q.
+template <int I0, int I1, int I2, int I3>
+__device__ __forceinline__ void lds_read_tr4x4(const uint32_t (&addr)[4], u32x2_t (&o)[16]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %1, %16 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %2, %16 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %3, %16 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %4, %17 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %5, %17 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %6, %17 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %7, %17 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %8, %18 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %9, %18 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %10, %18 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %11, %18 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %12, %19 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %13, %19 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %14, %19 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %15, %19 offset:%23\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+        "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(I0), "i"(I1), "i"(I2), "i"(I3)
       : "memory");
 }
 template <int N>

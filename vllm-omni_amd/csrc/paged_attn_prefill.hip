@@ -99,12 +99,18 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int seq = blockIdx.y;
-  // blockIdx.z = (kv head, chunk of heads_per_wg query heads of its GQA group)
+  // blockIdx.x = tile-major, (kv head, chunk of heads_per_wg query heads of its GQA group) minor: the dispatcher hands
+  // out workgroups in ascending blockIdx.x, so ALL kv heads' longest tiles go first (with the kv head in blockIdx.z the
+  // order was longest-to-shortest once per kv head, and the kernel lasted 2.4x its longest tile where the work is 2.0x),
+  // and consecutive ids — which go round-robin over the 8 XCDs — are different kv heads: an XCD's L2 serves the K/V
+  // stream of nz / 8 .. 1 kv heads instead of all of them.
   // (the last chunk of a group may be short: its surplus waves keep their DMA share and the barriers
   // but compute and store nothing)
   const int chunks = (p.kv_group + p.heads_per_wg - 1) / p.heads_per_wg;
-  const int kvh = blockIdx.z / chunks;
-  const int hg = (blockIdx.z % chunks) * p.heads_per_wg + wid;
+  const int nz = (p.num_q_heads / p.kv_group) * chunks;
+  const int zz = (int)blockIdx.x % nz, tile_rank = (int)blockIdx.x / nz;
+  const int kvh = zz / chunks;
+  const int hg = (zz % chunks) * p.heads_per_wg + wid;
   const bool active = hg < p.kv_group;                            // wave-uniform
   const int head = kvh * p.kv_group + min(hg, p.kv_group - 1);    // this wave's query head
 
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const int q_len = p.query_start_loc[seq + 1] - q0;
   const int seq_len = p.seq_lens[seq];
   // longest (latest) tiles first: the dispatcher hands out blockIdx.x in ascending order
-  const int tile0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QT;  // first query row of this tile inside the chunk
+  const int tile0 = ((int)gridDim.x / nz - 1 - tile_rank) * QT;  // first query row of this tile inside the chunk
   if (tile0 >= q_len) return;              // whole workgroup: uniform
   const int ctx_off = seq_len - q_len;     // absolute position of query row 0
   const int rows = min(QT, q_len - tile0);
@@ -487,11 +493,309 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The 32x32x16 formulation: head_dim 128, chunks longer than one 16-token tile.  Same ring, same DMA, same K image;
+// what changes is the shape of the matrix instruction — a wave's 32 query tokens are ONE 32-column tile:
+//   S^T (32 keys x 32 queries) = 8 MFMAs 32x32x16 over d;  O^T (128 d x 32 queries) += 4 d-blocks x 2 key halves.
+// Why: the step is bound by the SIMD's vector issue port, which an MFMA holds for 8 cycles whether it computes 16 or 32
+// cycles (MI355X_MICROARCH.md, constants table).  16 MFMAs of 32 cycles leave 16 x 24 = 384 issue cycles per wave and
+// step for the ~320 the softmax needs; 32 MFMAs of 16 cycles left 256.
+// Lane l: query column l % 32, half h = l / 32.  Score register i holds key 8 * (i / 4) + 4h + i % 4 of the step, so P
+// registers [8m, 8m + 8) are the B operand of key half m as they stand: B k-slot j <-> key 16m + 8 * (j / 4) + 4h + j % 4,
+// and the A operand (V^T, row d = l % 32 of a d-block) names the same keys: two transposed reads, rows 16m + 4h + (0..3)
+// and 16m + 8 + 4h + (0..3).  A 16-lane group of a transposed read supplies 4 key rows x 16 d; the 32 lanes of an LDS
+// cycle cover 4 key rows x 64 B, so the V image XORs the 16-B chunk index with 4 * (row & 3): four rows, four different
+// 64-B segments, every bank once (the 16x16x32 image's 2 * (row & 7) would be 2-way here).
+template <typename Tag, int NI>
+__global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams p) {
+  scalar_cache_acquire();
+  using E = Elem<Tag>;
+  constexpr int HD = 128;
+  constexpr int QT = 32;             // query tokens per workgroup
+  constexpr int ROWB = HD * 2;
+  constexpr int KS = HD / 16;        // k-steps of S^T
+  constexpr int NB = HD / 32;        // d-blocks of O^T
+  constexpr int LPR = ROWB / 16;
+  constexpr int RPI = 64 / LPR;
+  constexpr int IPS = 16 / RPI;
+  constexpr int IMG = kStep * ROWB;
+  constexpr int STAGE = 2 * IMG;
+  constexpr int NSTAGE = 4;
+  constexpr int SHARE = 4 * IPS / NI;
+  constexpr int SUBS = 4 / NI;
+  __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int seq = blockIdx.y;
+  const int chunks = (p.kv_group + p.heads_per_wg - 1) / p.heads_per_wg;
+  const int nz = (p.num_q_heads / p.kv_group) * chunks;
+  const int zz = (int)blockIdx.x % nz, tile_rank = (int)blockIdx.x / nz;
+  const int kvh = zz / chunks;
+  const int hg = (zz % chunks) * p.heads_per_wg + wid;
+  const bool active = hg < p.kv_group;                            // wave-uniform
+  const int head = kvh * p.kv_group + min(hg, p.kv_group - 1);
+
+  const int q0 = p.query_start_loc[seq];
+  const int q_len = p.query_start_loc[seq + 1] - q0;
+  const int seq_len = p.seq_lens[seq];
+  const int tile0 = ((int)gridDim.x / nz - 1 - tile_rank) * QT;  // longest tiles first, all kv heads (see the 16x16x32 kernel)
+  if (tile0 >= q_len) return;
+  const int ctx_off = seq_len - q_len;
+  const int rows = min(QT, q_len - tile0);
+
+  const int col = lane & 31;
+  const int h = lane >> 5;
+  const int limit = ctx_off + tile0 + rows;
+  const int t_end = (limit + kStep - 1) / kStep;
+  const int qpos = ctx_off + tile0 + col;
+
+  typedef const __attribute__((address_space(4))) int32_t cint32_t;
+  cint32_t* const bt_row = (cint32_t*)(p.block_table + (int64_t)seq * p.block_table_stride);
+  const int bs_mask = (1 << p.bs_log2) - 1;
+  const int last_blk = (limit - 1) >> p.bs_log2;
+
+  // ---- Q^T fragments: column = token tile0 + col of head `head`, dims 16s + 8h ..
+  uint4 qf[KS];
+  {
+    const bool ok = col < rows;
+    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)(q0 + tile0 + (ok ? col : 0)) * p.q_stride +
+                         (int64_t)head * HD + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = ok ? *reinterpret_cast<const uint4*>(qb + 16 * s) : make_uint4(0, 0, 0, 0);
+  }
+  // ---- per-lane LDS read addresses
+  uint32_t k_rd[KS];   // K row `col`, chunk 2s + h (dims 16s + 8h ..), swizzled by row & 15: a b128 lane group = 16 rows x 16 chunks
+#pragma unroll
+  for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(col * ROWB + (((2 * s + h) ^ (col & 15)) * 16));
+  const int j16 = lane & 15, db = (lane >> 4) & 1, rho = j16 >> 2;
+  uint32_t v_rd[NB];   // V row 4h + rho (+ 16m + 8r as an immediate), dims 32n + 16db + 4 * (j16 & 3) ..
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+    v_rd[n] = (uint32_t)(IMG + (4 * h + rho) * ROWB + ((((n ^ rho) << 2) + 2 * db + ((j16 & 3) >> 1)) * 16) + 8 * (j16 & 1));
+
+  // ---- DMA issue (as in the 16x16x32 kernel; only the V swizzle differs)
+  auto swz_v32 = [](int r) { return (r & 3) << 2; };
+  const int iw = wid - ((int)(blockDim.x >> 6) - NI);
+  const uint64_t blk_bytes = (uint64_t)p.blk_stride * 2;
+  const uint32_t tok_bytes = (uint32_t)p.tok_stride * 2;
+  const uint32_t grp_bytes = RPI * tok_bytes;
+  const char* const kbase_b = reinterpret_cast<const char*>(p.k_cache);
+  const char* const vbase_b = reinterpret_cast<const char*>(p.v_cache);
+  uint32_t my_off[SUBS][IPS];
+#pragma unroll
+  for (int u = 0; u < SUBS; ++u) {
+    const bool is_v = iw * SUBS + u >= 2;
+#pragma unroll
+    for (int ii = 0; ii < IPS; ++ii) {
+      const int r = RPI * ii + lane / LPR;
+      const int c = (lane % LPR) ^ (is_v ? swz_v32(r) : swz_k<HD>(r));
+      my_off[u][ii] = (uint32_t)(((int64_t)(lane / LPR) * p.tok_stride + (int64_t)kvh * p.head_stride) * 2 + c * 16);
+    }
+  }
+  int32_t bt_next[SUBS];
+#pragma unroll
+  for (int u = 0; u < SUBS; ++u) bt_next[u] = iw >= 0 ? bt_row[min((16 * ((iw * SUBS + u) & 1)) >> p.bs_log2, last_blk)] : 0;
+  auto issue = [&](int t, int st, auto interior) {
+    if (iw < 0) return;
+    const bool tail = !decltype(interior)::value && (t + 1) * kStep > limit;
+#pragma unroll
+    for (int u = 0; u < SUBS; ++u) {
+      const int sub = iw * SUBS + u;
+      const bool is_v = sub >= 2;
+      const int j = sub & 1;
+      char* dst = smem + st * STAGE + (is_v ? IMG : 0) + 16 * j * ROWB;
+      const char* const img = is_v ? vbase_b : kbase_b;
+      const int tok0 = t * kStep + 16 * j;
+      const int32_t blk_id = bt_next[u];
+      bt_next[u] = bt_row[min((tok0 + kStep) >> p.bs_log2, last_blk)];
+      if (!(tail && is_v)) {
+        const char* src = img + (uint64_t)(uint32_t)blk_id * blk_bytes + (uint32_t)(tok0 & bs_mask) * tok_bytes;
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src + my_off[u][ii]), (lds_void*)(dst + RPI * ii * ROWB), 16, 0, 0);
+          src += grp_bytes;
+        }
+      } else {  // V rows at or past `limit` take the bytes of row limit-1 (probability exactly 0 times a finite value)
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+          const int row0 = tok0 + RPI * ii;
+          const int tok = min(row0 + lane / LPR, limit - 1);
+          const int blk = __builtin_amdgcn_readfirstlane(min(row0, limit - 1) >> p.bs_log2);
+          const int c = (lane % LPR) ^ swz_v32(RPI * ii + lane / LPR);
+          const uint64_t off = (uint64_t)(uint32_t)bt_row[blk] * blk_bytes + (uint64_t)((uint32_t)(tok & bs_mask) * tok_bytes) +
+                               (uint64_t)((int64_t)kvh * p.head_stride * 2) + (uint32_t)(c * 16);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(img + off), (lds_void*)(dst + RPI * ii * ROWB), 16, 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- online softmax state (deferred reference maximum: see the 16x16x32 kernel)
+  constexpr float kThr = 6.0f;
+  const float thr_raw = kThr / p.scale_log2e;
+  float mu = 0.f, nms = 0.f, mu_thr = 0.f, l = 0.f;
+  f32x16_t acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  f32x16_t sc[2];
+  uint4 pb[2];
+
+  auto kread = [&](auto stc, u32x4_t (&k)[KS]) { lds_read_b128x8<decltype(stc)::value * STAGE>(k_rd, k); };
+  auto qk_mfma = [&](const u32x4_t (&k)[KS], f32x16_t& s) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s = mfma32<Tag>(__builtin_bit_cast(uint4, k[ks]), qf[ks], s);
+  };
+  auto pv = [&](auto stc) {
+    constexpr int SB = decltype(stc)::value * STAGE;
+    u32x2_t o[16];
+    lds_read_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const uint4 a = make_uint4(o[4 * n + 2 * m][0], o[4 * n + 2 * m][1], o[4 * n + 2 * m + 1][0], o[4 * n + 2 * m + 1][1]);
+        acc[n] = mfma32<Tag>(a, pb[m], acc[n]);
+      }
+  };
+  auto pre = [&](int t, f32x16_t& s, auto interior) {
+    const bool first = t == 0;
+    if (!decltype(interior)::value && (t + 1) * kStep > ctx_off + tile0 + 1) {   // the step reaches the tile's diagonal
+      const int kb = t * kStep + 4 * h;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (kb + 8 * (i >> 2) + (i & 3) > qpos) s[i] = -INFINITY;
+    }
+    const float ma = max3f(max3f(s[0], s[1], s[2]), max3f(s[3], s[4], s[5]), max3f(s[6], s[7], s[8]));
+    const float mb = max3f(max3f(s[9], s[10], s[11]), max3f(s[12], s[13], s[14]), s[15]);
+    const float mx = max2f(ma, mb);
+    if (__any(first || mx > mu_thr)) {  // rare after the first steps of a tile
+      float a = mx, b = mx;
+      permlane32_swap(a, b);             // the column's other 16 keys
+      const float m = max2f(a, b);
+      if (first) {
+        mu = m;                          // key 0 is visible to every column: finite; acc and l are still zero
+      } else {
+        const float gr = max2f(m - mu, 0.f);
+        const float alpha = fast_exp2(-gr * p.scale_log2e);
+        mu += gr;
+        l *= alpha;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[n] *= alpha;
+      }
+      nms = -mu * p.scale_log2e;
+      mu_thr = mu + thr_raw;
+    }
+  };
+  auto expo = [&](const f32x16_t& s) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fast_exp2(__builtin_fmaf(s[i], p.scale_log2e, nms));
+    l += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+         (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      pb[m] = make_uint4(E::pack(v[8 * m], v[8 * m + 1]), E::pack(v[8 * m + 2], v[8 * m + 3]), E::pack(v[8 * m + 4], v[8 * m + 5]),
+                         E::pack(v[8 * m + 6], v[8 * m + 7]));
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  // one iteration (see the 16x16x32 kernel): [branches of step t's softmax] K(t+1); S(t+1) MFMAs beside the exponentials
+  // of step t; V(t); O += V(t)^T.P(t).  Ring of four stages, loaders three stages ahead.
+  auto step = [&](int t, auto stc, auto interior) {
+    constexpr int ST = decltype(stc)::value;
+    constexpr bool INT = decltype(interior)::value;
+    using NEXT = std::integral_constant<int, (ST + 1) % NSTAGE>;
+    if (INT || t + 2 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (INT || t + 3 < t_end) issue(t + 3, (ST + 3) % NSTAGE, interior);
+    if (active) {
+      pre(t, sc[ST & 1], interior);
+      u32x4_t k[KS];
+      kread(NEXT{}, k);
+      qk_mfma(k, sc[(ST + 1) & 1]);
+      expo(sc[ST & 1]);
+      if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA (32 cycles of pipe, 8 of issue)
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two exponents' fma
+          __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   // two exponentials
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // sums / packs as they become ready
+        }
+      }
+      pv(stc);
+    }
+  };
+  if (MI_PREFILL_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
+  issue(0, 0, std::false_type{});
+  if (1 < t_end) issue(1, 1, std::false_type{});
+  if (2 < t_end) issue(2, 2, std::false_type{});
+  if (2 < t_end) wait_vmcnt<2 * SHARE>();
+  else if (1 < t_end) wait_vmcnt<SHARE>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (active) {
+    u32x4_t k[KS];
+    kread(S0{}, k);
+    qk_mfma(k, sc[0]);
+  }
+  const int t_int = max(0, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
+  int t = 0;
+  for (; t < t_int; t += 4) {
+    step(t, S0{}, std::true_type{});
+    step(t + 1, S1{}, std::true_type{});
+    step(t + 2, S2{}, std::true_type{});
+    step(t + 3, S3{}, std::true_type{});
+  }
+  for (; t < t_end; t += 4) {
+    step(t, S0{}, std::false_type{});
+    if (t + 1 < t_end) step(t + 1, S1{}, std::false_type{});
+    if (t + 2 < t_end) step(t + 2, S2{}, std::false_type{});
+    if (t + 3 < t_end) step(t + 3, S3{}, std::false_type{});
+  }
+
+  // ---- epilogue: O^T -> out[token][head][dim]; lane: d = 32n + 8 * (i / 4) + 4h + i % 4
+  float la = l, lb = l;
+  permlane32_swap(la, lb);
+  const float lsum = la + lb;
+  if (active && col < rows) {
+    const float inv = 1.f / lsum;
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + col) * p.out_stride + (int64_t)head * HD + 4 * h;
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        uint2 r;
+        r.x = E::pack(acc[n][4 * q4] * inv, acc[n][4 * q4 + 1] * inv);
+        r.y = E::pack(acc[n][4 * q4 + 2] * inv, acc[n][4 * q4 + 3] * inv);
+        *reinterpret_cast<uint2*>(o + 32 * n + 8 * q4) = r;
+      }
+  }
+}
+
+template <typename Tag>
+int launch_prefill32(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
+  const int waves = p.heads_per_wg;
+  const dim3 grid(((max_query_len + 31) / 32) * num_kv_heads * ((p.kv_group + waves - 1) / waves), p.num_seqs, 1), block(64 * waves);
+  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4>), grid, block, 0, s, p);
+  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 2>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 1>), grid, block, 0, s, p);
+  return launch_status();
+}
+
 template <typename Tag, int HD, int NC>
 int launch_prefill_nc(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
   const int waves = p.heads_per_wg;  // one wave per query head
   constexpr int QT = kColTile * NC;
-  const dim3 grid((max_query_len + QT - 1) / QT, p.num_seqs, num_kv_heads * ((p.kv_group + waves - 1) / waves)),
+  const dim3 grid(((max_query_len + QT - 1) / QT) * num_kv_heads * ((p.kv_group + waves - 1) / waves), p.num_seqs, 1),
       block(64 * waves);
   if (waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4, NC>), grid, block, 0, s, p);
   else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2, NC>), grid, block, 0, s, p);
@@ -509,6 +813,13 @@ int launch_prefill(const PrefillParams& p, int num_kv_heads, int max_query_len, 
     return e ? atoi(e) : 0;
   }();
   const int nc = forced ? forced : (max_query_len > kColTile ? 2 : 1);
+  // MI_PREFILL_MM=16 keeps the 16x16x32 kernel for 32-token tiles (A/B: tools/bench_prefill_kernel.py)
+  static const bool mm16 = [] {
+    const char* e = getenv("MI_PREFILL_MM");
+    return e && atoi(e) == 16;
+  }();
+  if constexpr (HD == 128)
+    if (nc >= 2 && !mm16) return launch_prefill32<Tag>(p, num_kv_heads, max_query_len, s);
   return nc >= 2 ? launch_prefill_nc<Tag, HD, 2>(p, num_kv_heads, max_query_len, s)
                  : launch_prefill_nc<Tag, HD, 1>(p, num_kv_heads, max_query_len, s);
 }
