@@ -1,4 +1,5 @@
-"""Compact a rocprofv3 `*_kernel_stats.csv` into a short markdown table (kernel names truncated).
+"""Compact a rocprofv3 `*_kernel_stats.csv` — or the rocpd `*_results.db` newer rocprofv3 writes by default — into a
+short markdown table (kernel names truncated).
 
     python tools/summarize_rocprof.py gpurun_out/prof1/runc/842_kernel_stats.csv [--top 20] > profiles/r01_bench_kernel_stats.md
 """
@@ -20,7 +21,15 @@ def short(name: str, n: int = 72) -> str:
 def main():
     path = sys.argv[1]
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 20
-    rows = list(csv.DictReader(open(path)))
+    if path.endswith(".db"):
+        import sqlite3
+
+        con = sqlite3.connect(path)
+        rows = [dict(Name=n, Calls=str(c), TotalDurationNs=str(t), AverageNs=str(t / c), MinNs=str(lo), MaxNs=str(hi))
+                for n, c, t, lo, hi in con.execute('SELECT name, COUNT(*), SUM("end" - start), MIN("end" - start), '
+                                                   'MAX("end" - start) FROM kernels GROUP BY name')]
+    else:
+        rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"source: {path}\n")

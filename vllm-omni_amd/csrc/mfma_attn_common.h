@@ -181,6 +181,54 @@ __device__ __forceinline__ void lds_read_tr4x4(const uint32_t (&addr)[4], u32x2_
       : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(I0), "i"(I1), "i"(I2), "i"(I3)
       : "memory");
 }
+// Issue-only forms + a separate wait (guide §5.4 rule 18, form (iii)): the reads' latency runs under whatever is placed
+// between the two.  `lds_wait_all()` ends with a full scheduling barrier, so no consumer can be hoisted above the wait;
+// what this form does NOT pin is register allocation — a compiler-inserted copy of a destination register between issue
+// and wait would read stale data: tools/check_prefill_isa.py checks the built kernel for exactly that.
+template <int IMM>
+__device__ __forceinline__ void lds_issue_b128x8(const uint32_t (&addr)[8], u32x4_t (&r)[8]) {
+  asm volatile(
+      "ds_read_b128 %0, %8 offset:%16\n\t"
+      "ds_read_b128 %1, %9 offset:%16\n\t"
+      "ds_read_b128 %2, %10 offset:%16\n\t"
+      "ds_read_b128 %3, %11 offset:%16\n\t"
+      "ds_read_b128 %4, %12 offset:%16\n\t"
+      "ds_read_b128 %5, %13 offset:%16\n\t"
+      "ds_read_b128 %6, %14 offset:%16\n\t"
+      "ds_read_b128 %7, %15 offset:%16"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
+        "i"(IMM)
+      : "memory");
+}
+template <int I0, int I1, int I2, int I3>
+__device__ __forceinline__ void lds_issue_tr4x4(const uint32_t (&addr)[4], u32x2_t (&o)[16]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %1, %16 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %2, %16 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %3, %16 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %4, %17 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %5, %17 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %6, %17 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %7, %17 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %8, %18 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %9, %18 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %10, %18 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %11, %18 offset:%23\n\t"
+      "ds_read_b64_tr_b16 %12, %19 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %13, %19 offset:%21\n\t"
+      "ds_read_b64_tr_b16 %14, %19 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %15, %19 offset:%23"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+        "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(I0), "i"(I1), "i"(I2), "i"(I3)
+      : "memory");
+}
+__device__ __forceinline__ void lds_wait_all() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");

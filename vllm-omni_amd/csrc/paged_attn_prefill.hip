@@ -16,12 +16,16 @@
 //   * both contractions are K = 32 MFMAs: the two transposed reads of a d-tile (keys 4g.. of either
 //     16-row sub-tile) concatenate into one A operand, the two packed P registers pairs into the B
 //     operand — the k index only has to name the same key on both sides;
-//   * the K/V stages form a ring of three shared by the workgroup: DMA issue is split over up to four
-//     waves, ONE raw `s_barrier` per step orders "stage t landed" and "stage t-1 consumed" before
-//     stage t+2 is issued over it (no __syncthreads: its implied vmcnt(0) would drain the ring);
+//   * the K/V stages form a ring of FOUR shared by the workgroup: DMA issue is split over up to four
+//     waves, ONE raw `s_barrier` per step orders "stage t+1 landed" and "iteration t-1 done" before
+//     stage t+3 is issued over stage t-1 (no __syncthreads: its implied vmcnt(0) would drain the ring);
+//   * the step is software-pipelined inside the wave: the scores of step t+1 are computed beside the
+//     exponentials of step t (see the comment in front of `step`);
 //   * the causal mask is per lane (column = query token); only steps that touch a column tile's
 //     diagonal evaluate it; the context loop stops at the last position any column may see; tiles
-//     are dispatched longest first.
+//     are dispatched longest first over all kv heads;
+//   * head_dim 128 with chunks longer than 16 tokens runs the 32x32x16 formulation further down
+//     (`prefill_mfma32_kernel`): same ring, same DMA, one 32-column tile per wave.
 // FLOPs per layer: 2 * S^2 * d * n_q (causal).  MFMA-bound by design; K/V bytes are read once per
 // (16*NC query tokens x G heads) and served from L2/MALL for any but the first tile of a sequence.
 #include <cstdlib>
@@ -48,7 +52,7 @@ struct PrefillParams {
 constexpr int kColTile = 16;  // query tokens per MFMA column tile
 #ifndef MI_PREFILL_ABLATE
 #define MI_PREFILL_ABLATE 0   // experiments only (wrong results): 1 no softmax arithmetic, 2 no MFMAs, 4 no LDS fragment reads,
-                              // 8 barrier on even steps only (an upper bound for a 64-key step)
+                              // 8 barrier on even steps only (an upper bound for a 64-key step), 16 no DMA (32x32x16 kernel)
 #endif
 #ifndef MI_PREFILL_PRIO
 #define MI_PREFILL_PRIO 1
@@ -598,6 +602,7 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   for (int u = 0; u < SUBS; ++u) bt_next[u] = iw >= 0 ? bt_row[min((16 * ((iw * SUBS + u) & 1)) >> p.bs_log2, last_blk)] : 0;
   auto issue = [&](int t, int st, auto interior) {
     if (iw < 0) return;
+    if constexpr ((MI_PREFILL_ABLATE & 16) != 0) return;
     const bool tail = !decltype(interior)::value && (t + 1) * kStep > limit;
 #pragma unroll
     for (int u = 0; u < SUBS; ++u) {
@@ -650,10 +655,7 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) s = mfma32<Tag>(__builtin_bit_cast(uint4, k[ks]), qf[ks], s);
   };
-  auto pv = [&](auto stc) {
-    constexpr int SB = decltype(stc)::value * STAGE;
-    u32x2_t o[16];
-    lds_read_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
+  auto pv_mfma = [&](const u32x2_t (&o)[16]) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -717,9 +719,15 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
     __builtin_amdgcn_s_barrier();
     if (INT || t + 3 < t_end) issue(t + 3, (ST + 3) % NSTAGE, interior);
     if (active) {
-      pre(t, sc[ST & 1], interior);
+      constexpr int SN = NEXT::value * STAGE, SB = ST * STAGE;
+      // fragment reads run under the work that does not need them: K(t+1) under the branches of step t's softmax,
+      // V(t) under the S(t+1) MFMAs and the exponentials
       u32x4_t k[KS];
-      kread(NEXT{}, k);
+      lds_issue_b128x8<SN>(k_rd, k);
+      pre(t, sc[ST & 1], interior);
+      lds_wait_all();
+      u32x2_t o[16];
+      lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
       qk_mfma(k, sc[(ST + 1) & 1]);
       expo(sc[ST & 1]);
       if constexpr (MI_PREFILL_SCHED) {
@@ -731,7 +739,8 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // sums / packs as they become ready
         }
       }
-      pv(stc);
+      lds_wait_all();
+      pv_mfma(o);
     }
   };
   if (MI_PREFILL_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
