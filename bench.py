@@ -371,81 +371,124 @@ def main():
         if a.batch % dp:
             raise SystemExit(f"global batch {a.batch} must divide by the data-parallel degree of {label}")
 
-    results = []
-    keep = None
-    for i, (tp, dp, label, role) in enumerate(plans):
-        elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal)
-        ms = elapsed / a.steps * 1e3
-        results.append({"parallelism": label, "role": role, "ms_per_step": round(ms, 3),
-                        "value": round(a.batch * a.steps / elapsed, 1), "hipgraph": bool(runner._graphs),
-                        "decode_partition": runner._decode_part, "tuned_gemm_csv_loaded": bool(getattr(runner, "tuned_gemms", False))})
-        if i == 0:
-            keep = (runner, local_batch, tp, elapsed)
-        else:
-            del runner
-            torch.cuda.empty_cache()
-    runner, local_batch, tp, elapsed = keep
-    head = results[0]
-    ms_per_step, tokens_per_s = head["ms_per_step"], head["value"]
+    def compose(results: list[dict], failures: list[dict]) -> dict:
+        """The ONE JSON line: the widest tensor-parallel plan that produced a number is the headline (the TP scaling
+        line the metric names); every other measured plan goes to `alt_plans`, failed attempts to `failed_plans`."""
+        head = max(results, key=lambda r: r["tp"])
+        ms_per_step, tokens_per_s = head["ms_per_step"], head["value"]
+        tp = head["tp"]
+        roofline = head["roofline"]
+        if a.simulate_shard:   # the whole plan would decode the global batch in this rank's step time
+            tokens_per_s = a.batch / (ms_per_step / 1e3)
+        out = {
+            "simulated": bool(a.simulate_shard),
+            "metric": ("decode tokens/s, Qwen-Omni-7B talker, bs=256 ctx=4k"
+                       if (a.config, a.batch, a.ctx, a.quantization, a.code_predictor) == ("qwen2_5_omni_talker", 256, 4096, None, False)
+                       else f"decode tokens/s, {cfg.name}{' int8' if a.quantization else ''}"
+                            f"{' + code predictor' if a.code_predictor else ''}, bs={a.batch} ctx={a.ctx} (not the headline shape)"),
+            "value": round(tokens_per_s, 1),
+            "unit": "tokens/s", "n_gpus": n_ranks_seen, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if a.quantization is None else "bf16 (attention, norms, activations) + int8 W8A8 decoder linears",
+            "data": "synthetic (random-init weights, N(0,1) KV cache, random non-contiguous block tables, fixed ctx)",
+            "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
+                       "global_batch": a.batch, "seq_len": a.ctx, "parallelism": head["parallelism"],
+                       "plan_role": head["role"],
+                       "hipgraph": head["hipgraph"], "kv_layout": a.kv_layout,
+                       "output": "sync" if a.sync_output else "pipelined one step behind (all outputs on the host inside the timed region)",
+                       "decode_partition": head["decode_partition"],
+                       "tuned_gemm_csv_loaded": head["tuned_gemm_csv_loaded"],
+                       "allreduce": os.environ.get("VLLM_OMNI_AMD_ALLREDUCE", "rccl") if tp > 1 else "none",
+                       "linear": os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
+                       + " (auto: hand-written streaming GEMM where measured faster than the TunableOp-selected library "
+                         "kernel, library GEMM elsewhere; same bf16 inputs, fp32 accumulation)"},
+            "roofline": roofline,
+        }
+        others = [{k: v for k, v in r.items() if k != "roofline"} for r in results if r is not head]
+        if others:
+            out["alt_plans"] = others
+        if failures:
+            out["failed_plans"] = failures
+        return out
 
-    # ---- roofline of the dominant kernel (paged-attention decode), this rank, headline plan ----
-    attn = runner.model.language_model.model.layers[0].self_attn
-    # unique KV bytes one launch must read: K+V, local kv heads, head_dim, 2 B, ctx tokens, local batch
-    algo_bytes = 2 * attn.num_kv_heads * attn.head_dim * 2 * a.ctx * local_batch
-    if len(plans) > 1 and world > 1:   # the TP groups of the headline plan are the current ones again
-        from vllm_omni_amd.distributed import init_distributed_environment
-
-        init_distributed_environment(world, rank, tp, backend="gloo" if rehearsal else "nccl",
-                                     device=None if rehearsal else dev)
-    kern_ms, launches = time_decode_launches(runner, a.roofline_steps)
-    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", "pmc_decode_bytes_per_launch.json")
-    if os.path.exists(prof):
-        try:
-            with open(prof) as f:
-                pj = json.load(f)
-            if pj.get("batch") == local_batch and pj.get("ctx") == a.ctx and pj.get("tp") == tp:
-                traffic = pj.get("hbm_bytes_per_launch")
-                traffic_src = ("NOT measured in this run: rocprofv3 --pmc pass of the same command, "
-                               "profiles/pmc_decode_bytes_per_launch.json (" + str(pj.get("source", "")) + ")")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": "mi::decode_mfma_kernel (paged-attention decode)", "achieved": round(achieved, 1),
+    def roofline_of(runner, local_batch: int, tp: int) -> dict:
+        """Roofline of the dominant kernel (paged-attention decode) on this rank, for the plan `runner` was built for."""
+        attn = runner.model.language_model.model.layers[0].self_attn
+        # unique KV bytes one launch must read: K+V, local kv heads, head_dim, 2 B, ctx tokens, local batch
+        algo_bytes = 2 * attn.num_kv_heads * attn.head_dim * 2 * a.ctx * local_batch
+        kern_ms, launches = time_decode_launches(runner, a.roofline_steps)
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        prof = os.path.join(ROOT, "profiles", "pmc_decode_bytes_per_launch.json")
+        if os.path.exists(prof):
+            try:
+                with open(prof) as f:
+                    pj = json.load(f)
+                if pj.get("batch") == local_batch and pj.get("ctx") == a.ctx and pj.get("tp") == tp:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_src = ("NOT measured in this run: rocprofv3 --pmc pass of the same command, "
+                                   "profiles/pmc_decode_bytes_per_launch.json (" + str(pj.get("source", "")) + ")")
+            except Exception:
+                traffic = None
+        return {"bound": "hbm", "kernel": "mi::decode_mfma_kernel (paged-attention decode)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 4),
                 "launches_timed": launches,
                 "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
 
-    if a.simulate_shard:   # the whole plan would decode the global batch in this rank's step time
-        tokens_per_s = a.batch / (ms_per_step / 1e3)
-    out = {
-        "simulated": bool(a.simulate_shard),
-        "metric": ("decode tokens/s, Qwen-Omni-7B talker, bs=256 ctx=4k"
-                   if (a.config, a.batch, a.ctx, a.quantization, a.code_predictor) == ("qwen2_5_omni_talker", 256, 4096, None, False)
-                   else f"decode tokens/s, {cfg.name}{' int8' if a.quantization else ''}"
-                        f"{' + code predictor' if a.code_predictor else ''}, bs={a.batch} ctx={a.ctx} (not the headline shape)"),
-        "value": round(tokens_per_s, 1),
-        "unit": "tokens/s", "n_gpus": n_ranks_seen, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16" if a.quantization is None else "bf16 (attention, norms, activations) + int8 W8A8 decoder linears",
-        "data": "synthetic (random-init weights, N(0,1) KV cache, random non-contiguous block tables, fixed ctx)",
-        "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
-                   "global_batch": a.batch, "seq_len": a.ctx, "parallelism": head["parallelism"],
-                   "plan_role": head["role"],
-                   "hipgraph": head["hipgraph"], "kv_layout": a.kv_layout,
-                   "output": "sync" if a.sync_output else "pipelined one step behind (all outputs on the host inside the timed region)",
-                   "decode_partition": head["decode_partition"],
-                   "tuned_gemm_csv_loaded": head["tuned_gemm_csv_loaded"],
-                   "allreduce": os.environ.get("VLLM_OMNI_AMD_ALLREDUCE", "rccl") if tp > 1 else "none",
-                   "linear": os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
-                   + " (auto: hand-written streaming GEMM where measured faster than the TunableOp-selected library "
-                     "kernel, library GEMM elsewhere; same bf16 inputs, fp32 accumulation)"},
-        "roofline": roofline,
-    }
-    if len(results) > 1:
-        out["alt_plans"] = results[1:]
+    def measure(tp: int, dp: int, label: str, role: str) -> dict:
+        elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal)
+        ms = elapsed / a.steps * 1e3
+        res = {"parallelism": label, "role": role, "tp": tp, "ms_per_step": round(ms, 3),
+               "value": round(a.batch * a.steps / elapsed, 1), "hipgraph": bool(runner._graphs),
+               "decode_partition": runner._decode_part,
+               "tuned_gemm_csv_loaded": bool(getattr(runner, "tuned_gemms", False)),
+               "roofline": roofline_of(runner, local_batch, tp)}
+        del runner
+        torch.cuda.empty_cache()
+        return res
+
+    # With more than one GPU the plan WITHOUT a data-path collective is measured first and kept; the tensor-parallel
+    # plan (RCCL all-reduces inside the captured step: never exercised on the 1-GPU boxes this repo is developed on)
+    # then runs under a wall-clock watchdog.  If it raises or hangs, rank 0 still prints ONE line — the data-parallel
+    # measurement, with what happened to the tensor-parallel attempt next to it — instead of nothing.
+    results: list[dict] = []
+    failures: list[dict] = []
+    ordered = sorted(plans, key=lambda pl: pl[0])     # tp == 1 first
+    safe_first = world > 1 and len(ordered) > 1 and ordered[0][0] == 1
+
+    def emit_and_exit(reason: str) -> None:      # watchdog thread
+        failures.append({"parallelism": "tensor-parallel plan", "error": reason})
+        if rank == 0 and results:
+            print(json.dumps(compose(results, failures)), flush=True)
+        os._exit(0 if results else 3)
+
+    for i, (tp, dp, label, role) in enumerate(ordered):
+        guard = None
+        if safe_first and i > 0:
+            import threading
+
+            limit = float(os.environ.get("MI_BENCH_TP_WATCHDOG_S", "300"))
+            guard = threading.Timer(limit, emit_and_exit, args=(f"no result within {limit:.0f} s (hung collective?)",))
+            guard.daemon = True
+            guard.start()
+        try:
+            results.append(measure(tp, dp, label, role))
+        except Exception as e:  # noqa: BLE001
+            if not (safe_first and i > 0):
+                raise
+            failures.append({"parallelism": label, "error": f"{type(e).__name__}: {str(e)[:300]}"})
+            if guard is not None:
+                guard.cancel()
+            # a failed capture / collective leaves the process group in an unknown state: report and leave
+            if rank == 0:
+                print(json.dumps(compose(results, failures)), flush=True)
+            os._exit(0)
+        finally:
+            if guard is not None:
+                guard.cancel()
+    out = compose(results, failures)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_batch, a.ctx, a.block_size)
     if world > 1:
