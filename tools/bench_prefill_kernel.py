@@ -23,8 +23,9 @@ def main():
     ap.add_argument("--nkv", type=int, default=4)
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--d", type=int, default=128)
     a = ap.parse_args()
-    d = 128
+    d = a.d
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     nblk = a.prompt // a.bs
@@ -37,11 +38,13 @@ def main():
         n = a.prompt // chunk
         flops = sum(2 * 2 * d * a.nq * chunk * (i * chunk + (chunk + 1) / 2) for i in range(n))
 
+        # metadata made once: a host->device copy per launch would be timed as kernel time
+        sls = [torch.tensor([(i + 1) * chunk], dtype=torch.int32, device=dev) for i in range(n)]
+        qsl = torch.tensor([0, chunk], dtype=torch.int32, device=dev)
+
         def run():
             for i in range(n):
-                sl = torch.tensor([(i + 1) * chunk], dtype=torch.int32, device=dev)
-                qsl = torch.tensor([0, chunk], dtype=torch.int32, device=dev)
-                ops.paged_attn_prefill(out[i * chunk:(i + 1) * chunk], q[i * chunk:(i + 1) * chunk], kb, vb, table, sl,
+                ops.paged_attn_prefill(out[i * chunk:(i + 1) * chunk], q[i * chunk:(i + 1) * chunk], kb, vb, table, sls[i],
                                        qsl, chunk, d ** -0.5)
         run()
         torch.cuda.synchronize()

@@ -45,6 +45,7 @@ struct PrefillParams {
   const int32_t* seq_lens;
   const int32_t* query_start_loc;
   int32_t num_seqs, num_q_heads, kv_group, heads_per_wg, bs_log2, block_table_stride;
+  int32_t qt;   // query tokens per workgroup tile (32x32x16 kernel)
   float scale_log2e;
   int64_t q_stride, out_stride, blk_stride, tok_stride, head_stride;
 };
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   scalar_cache_acquire();
   using E = Elem<Tag>;
   constexpr int HD = 128;
-  constexpr int QT = 32;             // query tokens per workgroup
+  const int QT = p.qt;               // query tokens per workgroup
   constexpr int ROWB = HD * 2;
   constexpr int KS = HD / 16;        // k-steps of S^T
   constexpr int NB = HD / 32;        // d-blocks of O^T
@@ -536,9 +537,8 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   const int nz = (p.num_q_heads / p.kv_group) * chunks;
   const int zz = (int)blockIdx.x % nz, tile_rank = (int)blockIdx.x / nz;
   const int kvh = zz / chunks;
-  const int hg = (zz % chunks) * p.heads_per_wg + wid;
-  const bool active = hg < p.kv_group;                            // wave-uniform
-  const int head = kvh * p.kv_group + min(hg, p.kv_group - 1);
+  const int h_first = (zz % chunks) * p.heads_per_wg;
+  const int nheads = min(p.heads_per_wg, p.kv_group - h_first);   // query heads of this workgroup
 
   const int q0 = p.query_start_loc[seq];
   const int q_len = p.query_start_loc[seq + 1] - q0;
@@ -550,9 +550,19 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
 
   const int col = lane & 31;
   const int h = lane >> 5;
+  // The workgroup's nheads x QT (head, query) pairs are laid out head-major over the waves' 32-column tiles: column
+  // cg = 32 * wave + col is query cg % QT of head cg / QT.  Every column of the swapped formulation is independent (its
+  // own q vector, causal position, statistics and output row), so a tile may mix heads.  With QT = 32 and one wave
+  // per head this is the plain mapping; with 7 heads the host picks 8 waves and QT = 36 (252 of 256 columns used)
+  // instead of 7 waves and an idle eighth: every SIMD then carries two waves, 12.5 % more work per step.
+  const int cg = wid * 32 + col;
+  const int hl = cg / QT, qi = cg - hl * QT;
+  const bool active = (wid * 32) / QT < nheads;                   // wave-uniform: the wave owns a real column
+  const bool valid = hl < nheads && qi < rows;
+  const int head = kvh * p.kv_group + h_first + min(hl, nheads - 1);
   const int limit = ctx_off + tile0 + rows;
   const int t_end = (limit + kStep - 1) / kStep;
-  const int qpos = ctx_off + tile0 + col;
+  const int qpos = ctx_off + tile0 + qi;
 
   typedef const __attribute__((address_space(4))) int32_t cint32_t;
   cint32_t* const bt_row = (cint32_t*)(p.block_table + (int64_t)seq * p.block_table_stride);
@@ -562,8 +572,8 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   // ---- Q^T fragments: column = token tile0 + col of head `head`, dims 16s + 8h ..
   uint4 qf[KS];
   {
-    const bool ok = col < rows;
-    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)(q0 + tile0 + (ok ? col : 0)) * p.q_stride +
+    const bool ok = valid;
+    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)(q0 + tile0 + (ok ? qi : 0)) * p.q_stride +
                          (int64_t)head * HD + 8 * h;
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = ok ? *reinterpret_cast<const uint4*>(qb + 16 * s) : make_uint4(0, 0, 0, 0);
@@ -775,9 +785,9 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   float la = l, lb = l;
   permlane32_swap(la, lb);
   const float lsum = la + lb;
-  if (active && col < rows) {
+  if (valid) {
     const float inv = 1.f / lsum;
-    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + col) * p.out_stride + (int64_t)head * HD + 4 * h;
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + qi) * p.out_stride + (int64_t)head * HD + 4 * h;
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
@@ -791,9 +801,23 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
 }
 
 template <typename Tag>
-int launch_prefill32(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
-  const int waves = p.heads_per_wg;
-  const dim3 grid(((max_query_len + 31) / 32) * num_kv_heads * ((p.kv_group + waves - 1) / waves), p.num_seqs, 1), block(64 * waves);
+int launch_prefill32(PrefillParams p, int num_kv_heads, int max_query_len, hipStream_t s) {
+  // waves and tile: one wave per head and 32-token tiles when the head count is a power of two, else the next power of
+  // two of waves and as many tokens as fill their columns (7 heads: 8 waves x 32 columns = 7 x 36 tokens + 4 idle).
+  // MI_PREFILL_FLAT=0 keeps one wave per head (A/B).
+  static const bool flat = [] {
+    const char* e = getenv("MI_PREFILL_FLAT");
+    return !e || atoi(e) != 0;
+  }();
+  const int hpw = p.heads_per_wg;
+  int waves = hpw;
+  p.qt = 32;
+  if (flat && (hpw & (hpw - 1))) {
+    waves = hpw > 4 ? 8 : 4;
+    p.qt = 32 * waves / hpw;
+  }
+  const dim3 grid(((max_query_len + p.qt - 1) / p.qt) * num_kv_heads * ((p.kv_group + hpw - 1) / hpw), p.num_seqs, 1),
+      block(64 * waves);
   if (waves >= 4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4>), grid, block, 0, s, p);
   else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 2>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 1>), grid, block, 0, s, p);
@@ -871,6 +895,14 @@ extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cac
     return e ? atoi(e) : 0;
   }();
   int heads_per_wg = kv_group <= 8 ? kv_group : 8;
+  // A launch with fewer workgroups than two per CU (a TP shard with one KV head; a short chunk) cannot balance tiles
+  // of very different context lengths: split the GQA group over two workgroups there.  Measured, 8k prompt: 7 heads /
+  // 1 KV head (S-A at TP=4) 0.216 -> 0.194 ms per layer in one chunk, 0.480 -> 0.401 in chunks of 2048; 8 / 1 heads of
+  // 64 dims (S-B at TP=2) 0.188 -> 0.152 and 0.432 -> 0.351 (profiles/r02_prefill_shard_shapes.log).
+  {
+    const int64_t tiles = (max_query_len + 31) / 32;
+    if (tiles * num_seqs * num_kv_heads < 2 * 256 && heads_per_wg > 4) heads_per_wg = (heads_per_wg + 1) / 2;
+  }
   if (forced_hpw > 0) heads_per_wg = forced_hpw < kv_group ? forced_hpw : kv_group;
   if (heads_per_wg > 8) heads_per_wg = 8;
   if (q_token_stride % 8 || out_token_stride % 8 || cache_block_stride % 8 || cache_token_stride % 8 ||
