@@ -75,6 +75,32 @@ def test_prefill_head_dim_64(dev, case, dtype):
     torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_prefill_flattened_columns_many_sequences(dev, dtype):
+    """A launch with >= 2 workgroups per CU keeps the whole 7-head GQA group in one workgroup, and the 32x32x16 kernel
+    then lays its 7 x 36 (head, query) pairs head-major over 8 waves (csrc/paged_attn_prefill.hip): a 32-column tile
+    mixes two heads, tiles are 36 tokens.  48 ragged sequences (chunks 37..120 tokens: partial last tiles of every
+    length class; contexts 0..200) x 28/4 heads = 768 workgroups, every row compared with the oracle."""
+    g = torch.Generator().manual_seed(11)
+    n = 48
+    ctxs = torch.randint(0, 201, (n,), generator=g).tolist()
+    chunks = torch.randint(37, 121, (n,), generator=g).tolist()
+    chunks[0], chunks[1], chunks[2] = 120, 72, 73          # the longest (4 tiles), an exact multiple of 36, one past it
+    got, ref = _case(dev, 28, 4, 16, ctxs, chunks, dtype, seed=12)
+    assert torch.isfinite(got).all()
+    atol = 8e-3 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol)
+
+
+@pytest.mark.parametrize("nq,nkv", [(10, 2), (12, 2), (6, 2), (5, 1), (3, 1)])
+def test_prefill_gqa_groups_that_are_not_powers_of_two(dev, nq, nkv):
+    """G = 5, 6, 3 on a small grid: the group is split over two workgroups (3 + 2, 3 + 3 heads) or kept (3), and 3
+    heads run as 4 waves x 32 columns = 3 x 42 tokens; 80-token chunks leave a 38-token last tile."""
+    got, ref = _case(dev, nq, nkv, 16, [0, 25, 90], [80, 43, 7], torch.bfloat16, seed=13)
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, ref, rtol=4e-3, atol=8e-3)
+
+
 def test_prefill_equals_decode_for_single_token_chunks(dev):
     """q_len == 1 everywhere: the prefill kernel must agree with the decode kernel (same P rounding)."""
     from vllm_omni_amd import ops

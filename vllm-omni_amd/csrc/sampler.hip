@@ -9,8 +9,9 @@
 // argmax).  The shipped talker stage samples with T = 0.9, top_p = 0.8, top_k = 40, repetition_penalty =
 // 1.05 (vllm_omni/platforms/rocm/stage_configs/qwen2_5_omni.yaml:51-59).
 //
-// No sort: both cut-offs are found by bisection over the order-preserving integer key of the fp32 values
-// (32 block-wide counts each), which is exact for top-k (ties with the k-th value are kept, as upstream's
+// No sort: both cut-offs are found by a search over the order-preserving integer key of the fp32 values — four key
+// bits per block-wide step (15 candidate thresholds counted / summed at once: 8 steps each instead of the 32 of a
+// bit-by-bit bisection; counts by ballot, masses summed by DPP rotations and row swaps) — which is exact for top-k (ties with the k-th value are kept, as upstream's
 // `logits_sort < kth` mask does) and, for top-p, keeps every element tied with the last kept VALUE (upstream
 // breaks such ties by sort position, i.e. arbitrarily).  The draw is the exponential race upstream uses:
 // id = argmax_i p_i / q_i, q_i = -ln(u_i), with u_i from Philox4x32-10 keyed by the request's seed and
@@ -78,6 +79,46 @@ struct BlockReduce {
     __syncthreads();
     return fmaxf(fmaxf(fbuf[0], fbuf[1]), fmaxf(fbuf[2], fbuf[3]));
   }
+  // 15 values at once (one step of the 4-bit searches); `mbuf` = [4][16] words of LDS.  Counts arrive per WAVE
+  // (ballot + popcount: no cross-lane traffic at all); masses are summed on the VALU — four row rotations (DPP) and the
+  // two row swaps — instead of six ds_bpermute round trips per value (15 x 6 of them were 3 us per step).
+  __device__ __forceinline__ void count15(uint32_t (&c)[15], uint32_t* mbuf) {   // c[]: this wave's counts (uniform)
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int d = 0; d < 15; ++d) mbuf[(threadIdx.x >> 6) * 16 + d] = c[d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 15; ++d) c[d] = mbuf[d] + mbuf[16 + d] + mbuf[32 + d] + mbuf[48 + d];
+  }
+  template <int N>
+  static __device__ __forceinline__ float ror(float v) {   // lane l of a 16-lane row <- lane (l + N) % 16
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+  }
+  static __device__ __forceinline__ float wave_sum(float v) {   // lane 0's association is the one that is used
+    v += ror<8>(v);
+    v += ror<4>(v);
+    v += ror<2>(v);
+    v += ror<1>(v);
+    float a = v, b = v;
+    permlane32_swap(a, b);
+    a = b = a + b;
+    permlane16_swap(a, b);
+    return a + b;
+  }
+  __device__ __forceinline__ void sum15(float (&m)[15], float* mbuf) {
+#pragma unroll
+    for (int d = 0; d < 15; ++d) m[d] = wave_sum(m[d]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int d = 0; d < 15; ++d) mbuf[(threadIdx.x >> 6) * 16 + d] = m[d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 15; ++d) m[d] = (mbuf[d] + mbuf[16 + d]) + (mbuf[32 + d] + mbuf[48 + d]);
+  }
   __device__ __forceinline__ uint32_t count(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -91,10 +132,11 @@ struct BlockReduce {
 template <int DT>
 __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
   scalar_cache_acquire();
-  extern __shared__ float vals[];  // [vocab] then 4 floats + 4 uints + 2 ints
+  extern __shared__ float vals[];  // [vocab] then 4 floats + 4 uints + 2 ints (+ pad) + [4][16] words
   float* fbuf = vals + p.vocab;
   uint32_t* ubuf = reinterpret_cast<uint32_t*>(fbuf + 4);
   int* ibuf = reinterpret_cast<int*>(ubuf + 4);
+  float* mbuf = fbuf + 16;
   BlockReduce red{fbuf, ubuf};
   const int row = blockIdx.x, tid = threadIdx.x, V = p.vocab;
   const float T = p.temperature[row];
@@ -122,11 +164,21 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
     const int k = p.top_k ? p.top_k[row] : 0;
     if (k > 0 && k < V) {
       uint32_t tau = 0;
-      for (int b = 31; b >= 0; --b) {
-        const uint32_t cand = tau | (1u << b);
-        uint32_t c = 0;
-        for (int i = tid; i < V; i += 256) c += fkey(vals[i]) >= cand;
-        if (red.count(c) >= (uint32_t)k) tau = cand;
+      for (int sh = 28; sh >= 0; sh -= 4) {   // digit = the largest d with count(key >= tau | d << sh) >= k (counts fall with d)
+        uint32_t c[15];
+#pragma unroll
+        for (int d = 0; d < 15; ++d) c[d] = 0;
+        for (int i = tid; i < V; i += 256) {
+          const uint32_t key = fkey(vals[i]);
+#pragma unroll
+          for (int d = 0; d < 15; ++d) c[d] += (uint32_t)__popcll(__ballot(key >= (tau | ((uint32_t)(d + 1) << sh))));
+        }
+        red.count15(c, reinterpret_cast<uint32_t*>(mbuf));
+        uint32_t dig = 0;
+#pragma unroll
+        for (int d = 0; d < 15; ++d)
+          if (c[d] >= (uint32_t)k) dig = d + 1;
+        tau |= dig << sh;
       }
       for (int i = tid; i < V; i += 256)
         if (fkey(vals[i]) < tau) vals[i] = -INFINITY;
@@ -148,17 +200,31 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
     const float tp = p.top_p ? p.top_p[row] : 1.f;
     uint32_t cut = 0;
     if (tp < 1.f) {
-      uint32_t lo = 0, hi = 0xffffffffu;
-      while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        float m = 0.f;
+      // the smallest key c with mass(key > c) < top_p, digit by digit: the smallest d whose bucket's LAST key
+      // (prefix | d << sh | ones below) satisfies it; d = 15 when none of 0..14 does (the mass above the largest key
+      // is 0 < top_p).  The predicate is monotone in c — the masses are sums of non-negative terms in a fixed
+      // association — so this lands on the same key as a bit-by-bit bisection.
+      uint32_t pre = 0;
+      for (int sh = 28; sh >= 0; sh -= 4) {
+        const uint32_t below = sh ? ((1u << sh) - 1u) : 0u;
+        float m[15];
+#pragma unroll
+        for (int d = 0; d < 15; ++d) m[d] = 0.f;
         for (int i = tid; i < V; i += 256) {
           const float pr = vals[i] * inv;
-          if (fkey(pr) > mid) m += pr;
+          const uint32_t key = fkey(pr);
+#pragma unroll
+          for (int d = 0; d < 15; ++d)
+            if (key > (pre | ((uint32_t)d << sh) | below)) m[d] += pr;
         }
-        if (red.sum(m) < tp) hi = mid; else lo = mid + 1;
+        red.sum15(m, mbuf);
+        uint32_t dig = 15;
+#pragma unroll
+        for (int d = 14; d >= 0; --d)
+          if (m[d] < tp) dig = d;
+        pre |= dig << sh;
       }
-      cut = lo;
+      cut = pre;
     }
     // 5. exponential race over the survivors
     const uint64_t sd = p.seed[row], off = p.offset[row];
@@ -209,11 +275,11 @@ extern "C" int mi_sample_tokens(int64_t* ids, const void* logits, int32_t num_ro
   if (num_rows == 0) return MI_OK;
   if (!ids || !logits || !temperature || !seed || !offset || num_rows < 0 || vocab <= 0 || row_stride < vocab)
     return MI_ERR_INVALID_ARG;
-  if (vocab > 16368) return MI_ERR_UNSUPPORTED;  // the fp32 row lives in 64 KB of LDS (talker vocabularies: 3072 / 8448)
+  if (vocab > 16304) return MI_ERR_UNSUPPORTED;  // the fp32 row lives in 64 KB of LDS (talker vocabularies: 3072 / 8448)
   if (seen_bitmap && bitmap_words_per_row * 32 < vocab) return MI_ERR_INVALID_ARG;
   SamplerParams p{ids, logits, row_stride, vocab, temperature, top_k, top_p, rep_penalty, seen_bitmap, seen_row,
                   bitmap_words_per_row, update_seen, seed, offset};
-  const size_t lds = (size_t)vocab * 4 + 64;
+  const size_t lds = (size_t)vocab * 4 + 64 + 256;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(num_rows), block(256);
   switch (logits_dtype) {
