@@ -264,7 +264,7 @@ def cpu_baseline(cfg, batch: int, ctx: int, block_size: int, budget_s: float = 2
                       "no extrapolation; CPU restatement of reference semantics, not a reference CPU backend"}
 
 
-def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bool):
+def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bool, eager: bool = False):
     """Build the runner of one (tp, dp) plan on this rank, warm up, time EXACTLY ``a.steps`` steps between barriers,
     return (max-over-ranks seconds, runner, local batch)."""
     from vllm_omni_amd.distributed import init_distributed_environment
@@ -277,7 +277,7 @@ def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bo
     max_model_len = a.ctx + a.block_size
     runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=local_batch, max_model_len=max_model_len,
                               max_num_batched_tokens=max(local_batch, 256), block_size=a.block_size,
-                              kv_layout=a.kv_layout, enforce_eager=a.eager, seed=0, quantization=a.quantization,
+                              kv_layout=a.kv_layout, enforce_eager=a.eager or eager, seed=0, quantization=a.quantization,
                               code_predictor=_code_predictor_config() if a.code_predictor else None,
                               copy_outputs=False)   # views of the pinned output ring
     runner.load_model()
@@ -374,7 +374,8 @@ def main():
     def compose(results: list[dict], failures: list[dict]) -> dict:
         """The ONE JSON line: the widest tensor-parallel plan that produced a number is the headline (the TP scaling
         line the metric names); every other measured plan goes to `alt_plans`, failed attempts to `failed_plans`."""
-        head = max(results, key=lambda r: r["tp"])
+        tp_top = max(r["tp"] for r in results)
+        head = max((r for r in results if r["tp"] == tp_top), key=lambda r: r["value"])
         ms_per_step, tokens_per_s = head["ms_per_step"], head["value"]
         tp = head["tp"]
         roofline = head["roofline"]
@@ -437,8 +438,8 @@ def main():
                 "launches_timed": launches,
                 "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
 
-    def measure(tp: int, dp: int, label: str, role: str) -> dict:
-        elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal)
+    def measure(tp: int, dp: int, label: str, role: str, eager: bool = False) -> dict:
+        elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal, eager)
         ms = elapsed / a.steps * 1e3
         res = {"parallelism": label, "role": role, "tp": tp, "ms_per_step": round(ms, 3),
                "value": round(a.batch * a.steps / elapsed, 1), "hipgraph": bool(runner._graphs),
@@ -449,32 +450,42 @@ def main():
         torch.cuda.empty_cache()
         return res
 
-    # With more than one GPU the plan WITHOUT a data-path collective is measured first and kept; the tensor-parallel
-    # plan (RCCL all-reduces inside the captured step: never exercised on the 1-GPU boxes this repo is developed on)
-    # then runs under a wall-clock watchdog.  If it raises or hangs, rank 0 still prints ONE line — the data-parallel
-    # measurement, with what happened to the tensor-parallel attempt next to it — instead of nothing.
+    # With more than one GPU the measurements go from the safest to the fastest, each kept once it exists:
+    #   1. the plan WITHOUT a data-path collective (pure data parallel, captured step);
+    #   2. the tensor-parallel plan run EAGERLY (RCCL all-reduces as plain stream operations);
+    #   3. the tensor-parallel plan with the step captured in a hipGraph (RCCL inside the capture: never exercised on
+    #      the 1-GPU boxes this repo is developed on).
+    # 2 and 3 run under a wall-clock watchdog.  Whatever raises or hangs, rank 0 still prints ONE line from what was
+    # measured before it — the widest tensor-parallel plan that produced a number is the headline, its faster variant
+    # if both exist — with what happened to the failed attempt next to it, instead of nothing.
     results: list[dict] = []
     failures: list[dict] = []
-    ordered = sorted(plans, key=lambda pl: pl[0])     # tp == 1 first
+    ordered = [(tp, dp, label, role, False) for tp, dp, label, role in sorted(plans, key=lambda pl: pl[0])]   # tp == 1 first
     safe_first = world > 1 and len(ordered) > 1 and ordered[0][0] == 1
+    if safe_first and not a.eager and os.environ.get("MI_BENCH_TP_EAGER_FIRST", "1") == "1":
+        staged = [ordered[0]]
+        for tp, dp, label, role, _ in ordered[1:]:
+            staged.append((tp, dp, label + " (eager)", role + ", eager launches", True))
+            staged.append((tp, dp, label, role, False))
+        ordered = staged
 
-    def emit_and_exit(reason: str) -> None:      # watchdog thread
-        failures.append({"parallelism": "tensor-parallel plan", "error": reason})
+    def emit_and_exit(reason: str, what: str) -> None:      # watchdog thread
+        failures.append({"parallelism": what, "error": reason})
         if rank == 0 and results:
             print(json.dumps(compose(results, failures)), flush=True)
         os._exit(0 if results else 3)
 
-    for i, (tp, dp, label, role) in enumerate(ordered):
+    for i, (tp, dp, label, role, eager) in enumerate(ordered):
         guard = None
         if safe_first and i > 0:
             import threading
 
-            limit = float(os.environ.get("MI_BENCH_TP_WATCHDOG_S", "300"))
-            guard = threading.Timer(limit, emit_and_exit, args=(f"no result within {limit:.0f} s (hung collective?)",))
+            limit = float(os.environ.get("MI_BENCH_TP_WATCHDOG_S", "240"))
+            guard = threading.Timer(limit, emit_and_exit, args=(f"no result within {limit:.0f} s (hung collective?)", label))
             guard.daemon = True
             guard.start()
         try:
-            results.append(measure(tp, dp, label, role))
+            results.append(measure(tp, dp, label, role, eager))
         except Exception as e:  # noqa: BLE001
             if not (safe_first and i > 0):
                 raise
