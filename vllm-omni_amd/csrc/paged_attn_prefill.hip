@@ -674,17 +674,26 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
         acc[n] = mfma32<Tag>(a, pb[m], acc[n]);
       }
   };
-  auto pre = [&](int t, f32x16_t& s, auto interior) {
-    const bool first = t == 0;
-    if (!decltype(interior)::value && (t + 1) * kStep > ctx_off + tile0 + 1) {   // the step reaches the tile's diagonal
-      const int kb = t * kStep + 4 * h;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (kb + 8 * (i >> 2) + (i & 3) > qpos) s[i] = -INFINITY;
-    }
+  auto row_max = [&](const f32x16_t& s) {
     const float ma = max3f(max3f(s[0], s[1], s[2]), max3f(s[3], s[4], s[5]), max3f(s[6], s[7], s[8]));
     const float mb = max3f(max3f(s[9], s[10], s[11]), max3f(s[12], s[13], s[14]), s[15]);
-    const float mx = max2f(ma, mb);
+    return max2f(ma, mb);
+  };
+  float mx_pre = 0.f;   // lane-local maximum of the NEXT step's unmasked scores, computed beside the PV MFMAs
+  auto pre = [&](int t, f32x16_t& s, auto interior) {
+    const bool first = t == 0;
+    float mx;
+    if constexpr (decltype(interior)::value) {
+      mx = mx_pre;
+    } else {
+      if ((t + 1) * kStep > ctx_off + tile0 + 1) {   // the step reaches the tile's diagonal
+        const int kb = t * kStep + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kb + 8 * (i >> 2) + (i & 3) > qpos) s[i] = -INFINITY;
+      }
+      mx = row_max(s);
+    }
     if (__any(first || mx > mu_thr)) {  // rare after the first steps of a tile
       float a = mx, b = mx;
       permlane32_swap(a, b);             // the column's other 16 keys
@@ -703,16 +712,18 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
       mu_thr = mu + thr_raw;
     }
   };
-  auto expo = [&](const f32x16_t& s) {
-    float v[16];
+  // exponentials and packs (beside the S MFMAs); the row sum of the same values later (beside the PV MFMAs)
+  auto expo = [&](const f32x16_t& s, float (&v)[16]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = fast_exp2(__builtin_fmaf(s[i], p.scale_log2e, nms));
-    l += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-         (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
 #pragma unroll
     for (int m = 0; m < 2; ++m)
       pb[m] = make_uint4(E::pack(v[8 * m], v[8 * m + 1]), E::pack(v[8 * m + 2], v[8 * m + 3]), E::pack(v[8 * m + 4], v[8 * m + 5]),
                          E::pack(v[8 * m + 6], v[8 * m + 7]));
+  };
+  auto row_sum = [&](const float (&v)[16]) {
+    l += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+         (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
   };
 
   using S0 = std::integral_constant<int, 0>;
@@ -734,23 +745,37 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
       // V(t) under the S(t+1) MFMAs and the exponentials
       u32x4_t k[KS];
       lds_issue_b128x8<SN>(k_rd, k);
+      __builtin_amdgcn_sched_barrier(0);   // the reads stay in FRONT of the work that covers their latency
       pre(t, sc[ST & 1], interior);
       lds_wait_all();
       u32x2_t o[16];
       lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
+      __builtin_amdgcn_sched_barrier(0);
       qk_mfma(k, sc[(ST + 1) & 1]);
-      expo(sc[ST & 1]);
+      float v[16];
+      expo(sc[ST & 1], v);
       if constexpr (MI_PREFILL_SCHED) {
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA (32 cycles of pipe, 8 of issue)
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two exponents' fma
           __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   // two exponentials
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // sums / packs as they become ready
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // a pack once its pair exists
         }
       }
       lds_wait_all();
+      // the PV MFMAs need nothing but P: the row sum of step t and the lane maximum of step t+1's scores (ready since
+      // the S MFMAs retired) fill their gaps instead of standing in front of the next step
       pv_mfma(o);
+      row_sum(v);
+      mx_pre = row_max(sc[(ST + 1) & 1]);
+      if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
+        }
+      }
     }
   };
   if (MI_PREFILL_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
@@ -765,6 +790,7 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
     u32x4_t k[KS];
     kread(S0{}, k);
     qk_mfma(k, sc[0]);
+    mx_pre = row_max(sc[0]);
   }
   const int t_int = max(0, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
   int t = 0;
