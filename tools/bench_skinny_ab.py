@@ -25,6 +25,7 @@ def timed(fn, iters=30):
 
 def main():
     m = int(os.environ.get("M", 256))
+    var = os.environ.get("AB_VAR", "MI_LINEAR_V2")   # the per-call switch under test: 0 = "v1" column, 1 = "v2" column
     rounds = int(os.environ.get("ROUNDS", 7))
     g = torch.Generator(device="cuda").manual_seed(0)
     shapes = [("gate_up+silu", 37888, 3584, True), ("down", 3584, 18944, False), ("qkv", 4608, 3584, False),
@@ -45,9 +46,9 @@ def main():
             return ops.silu_and_mul(y) if gated else y
 
         res = {"v1": [], "v2": [], "lib": []}
-        os.environ["MI_LINEAR_V2"] = "0"
+        os.environ[var] = "0"
         a = run().float()
-        os.environ["MI_LINEAR_V2"] = "1"
+        os.environ[var] = "1"
         b = run().float()
         i[0] -= 1
         diff = (a - b).abs().max().item()
@@ -56,7 +57,7 @@ def main():
             lib()
         for _ in range(rounds):
             for tag in ("v1", "v2", "lib"):
-                os.environ["MI_LINEAR_V2"] = "0" if tag == "v1" else "1"
+                os.environ[var] = "0" if tag == "v1" else "1"
                 res[tag].append(timed(lib if tag == "lib" else run))
         gb = n * k * 2 / 1e9
         line = f"{name:14s} m={m} n={n} k={k}:"
