@@ -511,8 +511,12 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
 // and 16m + 8 + 4h + (0..3).  A 16-lane group of a transposed read supplies 4 key rows x 16 d; the 32 lanes of an LDS
 // cycle cover 4 key rows x 64 B, so the V image XORs the 16-B chunk index with 4 * (row & 3): four rows, four different
 // 64-B segments, every bank once (the 16x16x32 image's 2 * (row & 7) would be 2-way here).
-template <typename Tag, int NI>
-__global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams p) {
+// NC = 32-column tiles per wave.  NC = 1: up to 8 waves of 256 registers, two per SIMD.  NC = 2: FOUR waves, one per
+// SIMD, each with the whole 512-register file (accumulators and Q fragments in the accumulation half) and two column
+// tiles: every K and V fragment read from LDS feeds two MFMAs instead of one, a step is 32 MFMAs between two fragment
+// waits instead of 16, and the barrier joins four waves instead of eight.
+template <typename Tag, int NI, int NC>
+__global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(const PrefillParams p) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
   constexpr int HD = 128;
@@ -555,14 +559,20 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   // own q vector, causal position, statistics and output row), so a tile may mix heads.  With QT = 32 and one wave
   // per head this is the plain mapping; with 7 heads the host picks 8 waves and QT = 36 (252 of 256 columns used)
   // instead of 7 waves and an idle eighth: every SIMD then carries two waves, 12.5 % more work per step.
-  const int cg = wid * 32 + col;
-  const int hl = cg / QT, qi = cg - hl * QT;
-  const bool active = (wid * 32) / QT < nheads;                   // wave-uniform: the wave owns a real column
-  const bool valid = hl < nheads && qi < rows;
-  const int head = kvh * p.kv_group + h_first + min(hl, nheads - 1);
+  const bool active = (wid * NC * 32) / QT < nheads;              // wave-uniform: the wave owns a real column
+  int qi[NC], head[NC], qpos[NC];
+  bool valid[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int cg = (wid * NC + c) * 32 + col;
+    const int hl = cg / QT;
+    qi[c] = cg - hl * QT;
+    valid[c] = hl < nheads && qi[c] < rows;
+    head[c] = kvh * p.kv_group + h_first + min(hl, nheads - 1);
+    qpos[c] = ctx_off + tile0 + qi[c];
+  }
   const int limit = ctx_off + tile0 + rows;
   const int t_end = (limit + kStep - 1) / kStep;
-  const int qpos = ctx_off + tile0 + qi;
 
   typedef const __attribute__((address_space(4))) int32_t cint32_t;
   cint32_t* const bt_row = (cint32_t*)(p.block_table + (int64_t)seq * p.block_table_stride);
@@ -570,13 +580,14 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   const int last_blk = (limit - 1) >> p.bs_log2;
 
   // ---- Q^T fragments: column = token tile0 + col of head `head`, dims 16s + 8h ..
-  uint4 qf[KS];
-  {
-    const bool ok = valid;
-    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)(q0 + tile0 + (ok ? qi : 0)) * p.q_stride +
-                         (int64_t)head * HD + 8 * h;
+  uint4 qf[NC][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = ok ? *reinterpret_cast<const uint4*>(qb + 16 * s) : make_uint4(0, 0, 0, 0);
+  for (int c = 0; c < NC; ++c) {
+    const bool ok = valid[c];
+    const uint16_t* qb = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)(q0 + tile0 + (ok ? qi[c] : 0)) * p.q_stride +
+                         (int64_t)head[c] * HD + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[c][s] = ok ? *reinterpret_cast<const uint4*>(qb + 16 * s) : make_uint4(0, 0, 0, 0);
   }
   // ---- per-lane LDS read addresses
   uint32_t k_rd[KS];   // K row `col`, chunk 2s + h (dims 16s + 8h ..), swizzled by row & 15: a b128 lane group = 16 rows x 16 chunks
@@ -649,21 +660,29 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   // ---- online softmax state (deferred reference maximum: see the 16x16x32 kernel)
   constexpr float kThr = 6.0f;
   const float thr_raw = kThr / p.scale_log2e;
-  float mu = 0.f, nms = 0.f, mu_thr = 0.f, l = 0.f;
-  f32x16_t acc[NB];
+  float mu[NC], nms[NC], mu_thr[NC], l[NC];
+  f32x16_t acc[NC][NB];
 #pragma unroll
-  for (int n = 0; n < NB; ++n)
+  for (int c = 0; c < NC; ++c) {
+    mu[c] = nms[c] = mu_thr[c] = l[c] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-  f32x16_t sc[2];
-  uint4 pb[2];
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][n][i] = 0.f;
+  }
+  f32x16_t sc[2][NC];
+  uint4 pb[NC][2];
 
   auto kread = [&](auto stc, u32x4_t (&k)[KS]) { lds_read_b128x8<decltype(stc)::value * STAGE>(k_rd, k); };
-  auto qk_mfma = [&](const u32x4_t (&k)[KS], f32x16_t& s) {
+  auto qk_mfma = [&](const u32x4_t (&k)[KS], f32x16_t (&s)[NC]) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s = mfma32<Tag>(__builtin_bit_cast(uint4, k[ks]), qf[ks], s);
+      for (int i = 0; i < 16; ++i) s[c][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) s[c] = mfma32<Tag>(__builtin_bit_cast(uint4, k[ks]), qf[c][ks], s[c]);
   };
   auto pv_mfma = [&](const u32x2_t (&o)[16]) {
 #pragma unroll
@@ -671,7 +690,8 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
         const uint4 a = make_uint4(o[4 * n + 2 * m][0], o[4 * n + 2 * m][1], o[4 * n + 2 * m + 1][0], o[4 * n + 2 * m + 1][1]);
-        acc[n] = mfma32<Tag>(a, pb[m], acc[n]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c][n] = mfma32<Tag>(a, pb[c][m], acc[c][n]);
       }
   };
   auto row_max = [&](const f32x16_t& s) {
@@ -679,51 +699,66 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
     const float mb = max3f(max3f(s[9], s[10], s[11]), max3f(s[12], s[13], s[14]), s[15]);
     return max2f(ma, mb);
   };
-  float mx_pre = 0.f;   // lane-local maximum of the NEXT step's unmasked scores, computed beside the PV MFMAs
-  auto pre = [&](int t, f32x16_t& s, auto interior) {
+  float mx_pre[NC];   // lane-local maxima of the NEXT step's unmasked scores, computed beside the PV MFMAs
+#pragma unroll
+  for (int c = 0; c < NC; ++c) mx_pre[c] = 0.f;
+  auto pre = [&](int t, f32x16_t (&s)[NC], auto interior) {
     const bool first = t == 0;
-    float mx;
-    if constexpr (decltype(interior)::value) {
-      mx = mx_pre;
-    } else {
-      if ((t + 1) * kStep > ctx_off + tile0 + 1) {   // the step reaches the tile's diagonal
-        const int kb = t * kStep + 4 * h;
+    float mx[NC];
+    bool raise = first;
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (kb + 8 * (i >> 2) + (i & 3) > qpos) s[i] = -INFINITY;
-      }
-      mx = row_max(s);
-    }
-    if (__any(first || mx > mu_thr)) {  // rare after the first steps of a tile
-      float a = mx, b = mx;
-      permlane32_swap(a, b);             // the column's other 16 keys
-      const float m = max2f(a, b);
-      if (first) {
-        mu = m;                          // key 0 is visible to every column: finite; acc and l are still zero
+    for (int c = 0; c < NC; ++c) {
+      if constexpr (decltype(interior)::value) {
+        mx[c] = mx_pre[c];
       } else {
-        const float gr = max2f(m - mu, 0.f);
-        const float alpha = fast_exp2(-gr * p.scale_log2e);
-        mu += gr;
-        l *= alpha;
+        if ((t + 1) * kStep > ctx_off + tile0 + 1) {   // the step reaches the tile's diagonal
+          const int kb = t * kStep + 4 * h;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) acc[n] *= alpha;
+          for (int i = 0; i < 16; ++i)
+            if (kb + 8 * (i >> 2) + (i & 3) > qpos[c]) s[c][i] = -INFINITY;
+        }
+        mx[c] = row_max(s[c]);
       }
-      nms = -mu * p.scale_log2e;
-      mu_thr = mu + thr_raw;
+      raise |= mx[c] > mu_thr[c];
+    }
+    if (__any(raise)) {  // rare after the first steps of a tile
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float a = mx[c], b = mx[c];
+        permlane32_swap(a, b);             // the column's other 16 keys
+        const float m = max2f(a, b);
+        if (first) {
+          mu[c] = m;                       // key 0 is visible to every column: finite; acc and l are still zero
+        } else {
+          const float gr = max2f(m - mu[c], 0.f);
+          const float alpha = fast_exp2(-gr * p.scale_log2e);
+          mu[c] += gr;
+          l[c] *= alpha;
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[c][n] *= alpha;
+        }
+        nms[c] = -mu[c] * p.scale_log2e;
+        mu_thr[c] = mu[c] + thr_raw;
+      }
     }
   };
   // exponentials and packs (beside the S MFMAs); the row sum of the same values later (beside the PV MFMAs)
-  auto expo = [&](const f32x16_t& s, float (&v)[16]) {
+  auto expo = [&](const f32x16_t (&s)[NC], float (&v)[NC][16]) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = fast_exp2(__builtin_fmaf(s[i], p.scale_log2e, nms));
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-      pb[m] = make_uint4(E::pack(v[8 * m], v[8 * m + 1]), E::pack(v[8 * m + 2], v[8 * m + 3]), E::pack(v[8 * m + 4], v[8 * m + 5]),
-                         E::pack(v[8 * m + 6], v[8 * m + 7]));
+      for (int i = 0; i < 16; ++i) v[c][i] = fast_exp2(__builtin_fmaf(s[c][i], p.scale_log2e, nms[c]));
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        pb[c][m] = make_uint4(E::pack(v[c][8 * m], v[c][8 * m + 1]), E::pack(v[c][8 * m + 2], v[c][8 * m + 3]),
+                              E::pack(v[c][8 * m + 4], v[c][8 * m + 5]), E::pack(v[c][8 * m + 6], v[c][8 * m + 7]));
+    }
   };
-  auto row_sum = [&](const float (&v)[16]) {
-    l += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-         (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+  auto row_sum = [&](const float (&v)[NC][16]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      l[c] += (((v[c][0] + v[c][1]) + (v[c][2] + v[c][3])) + ((v[c][4] + v[c][5]) + (v[c][6] + v[c][7]))) +
+              (((v[c][8] + v[c][9]) + (v[c][10] + v[c][11])) + ((v[c][12] + v[c][13]) + (v[c][14] + v[c][15])));
   };
 
   using S0 = std::integral_constant<int, 0>;
@@ -752,11 +787,11 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
       lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
       __builtin_amdgcn_sched_barrier(0);
       qk_mfma(k, sc[(ST + 1) & 1]);
-      float v[16];
+      float v[NC][16];
       expo(sc[ST & 1], v);
       if constexpr (MI_PREFILL_SCHED) {
 #pragma unroll
-        for (int i = 0; i < KS; ++i) {
+        for (int i = 0; i < NC * KS; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA (32 cycles of pipe, 8 of issue)
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two exponents' fma
           __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   // two exponentials
@@ -768,10 +803,11 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
       // the S MFMAs retired) fill their gaps instead of standing in front of the next step
       pv_mfma(o);
       row_sum(v);
-      mx_pre = row_max(sc[(ST + 1) & 1]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(sc[(ST + 1) & 1][c]);
       if constexpr (MI_PREFILL_SCHED) {
 #pragma unroll
-        for (int i = 0; i < 2 * NB; ++i) {
+        for (int i = 0; i < NC * 2 * NB; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
           __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
         }
@@ -790,7 +826,8 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
     u32x4_t k[KS];
     kread(S0{}, k);
     qk_mfma(k, sc[0]);
-    mx_pre = row_max(sc[0]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(sc[0][c]);
   }
   const int t_int = max(0, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
   int t = 0;
@@ -808,45 +845,62 @@ __global__ __launch_bounds__(512) void prefill_mfma32_kernel(const PrefillParams
   }
 
   // ---- epilogue: O^T -> out[token][head][dim]; lane: d = 32n + 8 * (i / 4) + 4h + i % 4
-  float la = l, lb = l;
-  permlane32_swap(la, lb);
-  const float lsum = la + lb;
-  if (valid) {
-    const float inv = 1.f / lsum;
-    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + qi) * p.out_stride + (int64_t)head * HD + 4 * h;
 #pragma unroll
-    for (int n = 0; n < NB; ++n)
+  for (int c = 0; c < NC; ++c) {
+    float la = l[c], lb = l[c];
+    permlane32_swap(la, lb);
+    const float lsum = la + lb;
+    if (valid[c]) {
+      const float inv = 1.f / lsum;
+      uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + qi[c]) * p.out_stride + (int64_t)head[c] * HD + 4 * h;
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        uint2 r;
-        r.x = E::pack(acc[n][4 * q4] * inv, acc[n][4 * q4 + 1] * inv);
-        r.y = E::pack(acc[n][4 * q4 + 2] * inv, acc[n][4 * q4 + 3] * inv);
-        *reinterpret_cast<uint2*>(o + 32 * n + 8 * q4) = r;
-      }
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          uint2 r;
+          r.x = E::pack(acc[c][n][4 * q4] * inv, acc[c][n][4 * q4 + 1] * inv);
+          r.y = E::pack(acc[c][n][4 * q4 + 2] * inv, acc[c][n][4 * q4 + 3] * inv);
+          *reinterpret_cast<uint2*>(o + 32 * n + 8 * q4) = r;
+        }
+    }
   }
 }
 
 template <typename Tag>
 int launch_prefill32(PrefillParams p, int num_kv_heads, int max_query_len, hipStream_t s) {
-  // waves and tile: one wave per head and 32-token tiles when the head count is a power of two, else the next power of
-  // two of waves and as many tokens as fill their columns (7 heads: 8 waves x 32 columns = 7 x 36 tokens + 4 idle).
-  // MI_PREFILL_FLAT=0 keeps one wave per head (A/B).
+  // Waves, column tiles per wave and tokens per tile.
+  //   MI_PREFILL_W4=1 (experiment, off): 4..8 heads per workgroup as FOUR waves x 2 tiles x 32 columns, one wave per
+  //     SIMD with the 512-register file.  Measured 668-706 TFLOP/s against 842-889 for the 8-wave kernel at the 8k
+  //     prompt: hipcc keeps the 128 accumulators in the accumulation half but copies 110-190 registers between the
+  //     halves in every step (the rescale path needs them as plain VGPRs); this structure needs hand-owned registers.
+  //   default, one tile per wave: one wave per head and 32-token tiles when the head count is a power of two, else the
+  //     next power of two of waves and as many tokens as fill their columns (MI_PREFILL_FLAT=0: one wave per head).
   static const bool flat = [] {
     const char* e = getenv("MI_PREFILL_FLAT");
     return !e || atoi(e) != 0;
   }();
+  static const bool w4 = [] {
+    const char* e = getenv("MI_PREFILL_W4");
+    return e && atoi(e) != 0;
+  }();
   const int hpw = p.heads_per_wg;
+  const int nz = num_kv_heads * ((p.kv_group + hpw - 1) / hpw);
+  if (w4 && hpw >= 4) {
+    p.qt = 256 / hpw;
+    const dim3 grid(((max_query_len + p.qt - 1) / p.qt) * nz, p.num_seqs, 1), block(256);
+    hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 2>), grid, block, 0, s, p);
+    return launch_status();
+  }
   int waves = hpw;
   p.qt = 32;
   if (flat && (hpw & (hpw - 1))) {
     waves = hpw > 4 ? 8 : 4;
     p.qt = 32 * waves / hpw;
   }
-  const dim3 grid(((max_query_len + p.qt - 1) / p.qt) * num_kv_heads * ((p.kv_group + hpw - 1) / hpw), p.num_seqs, 1),
-      block(64 * waves);
-  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4>), grid, block, 0, s, p);
-  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 2>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 1>), grid, block, 0, s, p);
+  const dim3 grid(((max_query_len + p.qt - 1) / p.qt) * nz, p.num_seqs, 1), block(64 * waves);
+  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 1>), grid, block, 0, s, p);
+  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 2, 1>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 1, 1>), grid, block, 0, s, p);
   return launch_status();
 }
 
