@@ -145,6 +145,29 @@ def test_decode_at_baseline_ctx_matches_oracle(dev, geom, ctx, dtype):
 
 
 @pytest.mark.parametrize("geom", [S_A, S_B], ids=["S-A", "S-B"])
+def test_decode_32k_context_matches_oracle(dev, geom):
+    """Far past the benchmarked context: 32768 (+17) tokens = 33 partitions of 1024 (2049 KV blocks per sequence, block
+    ids well beyond one 64-lane window, the merge over 33 partials), next to a 1-token and a 5000-token sequence in the
+    same launch; production (packed-P) mode against the fp32 oracle and 16-bit == round(fp32)."""
+    nq, nkv, d = geom["nq"], geom["nkv"], geom["d"]
+    lens = [32768 + 17, 1, 5000, 32768]
+    S = len(lens)
+    bound = 32768 + 32
+    table, nb = _table(S, lens, seed=77 + d, max_blocks=(bound + BS - 1) // BS)
+    kv, kb, vb = _device_cache(dev, nb, nkv, d, torch.bfloat16, seed=5)
+    q = torch.randn(S, nq, d, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).to(dev)
+    ref = _oracle_rows(kb, vb, table, lens, q, list(range(S)))
+    for part in (1024, 0, 512):
+        got = _decode(dev, q, kb, vb, table, lens, bound, torch.float32, "fast", part).cpu()
+        assert torch.isfinite(got).all()
+        e = _errs(got, ref)
+        _record(f"decode {nq}/{nkv}/{d} ctx32k bf16 fast part={part} vs fp32 oracle", **e)
+        assert e["atol_needed_at_rtol_1e-3"] <= _BOUNDS[("fast", torch.bfloat16)], (part, e)
+        got16 = _decode(dev, q, kb, vb, table, lens, bound, torch.bfloat16, "fast", part).cpu()
+        assert torch.equal(got16, got.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("geom", [S_A, S_B], ids=["S-A", "S-B"])
 def test_decode_one_hot_target_in_every_partition_bit_exact(dev, geom):
     """ctx 4096 (+1): a one-hot attention target in EACH of the four 1024-token partitions — first token of a
     window, last token of a window (block 63 of the window = lane 63 of the block-id register) — and in the 5th
@@ -267,6 +290,41 @@ def test_prefill_8192_token_prompt_chunked(dev, geom):
             # the output is rounded to bf16 (2^-9 relative) on top of the packed-P rounding; early rows attend to
             # few keys and are O(1), late rows average thousands of keys and are O(1e-2)
             assert e["max_rel_to_rowmax"] <= 8e-3 and e["max_abs"] <= 1.6e-2, (c, h, e)
+
+
+@pytest.mark.parametrize("geom", [S_A, S_B], ids=["S-A", "S-B"])
+def test_prefill_late_chunks_on_a_16k_context(dev, geom):
+    """Chunks far into a long prompt: two sequences in one launch, 500 and 77 new tokens on 16384 and 16000 cached ones
+    (tiles that run 512+ steps, ragged last tiles, contexts that are not multiples of the 32-key step or of the
+    block), all query heads, every row against the fp32 oracle."""
+    from vllm_omni_amd import ops
+
+    nq, nkv, d = geom["nq"], geom["nkv"], geom["d"]
+    dtype = torch.bfloat16
+    ctxs, chunks = [16384, 16000 + 5], [500, 77]
+    lens = [c + n for c, n in zip(ctxs, chunks)]
+    table, nb = _table(2, lens, seed=21 + d)
+    kv, kb, vb = _device_cache(dev, nb, nkv, d, dtype, seed=8)
+    T = sum(chunks)
+    q = torch.randn(T, nq, d, generator=torch.Generator().manual_seed(9)).to(dtype).to(dev)
+    out = torch.full((T, nq * d), float("nan"), dtype=dtype, device=dev)
+    qsl = torch.tensor([0, chunks[0], T], dtype=torch.int32)
+    ops.paged_attn_prefill(out, q.view(T, nq * d), kb, vb, table.to(dev), torch.tensor(lens, dtype=torch.int32, device=dev),
+                           qsl.to(dev), max(chunks), d ** -0.5)
+    torch.cuda.synchronize()
+    got = out.view(T, nq, d).float().cpu()
+    assert torch.isfinite(got).all()
+    for s_ in range(2):
+        nblk = (lens[s_] + BS - 1) // BS
+        ids = table[s_, :nblk].to(torch.int64)
+        kc, vc = kb[ids.to(dev)].cpu(), vb[ids.to(dev)].cpu()
+        t = torch.arange(nblk, dtype=torch.int32).view(1, -1)
+        a, b = int(qsl[s_]), int(qsl[s_ + 1])
+        ref = ref_ops.paged_attention_prefill(q[a:b].cpu(), kc, vc, t, torch.tensor([lens[s_]], dtype=torch.int32),
+                                              torch.tensor([0, b - a], dtype=torch.int32), d ** -0.5)
+        e = _errs(got[a:b], ref)
+        _record(f"prefill {nq}/{nkv}/{d} chunk {b - a} on ctx {ctxs[s_]} vs fp32 oracle (bf16 output)", **e)
+        assert e["max_rel_to_rowmax"] <= 8e-3 and e["max_abs"] <= 4e-3, (s_, e)
 
 
 # ------------------------------------------------------------------ config #5: int8 decode layer, S-B, batch 512
