@@ -264,15 +264,66 @@ def cpu_baseline(cfg, batch: int, ctx: int, block_size: int, budget_s: float = 2
                       "no extrapolation; CPU restatement of reference semantics, not a reference CPU backend"}
 
 
-def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bool, eager: bool = False):
+def validate_in_tree_allreduce(dev, rows: int, cols: int) -> None:
+    """Before anything is timed on the in-tree all-reduce (csrc/allreduce.hip) it must reproduce, on THESE ranks, what the
+    transport every other plan used gives: the decode step's message, a ragged one, eager and replayed from a hipGraph
+    with fresh inputs, against an fp32 all-reduce over the TP group (its sum is rank-ordered fp32 rounded once, the
+    library's order is its own: one 16-bit ulp of slack).  The verdict is agreed over the group, so either every rank
+    raises or none does."""
+    from vllm_omni_amd.distributed import get_parallel_state
+
+    st = get_parallel_state()
+    ar = st.custom_ar
+    ok = ar is not None
+    if ok:
+        def agree(got: torch.Tensor, x: torch.Tensor) -> bool:
+            want = x.float()
+            dist.all_reduce(want, group=st.tp_group)
+            return bool(((got.float() - want).abs() <= want.abs() * 2.0 ** -7 + 1e-3).all())
+
+        g = torch.Generator(device=dev).manual_seed(1234 + st.tp_rank)
+        for shape in ((rows, cols), (13, 8), (1, 8)):
+            x = torch.randn(*shape, device=dev, generator=g).to(torch.bfloat16)
+            ok = ok and agree(ar.all_reduce(x.clone()), x)
+        buf = torch.zeros(rows, cols, dtype=torch.bfloat16, device=dev)
+        out = torch.zeros_like(buf)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            ar.all_reduce(buf, out)
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            ar.all_reduce(buf, out)
+        for _ in range(3):
+            x = torch.randn(rows, cols, device=dev, generator=g).to(torch.bfloat16)
+            buf.copy_(x)
+            gr.replay()
+            torch.cuda.synchronize()
+            ok = ok and agree(out, x)
+        try:
+            ar.check()
+        except Exception:  # noqa: BLE001
+            ok = False
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=st.tp_group)
+    if flag.item() < 1.0:
+        raise RuntimeError("the in-tree all-reduce did not reproduce the library all-reduce on these ranks")
+
+
+def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bool, eager: bool = False,
+             allreduce: str = "rccl"):
     """Build the runner of one (tp, dp) plan on this rank, warm up, time EXACTLY ``a.steps`` steps between barriers,
     return (max-over-ranks seconds, runner, local batch)."""
     from vllm_omni_amd.distributed import init_distributed_environment
     from vllm_omni_amd.model_runner import GPUARModelRunner
 
     if world > 1:
+        os.environ["VLLM_OMNI_AMD_ALLREDUCE"] = allreduce
         init_distributed_environment(world, rank, tp, backend="gloo" if rehearsal else "nccl",
                                      device=None if rehearsal else dev)
+        if allreduce == "custom" and tp > 1:
+            validate_in_tree_allreduce(dev, a.batch // dp, cfg.hidden_size)
     local_batch = a.batch // dp
     max_model_len = a.ctx + a.block_size
     runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=local_batch, max_model_len=max_model_len,
@@ -399,7 +450,7 @@ def main():
                        "output": "sync" if a.sync_output else "pipelined one step behind (all outputs on the host inside the timed region)",
                        "decode_partition": head["decode_partition"],
                        "tuned_gemm_csv_loaded": head["tuned_gemm_csv_loaded"],
-                       "allreduce": os.environ.get("VLLM_OMNI_AMD_ALLREDUCE", "rccl") if tp > 1 else "none",
+                       "allreduce": head["allreduce"],
                        "linear": os.environ.get("VLLM_OMNI_AMD_LINEAR", "auto")
                        + " (auto: hand-written streaming GEMM where measured faster than the TunableOp-selected library "
                          "kernel, library GEMM elsewhere; same bf16 inputs, fp32 accumulation)"},
@@ -438,10 +489,11 @@ def main():
                 "launches_timed": launches,
                 "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
 
-    def measure(tp: int, dp: int, label: str, role: str, eager: bool = False) -> dict:
-        elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal, eager)
+    def measure(tp: int, dp: int, label: str, role: str, eager: bool = False, allreduce: str = "rccl") -> dict:
+        elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal, eager, allreduce)
         ms = elapsed / a.steps * 1e3
-        res = {"parallelism": label, "role": role, "tp": tp, "ms_per_step": round(ms, 3),
+        res = {"parallelism": label, "role": role, "tp": tp, "allreduce": allreduce if tp > 1 else "none",
+               "ms_per_step": round(ms, 3),
                "value": round(a.batch * a.steps / elapsed, 1), "hipgraph": bool(runner._graphs),
                "decode_partition": runner._decode_part,
                "tuned_gemm_csv_loaded": bool(getattr(runner, "tuned_gemms", False)),
@@ -453,20 +505,27 @@ def main():
     # With more than one GPU the measurements go from the safest to the fastest, each kept once it exists:
     #   1. the plan WITHOUT a data-path collective (pure data parallel, captured step);
     #   2. the tensor-parallel plan run EAGERLY (RCCL all-reduces as plain stream operations);
-    #   3. the tensor-parallel plan with the step captured in a hipGraph (RCCL inside the capture: never exercised on
-    #      the 1-GPU boxes this repo is developed on).
-    # 2 and 3 run under a wall-clock watchdog.  Whatever raises or hangs, rank 0 still prints ONE line from what was
+    #   3. the tensor-parallel plan captured in a hipGraph with the in-tree all-reduce, after an on-rank validation;
+    #   4. the tensor-parallel plan captured with RCCL inside the capture (never exercised on the 1-GPU boxes this repo
+    #      is developed on).
+    # 2 to 4 run under a wall-clock watchdog.  Whatever raises or hangs, rank 0 still prints ONE line from what was
     # measured before it — the widest tensor-parallel plan that produced a number is the headline, its faster variant
     # if both exist — with what happened to the failed attempt next to it, instead of nothing.
     results: list[dict] = []
     failures: list[dict] = []
-    ordered = [(tp, dp, label, role, False) for tp, dp, label, role in sorted(plans, key=lambda pl: pl[0])]   # tp == 1 first
+    first_ar = os.environ.get("VLLM_OMNI_AMD_ALLREDUCE", "rccl")
+    ordered = [(tp, dp, label, role, False, first_ar) for tp, dp, label, role in sorted(plans, key=lambda pl: pl[0])]   # tp == 1 first
     safe_first = world > 1 and len(ordered) > 1 and ordered[0][0] == 1
     if safe_first and not a.eager and os.environ.get("MI_BENCH_TP_EAGER_FIRST", "1") == "1":
         staged = [ordered[0]]
-        for tp, dp, label, role, _ in ordered[1:]:
-            staged.append((tp, dp, label + " (eager)", role + ", eager launches", True))
-            staged.append((tp, dp, label, role, False))
+        for tp, dp, label, role, _, ar in ordered[1:]:
+            staged.append((tp, dp, label + " (eager)", role + ", eager launches", True, ar))
+            # 3. the same plan, captured, on the in-tree all-reduce (csrc/allreduce.hip) once it has reproduced the
+            #    library's sums on these very ranks (validate_in_tree_allreduce): the multi-GPU run DESIGN.md 5.1 waits
+            #    for.  Before 4 because a failed capture of library collectives leaves the process unusable.
+            if ar != "custom" and os.environ.get("MI_BENCH_TRY_IN_TREE_ALLREDUCE", "1") == "1":
+                staged.append((tp, dp, label + " (in-tree all-reduce)", role + ", in-tree two-shot all-reduce", False, "custom"))
+            staged.append((tp, dp, label, role, False, ar))   # 4. captured, library collectives inside the graph
         ordered = staged
 
     def emit_and_exit(reason: str, what: str) -> None:      # watchdog thread
@@ -475,7 +534,7 @@ def main():
             print(json.dumps(compose(results, failures)), flush=True)
         os._exit(0 if results else 3)
 
-    for i, (tp, dp, label, role, eager) in enumerate(ordered):
+    for i, (tp, dp, label, role, eager, ar_kind) in enumerate(ordered):
         guard = None
         if safe_first and i > 0:
             import threading
@@ -485,7 +544,7 @@ def main():
             guard.daemon = True
             guard.start()
         try:
-            results.append(measure(tp, dp, label, role, eager))
+            results.append(measure(tp, dp, label, role, eager, ar_kind))
         except Exception as e:  # noqa: BLE001
             if not (safe_first and i > 0):
                 raise
