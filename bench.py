@@ -264,6 +264,10 @@ def cpu_baseline(cfg, batch: int, ctx: int, block_size: int, budget_s: float = 2
                       "no extrapolation; CPU restatement of reference semantics, not a reference CPU backend"}
 
 
+class StageSkipped(RuntimeError):
+    """A staged attempt declined to run (agreed by all ranks, nothing left in a bad state): the next stage may go on."""
+
+
 def validate_in_tree_allreduce(dev, rows: int, cols: int) -> None:
     """Before anything is timed on the in-tree all-reduce (csrc/allreduce.hip) it must reproduce, on THESE ranks, what the
     transport every other plan used gives: the decode step's message, a ragged one, eager and replayed from a hipGraph
@@ -308,7 +312,7 @@ def validate_in_tree_allreduce(dev, rows: int, cols: int) -> None:
     flag = torch.tensor([1.0 if ok else 0.0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=st.tp_group)
     if flag.item() < 1.0:
-        raise RuntimeError("the in-tree all-reduce did not reproduce the library all-reduce on these ranks")
+        raise StageSkipped("the in-tree all-reduce did not reproduce the library all-reduce on these ranks")
 
 
 def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bool, eager: bool = False,
@@ -545,6 +549,9 @@ def main():
             guard.start()
         try:
             results.append(measure(tp, dp, label, role, eager, ar_kind))
+        except StageSkipped as e:
+            failures.append({"parallelism": label, "error": str(e)})
+            continue
         except Exception as e:  # noqa: BLE001
             if not (safe_first and i > 0):
                 raise
