@@ -538,12 +538,21 @@ def main():
             print(json.dumps(compose(results, failures)), flush=True)
         os._exit(0 if results else 3)
 
+    t_bench0 = time.monotonic()
+    budget = float(os.environ.get("MI_BENCH_BUDGET_S", "420"))   # no further stage is STARTED past this many seconds
     for i, (tp, dp, label, role, eager, ar_kind) in enumerate(ordered):
         guard = None
         if safe_first and i > 0:
             import threading
 
-            limit = float(os.environ.get("MI_BENCH_TP_WATCHDOG_S", "240"))
+            # every rank must take the same decision: rank 0's clock decides
+            late = torch.tensor([1.0 if time.monotonic() - t_bench0 > budget else 0.0], device=dev if not rehearsal else "cpu")
+            dist.broadcast(late, src=0)
+            if late.item() > 0:
+                failures.append({"parallelism": label, "error": f"not started: {budget:.0f} s budget of the run used up"})
+                continue
+
+            limit = float(os.environ.get("MI_BENCH_TP_WATCHDOG_S", "200"))
             guard = threading.Timer(limit, emit_and_exit, args=(f"no result within {limit:.0f} s (hung collective?)", label))
             guard.daemon = True
             guard.start()
