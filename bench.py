@@ -327,7 +327,10 @@ def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bo
         init_distributed_environment(world, rank, tp, backend="gloo" if rehearsal else "nccl",
                                      device=None if rehearsal else dev)
         if allreduce == "custom" and tp > 1:
-            validate_in_tree_allreduce(dev, a.batch // dp, cfg.hidden_size)
+            # inference mode like the runner's own captures: the capture bookkeeping of the default generator was created
+            # under it by the earlier plans and may only be updated under it
+            with torch.inference_mode():
+                validate_in_tree_allreduce(dev, a.batch // dp, cfg.hidden_size)
     local_batch = a.batch // dp
     max_model_len = a.ctx + a.block_size
     runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=local_batch, max_model_len=max_model_len,
@@ -503,6 +506,9 @@ def main():
                "tuned_gemm_csv_loaded": bool(getattr(runner, "tuned_gemms", False)),
                "roofline": roofline_of(runner, local_batch, tp)}
         del runner
+        import gc
+
+        gc.collect()               # the runner's object graph has cycles; the next plan needs its HBM back
         torch.cuda.empty_cache()
         return res
 
@@ -564,7 +570,10 @@ def main():
         except Exception as e:  # noqa: BLE001
             if not (safe_first and i > 0):
                 raise
-            failures.append({"parallelism": label, "error": f"{type(e).__name__}: {str(e)[:300]}"})
+            import traceback
+
+            failures.append({"parallelism": label, "error": f"{type(e).__name__}: {str(e)[:300]}",
+                             "where": traceback.format_exc()[-700:]})
             if guard is not None:
                 guard.cancel()
             # a failed capture / collective leaves the process group in an unknown state: report and leave
