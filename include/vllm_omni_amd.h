@@ -174,6 +174,29 @@ int mi_paged_attn_prefill(void* out, const void* q, const void* k_cache, const v
                           int64_t cache_token_stride, int64_t cache_head_stride, int dtype,
                           void* stream);
 
+/* The same op with its context split into segments where the launch would otherwise leave most CUs idle — the ragged
+ * last chunk of a long prompt (77 tokens on 16k of context are 12 workgroups of 500 steps), a TP shard with one KV
+ * head: every query tile's keys are cut into runs handled by separate workgroups that write a normalised fp32
+ * partial and its log-sum-exp to `workspace`; a merge kernel combines them (same stream, no host involvement).
+ *   max_seq_len     host upper bound of seq_lens (0: never split)
+ *   force_segments  0 automatic (only launches below two workgroups per CU, >= 512 keys per segment),
+ *                   1 never, n > 1 n segments (tests)
+ *   workspace       >= mi_paged_attn_prefill_workspace_bytes(...) bytes for the same arguments, 16-byte aligned;
+ *                   NULL: never split.  MI_ERR_WORKSPACE when too small.
+ * mi_paged_attn_prefill == this with max_seq_len 0 and no workspace. */
+int64_t mi_paged_attn_prefill_workspace_bytes(int32_t num_tokens, int32_t num_seqs, int32_t max_query_len,
+                                              int32_t max_seq_len, int32_t num_q_heads, int32_t num_kv_heads,
+                                              int32_t head_dim, int32_t force_segments);
+int mi_paged_attn_prefill_split(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                const int32_t* block_table, const int32_t* seq_lens,
+                                const int32_t* query_start_loc, int32_t num_seqs, int32_t num_tokens,
+                                int32_t max_query_len, int32_t num_q_heads, int32_t num_kv_heads,
+                                int32_t head_dim, int32_t block_size, int32_t block_table_stride, float scale,
+                                int64_t q_token_stride, int64_t out_token_stride, int64_t cache_block_stride,
+                                int64_t cache_token_stride, int64_t cache_head_stride, int dtype,
+                                int32_t max_seq_len, int32_t force_segments, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * A8 — RMSNorm and fused residual-add RMSNorm.
  * Replaces upstream `RMSNorm.forward(x[, residual])` at qwen2_old.py:212-216,

@@ -11,8 +11,9 @@ from oracle import ref_ops
 pytestmark = pytest.mark.gpu
 
 
-def _case(dev, nq, nkv, bs, ctxs, chunks, dtype, seed=0, d=128):  # noqa: D401
-    """ctxs[i] tokens already cached + chunks[i] new query tokens per sequence."""
+def _case(dev, nq, nkv, bs, ctxs, chunks, dtype, seed=0, d=128, segments=1):  # noqa: D401
+    """ctxs[i] tokens already cached + chunks[i] new query tokens per sequence.  ``segments``: 1 = the context of a
+    tile is never split; 0 = automatic; n > 1 = forced (ops.paged_attn_prefill)."""
     from vllm_omni_amd import ops
 
     g = torch.Generator().manual_seed(seed)
@@ -30,7 +31,7 @@ def _case(dev, nq, nkv, bs, ctxs, chunks, dtype, seed=0, d=128):  # noqa: D401
     kvg = kv.to(dev)
     out = torch.full((T, nq * d), float("nan"), dtype=dtype, device=dev)
     ops.paged_attn_prefill(out, q.view(T, -1).to(dev), kvg[:, 0], kvg[:, 1], table.to(dev), seq_lens.to(dev),
-                           qsl.to(dev), max(chunks), d ** -0.5)
+                           qsl.to(dev), max(chunks), d ** -0.5, max_seq_len=max(lens), segments=segments)
     torch.cuda.synchronize()
     return out.cpu().float().view(T, nq, d), ref
 
@@ -99,6 +100,47 @@ def test_prefill_gqa_groups_that_are_not_powers_of_two(dev, nq, nkv):
     got, ref = _case(dev, nq, nkv, 16, [0, 25, 90], [80, 43, 7], torch.bfloat16, seed=13)
     assert torch.isfinite(got).all()
     torch.testing.assert_close(got, ref, rtol=4e-3, atol=8e-3)
+
+
+SPLIT_CASES = [
+    # nq, nkv, d, ctxs, chunks, forced segments
+    (28, 4, 128, [1000], [77], 4),                 # a ragged last chunk on a long context (32x32x16 kernel, 36-token tiles)
+    (28, 4, 128, [300, 0, 2100], [40, 130, 5], 3),   # sequences of very different lengths: some tiles fit one segment
+    (7, 1, 128, [513], [129], 5),                  # one KV head (a TP=4 rank); a segment boundary inside a tile's diagonal
+    (8, 8, 128, [250], [20], 2),                   # MHA: one-wave workgroups
+    (16, 2, 64, [900], [64], 4),                   # head_dim 64: the 16x16x32 kernel
+    (16, 2, 64, [700, 64], [9, 16], 3),            # chunks <= 16 tokens: 16-token tiles
+    (28, 4, 128, [2000], [8], 6),                  # a speculative-verify-sized chunk on a long context (16-token tiles)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_prefill_with_context_segments(dev, case, dtype):
+    """The context of every query tile cut into segments run by separate workgroups and merged (fp32 partials + log-sum-exp,
+    csrc/paged_attn_prefill.hip): against the oracle at the unsplit kernel's tolerance, and against the unsplit kernel
+    itself (the same products, one more fp32 re-association).  Segment boundaries fall inside tiles' causal diagonals,
+    so some query columns see no key at all of a later segment."""
+    nq, nkv, d, ctxs, chunks, nseg = case
+    got, ref = _case(dev, nq, nkv, 16, ctxs, chunks, dtype, seed=31, d=d, segments=nseg)
+    one, _ = _case(dev, nq, nkv, 16, ctxs, chunks, dtype, seed=31, d=d, segments=1)
+    assert torch.isfinite(got).all()
+    atol = 8e-3 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol)
+    # split and unsplit round the same fp32 quantity up to re-association: at most one 16-bit ulp apart
+    torch.testing.assert_close(got, one, rtol=2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10, atol=1e-3)
+
+
+def test_prefill_automatic_segments_on_a_small_launch(dev):
+    """No forcing: 77 new tokens on 6000 cached ones are 3 tiles x 4 KV heads = 12 workgroups, so the launch policy splits
+    the context (and leaves a big launch alone: the workspace query returns 0 for the 8k prompt)."""
+    from vllm_omni_amd import _C
+
+    got, ref = _case(dev, 28, 4, 16, [6000], [77], torch.bfloat16, seed=33, segments=0)
+    torch.testing.assert_close(got, ref, rtol=4e-3, atol=8e-3)
+    assert _C.lib.mi_paged_attn_prefill_workspace_bytes(77, 1, 77, 6077, 28, 4, 128, 0) > 0
+    assert _C.lib.mi_paged_attn_prefill_workspace_bytes(8192, 1, 8192, 8192, 28, 4, 128, 0) == 0
+    assert _C.lib.mi_paged_attn_prefill_workspace_bytes(77, 1, 77, 6077, 28, 4, 128, 1) == 0
 
 
 def test_prefill_equals_decode_for_single_token_chunks(dev):

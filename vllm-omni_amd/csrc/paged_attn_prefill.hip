@@ -46,6 +46,11 @@ struct PrefillParams {
   const int32_t* query_start_loc;
   int32_t num_seqs, num_q_heads, kv_group, heads_per_wg, bs_log2, block_table_stride;
   int32_t qt;   // query tokens per workgroup tile (32x32x16 kernel)
+  // context segments ("split-KV"): a tile's keys are cut into nseg runs of seg_steps 32-key steps, each run a workgroup
+  // of its own that writes a normalised fp32 partial + its log2-sum-exp to `ws`; prefill_merge_kernel combines them.
+  // nseg == 1 (seg_steps huge): no split, the kernels store the 16-bit output themselves.
+  int32_t nseg, seg_steps;
+  float* ws;    // [token][q head][nseg][head_dim + 1]
   float scale_log2e;
   int64_t q_stride, out_stride, blk_stride, tok_stride, head_stride;
 };
@@ -113,7 +118,8 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   // but compute and store nothing)
   const int chunks = (p.kv_group + p.heads_per_wg - 1) / p.heads_per_wg;
   const int nz = (p.num_q_heads / p.kv_group) * chunks;
-  const int zz = (int)blockIdx.x % nz, tile_rank = (int)blockIdx.x / nz;
+  const int zz = (int)blockIdx.x % nz, wrank = (int)blockIdx.x / nz;
+  const int seg = wrank % p.nseg, tile_rank = wrank / p.nseg;   // segment-minor: a tile's segments are dispatched together
   const int kvh = zz / chunks;
   const int hg = (zz % chunks) * p.heads_per_wg + wid;
   const bool active = hg < p.kv_group;                            // wave-uniform
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const int q_len = p.query_start_loc[seq + 1] - q0;
   const int seq_len = p.seq_lens[seq];
   // longest (latest) tiles first: the dispatcher hands out blockIdx.x in ascending order
-  const int tile0 = ((int)gridDim.x / nz - 1 - tile_rank) * QT;  // first query row of this tile inside the chunk
+  const int tile0 = ((int)gridDim.x / (nz * p.nseg) - 1 - tile_rank) * QT;  // first query row of this tile inside the chunk
   if (tile0 >= q_len) return;              // whole workgroup: uniform
   const int ctx_off = seq_len - q_len;     // absolute position of query row 0
   const int rows = min(QT, q_len - tile0);
@@ -131,7 +137,11 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const int col = lane & 15;  // query token inside a column tile
   const int g = lane >> 4;
   const int limit = ctx_off + tile0 + rows;                // keys [0, limit) are visible to the tile
-  const int t_end = (limit + kStep - 1) / kStep;
+  const int t_full = (limit + kStep - 1) / kStep;          // steps of the whole tile
+  const int t_begin = seg * p.seg_steps;                   // this workgroup's run of them (a multiple of 4: stages)
+  if (t_begin >= t_full) return;                           // whole workgroup, before any barrier
+  const int t_end = min(t_full, t_begin + p.seg_steps);
+  const bool split = t_full > p.seg_steps;                 // the tile has more than one segment: partials + merge
   const int qpos0 = ctx_off + tile0 + col;                 // absolute position of my column in tile 0
 
   // constant address space: the (wave-uniform) block-id fetch becomes a SCALAR load (lgkmcnt), so
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   // load's latency sat in front of the DMA instructions of every step otherwise (180 ns per step on the issuing waves).
   int32_t bt_next[SUBS];
 #pragma unroll
-  for (int u = 0; u < SUBS; ++u) bt_next[u] = iw >= 0 ? bt_row[min((16 * ((iw * SUBS + u) & 1)) >> p.bs_log2, last_blk)] : 0;
+  for (int u = 0; u < SUBS; ++u) bt_next[u] = iw >= 0 ? bt_row[min((t_begin * kStep + 16 * ((iw * SUBS + u) & 1)) >> p.bs_log2, last_blk)] : 0;
   // `interior`: the caller guarantees that every row of step t is below `limit` (no tail rows, no clamped block index)
   auto issue = [&](int t, int st, auto interior) {  // my share of the stage (the first waves issue nothing)
     if (iw < 0) return;
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   // masks, lane-local maximum, the rare raise: everything of step t's softmax that branches
   auto pre = [&](int t, f32x4_t (&s0)[NC], f32x4_t (&s1)[NC], auto interior) {
     if constexpr (MI_PREFILL_ABLATE & 1) return;
-    const bool first = t == 0;   // wave-uniform
+    const bool first = t == t_begin;   // wave-uniform
     bool raise = first;
     float mx[NC];
 #pragma unroll
@@ -363,7 +373,8 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
       for (int c = 0; c < NC; ++c) {
         const float m = rows_allreduce_max(mx[c]);   // per column, the same in its four lane rows
         if (first) {
-          mu[c] = m;                   // key 0 is visible to every column of a tile: finite; acc and l are still zero
+          mu[c] = m > -INFINITY ? m : 0.f;   // acc and l are still zero; a column that sees NO key of a later segment's
+                                             // first step keeps a finite reference (its p are all exactly 0)
         } else {
           const float gr = max2f(m - mu[c], 0.f);
           const float alpha = fast_exp2(-gr * p.scale_log2e);
@@ -440,12 +451,12 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   // the second-dispatched half of the workgroup loses the issue arbitration of its SIMD on every step (older wave first:
   // 700 vs 1090 ns of compute per step measured); one static priority raise (MI355X_MICROARCH.md, two waves per SIMD, item 4)
   if (MI_PREFILL_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
-  issue(0, 0, std::false_type{});
-  if (1 < t_end) issue(1, 1, std::false_type{});
-  if (2 < t_end) issue(2, 2, std::false_type{});
+  issue(t_begin, 0, std::false_type{});
+  if (t_begin + 1 < t_end) issue(t_begin + 1, 1, std::false_type{});
+  if (t_begin + 2 < t_end) issue(t_begin + 2, 2, std::false_type{});
   // scores of step 0 ahead of the loop
-  if (2 < t_end) wait_vmcnt<2 * SHARE>();
-  else if (1 < t_end) wait_vmcnt<SHARE>();
+  if (t_begin + 2 < t_end) wait_vmcnt<2 * SHARE>();
+  else if (t_begin + 1 < t_end) wait_vmcnt<SHARE>();
   else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (active) {
@@ -454,8 +465,8 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     qk_mfma(k0, k1, sc0[0], sc1[0]);
   }
   // interior steps [0, t_int): t + 3 < t_end, (t + 1) * 32 <= first diagonal key of the tile; whole groups of four
-  const int t_int = max(0, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
-  int t = 0;
+  const int t_int = max(t_begin, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
+  int t = t_begin;
   for (; t < t_int; t += 4) {
     step(t, S0{}, std::true_type{});
     step(t + 1, S1{}, std::true_type{});
@@ -484,15 +495,25 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
     float lc = l[c];
     lc = rows_allreduce_sum(lc);
     if (active && kColTile * c + col < rows) {
-      const float inv = 1.f / lc;
-      uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + kColTile * c + col) * p.out_stride +
-                    (int64_t)head * HD + 4 * g;
+      const float inv = lc > 0.f ? 1.f / lc : 0.f;   // lc == 0: a column that saw no key of this segment
+      if (split) {
+        // normalised fp32 partial + log2-sum-exp of the segment; merged by prefill_merge_kernel
+        float* w = p.ws + (((int64_t)(q0 + tile0 + kColTile * c + col) * p.num_q_heads + head) * p.nseg + seg) * (HD + 1);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        uint2 r;
-        r.x = E::pack(acc[c][n][0] * inv, acc[c][n][1] * inv);
-        r.y = E::pack(acc[c][n][2] * inv, acc[c][n][3] * inv);
-        *reinterpret_cast<uint2*>(o + 16 * n) = r;
+        for (int n = 0; n < NT; ++n)
+          *reinterpret_cast<f32x4_t*>(w + 16 * n + 4 * g) =
+              f32x4_t{acc[c][n][0] * inv, acc[c][n][1] * inv, acc[c][n][2] * inv, acc[c][n][3] * inv};
+        if (g == 0) w[HD] = lc > 0.f ? mu[c] * p.scale_log2e + __builtin_amdgcn_logf(lc) : -INFINITY;
+      } else {
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + kColTile * c + col) * p.out_stride +
+                      (int64_t)head * HD + 4 * g;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          uint2 r;
+          r.x = E::pack(acc[c][n][0] * inv, acc[c][n][1] * inv);
+          r.y = E::pack(acc[c][n][2] * inv, acc[c][n][3] * inv);
+          *reinterpret_cast<uint2*>(o + 16 * n) = r;
+        }
       }
     }
   }
@@ -539,7 +560,8 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   const int seq = blockIdx.y;
   const int chunks = (p.kv_group + p.heads_per_wg - 1) / p.heads_per_wg;
   const int nz = (p.num_q_heads / p.kv_group) * chunks;
-  const int zz = (int)blockIdx.x % nz, tile_rank = (int)blockIdx.x / nz;
+  const int zz = (int)blockIdx.x % nz, wrank = (int)blockIdx.x / nz;
+  const int seg = wrank % p.nseg, tile_rank = wrank / p.nseg;   // segment-minor: a tile's segments are dispatched together
   const int kvh = zz / chunks;
   const int h_first = (zz % chunks) * p.heads_per_wg;
   const int nheads = min(p.heads_per_wg, p.kv_group - h_first);   // query heads of this workgroup
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   const int q0 = p.query_start_loc[seq];
   const int q_len = p.query_start_loc[seq + 1] - q0;
   const int seq_len = p.seq_lens[seq];
-  const int tile0 = ((int)gridDim.x / nz - 1 - tile_rank) * QT;  // longest tiles first, all kv heads (see the 16x16x32 kernel)
+  const int tile0 = ((int)gridDim.x / (nz * p.nseg) - 1 - tile_rank) * QT;  // longest tiles first, all kv heads (see the 16x16x32 kernel)
   if (tile0 >= q_len) return;
   const int ctx_off = seq_len - q_len;
   const int rows = min(QT, q_len - tile0);
@@ -572,7 +594,11 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     qpos[c] = ctx_off + tile0 + qi[c];
   }
   const int limit = ctx_off + tile0 + rows;
-  const int t_end = (limit + kStep - 1) / kStep;
+  const int t_full = (limit + kStep - 1) / kStep;          // steps of the whole tile
+  const int t_begin = seg * p.seg_steps;                   // this workgroup's run of them (a multiple of 4: stages)
+  if (t_begin >= t_full) return;                           // whole workgroup, before any barrier
+  const int t_end = min(t_full, t_begin + p.seg_steps);
+  const bool split = t_full > p.seg_steps;                 // the tile has more than one segment: partials + merge
 
   typedef const __attribute__((address_space(4))) int32_t cint32_t;
   cint32_t* const bt_row = (cint32_t*)(p.block_table + (int64_t)seq * p.block_table_stride);
@@ -620,7 +646,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   }
   int32_t bt_next[SUBS];
 #pragma unroll
-  for (int u = 0; u < SUBS; ++u) bt_next[u] = iw >= 0 ? bt_row[min((16 * ((iw * SUBS + u) & 1)) >> p.bs_log2, last_blk)] : 0;
+  for (int u = 0; u < SUBS; ++u) bt_next[u] = iw >= 0 ? bt_row[min((t_begin * kStep + 16 * ((iw * SUBS + u) & 1)) >> p.bs_log2, last_blk)] : 0;
   auto issue = [&](int t, int st, auto interior) {
     if (iw < 0) return;
     if constexpr ((MI_PREFILL_ABLATE & 16) != 0) return;
@@ -703,7 +729,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
   for (int c = 0; c < NC; ++c) mx_pre[c] = 0.f;
   auto pre = [&](int t, f32x16_t (&s)[NC], auto interior) {
-    const bool first = t == 0;
+    const bool first = t == t_begin;
     float mx[NC];
     bool raise = first;
 #pragma unroll
@@ -728,7 +754,8 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
         permlane32_swap(a, b);             // the column's other 16 keys
         const float m = max2f(a, b);
         if (first) {
-          mu[c] = m;                       // key 0 is visible to every column: finite; acc and l are still zero
+          mu[c] = m > -INFINITY ? m : 0.f;   // acc and l are still zero; a column that sees NO key of a later segment's
+                                             // first step keeps a finite reference (its p are all exactly 0)
         } else {
           const float gr = max2f(m - mu[c], 0.f);
           const float alpha = fast_exp2(-gr * p.scale_log2e);
@@ -815,11 +842,11 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     }
   };
   if (MI_PREFILL_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
-  issue(0, 0, std::false_type{});
-  if (1 < t_end) issue(1, 1, std::false_type{});
-  if (2 < t_end) issue(2, 2, std::false_type{});
-  if (2 < t_end) wait_vmcnt<2 * SHARE>();
-  else if (1 < t_end) wait_vmcnt<SHARE>();
+  issue(t_begin, 0, std::false_type{});
+  if (t_begin + 1 < t_end) issue(t_begin + 1, 1, std::false_type{});
+  if (t_begin + 2 < t_end) issue(t_begin + 2, 2, std::false_type{});
+  if (t_begin + 2 < t_end) wait_vmcnt<2 * SHARE>();
+  else if (t_begin + 1 < t_end) wait_vmcnt<SHARE>();
   else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (active) {
@@ -829,8 +856,8 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
     for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(sc[0][c]);
   }
-  const int t_int = max(0, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
-  int t = 0;
+  const int t_int = max(t_begin, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
+  int t = t_begin;
   for (; t < t_int; t += 4) {
     step(t, S0{}, std::true_type{});
     step(t + 1, S1{}, std::true_type{});
@@ -851,90 +878,207 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     permlane32_swap(la, lb);
     const float lsum = la + lb;
     if (valid[c]) {
-      const float inv = 1.f / lsum;
-      uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + qi[c]) * p.out_stride + (int64_t)head[c] * HD + 4 * h;
+      const float inv = lsum > 0.f ? 1.f / lsum : 0.f;   // lsum == 0: a column that saw no key of this segment
+      if (split) {
+        float* w = p.ws + (((int64_t)(q0 + tile0 + qi[c]) * p.num_q_heads + head[c]) * p.nseg + seg) * (HD + 1);
 #pragma unroll
-      for (int n = 0; n < NB; ++n)
+        for (int n = 0; n < NB; ++n)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          uint2 r;
-          r.x = E::pack(acc[c][n][4 * q4] * inv, acc[c][n][4 * q4 + 1] * inv);
-          r.y = E::pack(acc[c][n][4 * q4 + 2] * inv, acc[c][n][4 * q4 + 3] * inv);
-          *reinterpret_cast<uint2*>(o + 32 * n + 8 * q4) = r;
-        }
+          for (int q4 = 0; q4 < 4; ++q4)
+            *reinterpret_cast<f32x4_t*>(w + 32 * n + 8 * q4 + 4 * h) =
+                f32x4_t{acc[c][n][4 * q4] * inv, acc[c][n][4 * q4 + 1] * inv, acc[c][n][4 * q4 + 2] * inv, acc[c][n][4 * q4 + 3] * inv};
+        if (h == 0) w[HD] = lsum > 0.f ? mu[c] * p.scale_log2e + __builtin_amdgcn_logf(lsum) : -INFINITY;
+      } else {
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + tile0 + qi[c]) * p.out_stride + (int64_t)head[c] * HD + 4 * h;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            uint2 r;
+            r.x = E::pack(acc[c][n][4 * q4] * inv, acc[c][n][4 * q4 + 1] * inv);
+            r.y = E::pack(acc[c][n][4 * q4 + 2] * inv, acc[c][n][4 * q4 + 3] * inv);
+            *reinterpret_cast<uint2*>(o + 32 * n + 8 * q4) = r;
+          }
+      }
     }
   }
 }
 
-template <typename Tag>
-int launch_prefill32(PrefillParams p, int num_kv_heads, int max_query_len, hipStream_t s) {
-  // Waves, column tiles per wave and tokens per tile.
-  //   MI_PREFILL_W4=1 (experiment, off): 4..8 heads per workgroup as FOUR waves x 2 tiles x 32 columns, one wave per
-  //     SIMD with the 512-register file.  Measured 668-706 TFLOP/s against 842-889 for the 8-wave kernel at the 8k
-  //     prompt: hipcc keeps the 128 accumulators in the accumulation half but copies 110-190 registers between the
-  //     halves in every step (the rescale path needs them as plain VGPRs); this structure needs hand-owned registers.
-  //   default, one tile per wave: one wave per head and 32-token tiles when the head count is a power of two, else the
-  //     next power of two of waves and as many tokens as fill their columns (MI_PREFILL_FLAT=0: one wave per head).
-  static const bool flat = [] {
-    const char* e = getenv("MI_PREFILL_FLAT");
-    return !e || atoi(e) != 0;
-  }();
-  static const bool w4 = [] {
-    const char* e = getenv("MI_PREFILL_W4");
-    return e && atoi(e) != 0;
-  }();
-  const int hpw = p.heads_per_wg;
-  const int nz = num_kv_heads * ((p.kv_group + hpw - 1) / hpw);
-  if (w4 && hpw >= 4) {
-    p.qt = 256 / hpw;
-    const dim3 grid(((max_query_len + p.qt - 1) / p.qt) * nz, p.num_seqs, 1), block(256);
-    hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 2>), grid, block, 0, s, p);
-    return launch_status();
-  }
-  int waves = hpw;
-  p.qt = 32;
-  if (flat && (hpw & (hpw - 1))) {
-    waves = hpw > 4 ? 8 : 4;
-    p.qt = 32 * waves / hpw;
-  }
-  const dim3 grid(((max_query_len + p.qt - 1) / p.qt) * nz, p.num_seqs, 1), block(64 * waves);
-  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 1>), grid, block, 0, s, p);
-  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 2, 1>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 1, 1>), grid, block, 0, s, p);
-  return launch_status();
-}
-
-template <typename Tag, int HD, int NC>
-int launch_prefill_nc(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
-  const int waves = p.heads_per_wg;  // one wave per query head
-  constexpr int QT = kColTile * NC;
-  const dim3 grid(((max_query_len + QT - 1) / QT) * num_kv_heads * ((p.kv_group + waves - 1) / waves), p.num_seqs, 1),
-      block(64 * waves);
-  if (waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4, NC>), grid, block, 0, s, p);
-  else if (waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2, NC>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1, NC>), grid, block, 0, s, p);
-  return launch_status();
-}
-
-// Column tiles per wave: 2 (32 query tokens per workgroup) once the chunk is long enough to use them;
-// a short chunk (decode-like mixed batches, tails) keeps 16-token tiles so that rows are not wasted.
-// MI_PREFILL_NC=1|2 overrides (tools/bench_prefill_kernel.py).
+// Combine the context segments of every split tile: out = sum_s 2^(lse_s - max) O_s / sum_s 2^(lse_s - max), fp32, one
+// 16-bit rounding.  One workgroup per (query token, sequence) — a launch that is split at all has few tiles, so the
+// parallelism has to come from tokens x heads; a token whose tile's context fits one segment was stored by its attention
+// workgroup and is skipped.  Segments a tile does not have are never read.
 template <typename Tag, int HD>
-int launch_prefill(const PrefillParams& p, int num_kv_heads, int max_query_len, hipStream_t s) {
-  static const int forced = [] {
+__global__ __launch_bounds__(256) void prefill_merge_kernel(const PrefillParams p) {
+  scalar_cache_acquire();
+  using E = Elem<Tag>;
+  const int seq = blockIdx.y, r = blockIdx.x;   // r: token inside the sequence's chunk
+  const int q0 = p.query_start_loc[seq];
+  const int q_len = p.query_start_loc[seq + 1] - q0;
+  if (r >= q_len) return;
+  const int tile0 = r / p.qt * p.qt;
+  const int rows = min(p.qt, q_len - tile0);
+  const int limit = p.seq_lens[seq] - q_len + tile0 + rows;
+  const int t_full = (limit + kStep - 1) / kStep;
+  if (t_full <= p.seg_steps) return;
+  const int ns = (t_full + p.seg_steps - 1) / p.seg_steps;
+  constexpr int Q = HD / 4;   // float4 groups per head row
+  for (int i = threadIdx.x; i < p.num_q_heads * Q; i += 256) {
+    const int d4 = i % Q, hq = i / Q;
+    const float* w = p.ws + ((int64_t)(q0 + r) * p.num_q_heads + hq) * p.nseg * (HD + 1);
+    float m = -INFINITY;
+    for (int sidx = 0; sidx < ns; ++sidx) m = fmaxf(m, w[sidx * (HD + 1) + HD]);
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (int sidx = 0; sidx < ns; ++sidx) {
+      const float wt = fast_exp2(w[sidx * (HD + 1) + HD] - m);   // segment 0 always has a finite lse: m is finite
+      den += wt;
+      a += *reinterpret_cast<const f32x4_t*>(w + sidx * (HD + 1) + 4 * d4) * wt;
+    }
+    const float inv = 1.f / den;
+    uint2 o;
+    o.x = E::pack(a[0] * inv, a[1] * inv);
+    o.y = E::pack(a[2] * inv, a[3] * inv);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)(q0 + r) * p.out_stride + (int64_t)hq * HD + 4 * d4) = o;
+  }
+}
+
+template <typename Tag, int HD>
+int launch_prefill_merge(const PrefillParams& p, int max_query_len, hipStream_t s) {
+  if (p.nseg <= 1) return MI_OK;
+  const dim3 grid(max_query_len, p.num_seqs, 1);
+  hipLaunchKernelGGL((prefill_merge_kernel<Tag, HD>), grid, dim3(256), 0, s, p);
+  return launch_status();
+}
+
+// Everything the host decides about a launch, in one place (the workspace query must size for the same plan the launch
+// will take): heads per workgroup, kernel, tile, context segments.
+struct PrefillPlan {
+  int hpw, nc, kernel32, w4, waves, qt, nseg, seg_steps;
+};
+
+PrefillPlan prefill_plan(int max_query_len, int num_seqs, int num_q_heads, int num_kv_heads, int head_dim, int max_seq_len,
+                         int force_segments) {
+  static const int forced_hpw = [] {
+    const char* e = getenv("MI_PREFILL_HPW");
+    return e ? atoi(e) : 0;
+  }();
+  static const int forced_nc = [] {
     const char* e = getenv("MI_PREFILL_NC");
     return e ? atoi(e) : 0;
   }();
-  const int nc = forced ? forced : (max_query_len > kColTile ? 2 : 1);
-  // MI_PREFILL_MM=16 keeps the 16x16x32 kernel for 32-token tiles (A/B: tools/bench_prefill_kernel.py)
-  static const bool mm16 = [] {
+  static const bool mm16 = [] {   // MI_PREFILL_MM=16 keeps the 16x16x32 kernel for 32-token tiles (A/B)
     const char* e = getenv("MI_PREFILL_MM");
     return e && atoi(e) == 16;
   }();
-  if constexpr (HD == 128)
-    if (nc >= 2 && !mm16) return launch_prefill32<Tag>(p, num_kv_heads, max_query_len, s);
-  return nc >= 2 ? launch_prefill_nc<Tag, HD, 2>(p, num_kv_heads, max_query_len, s)
-                 : launch_prefill_nc<Tag, HD, 1>(p, num_kv_heads, max_query_len, s);
+  static const bool flat = [] {   // MI_PREFILL_FLAT=0: one wave per head
+    const char* e = getenv("MI_PREFILL_FLAT");
+    return !e || atoi(e) != 0;
+  }();
+  static const bool w4 = [] {     // MI_PREFILL_W4=1: the four-wave / 512-register experiment
+    const char* e = getenv("MI_PREFILL_W4");
+    return e && atoi(e) != 0;
+  }();
+  PrefillPlan pl;
+  const int kv_group = num_q_heads / num_kv_heads;
+  // Query heads (= waves) per workgroup: the whole GQA group when it fits 8 waves (256-VGPR budget), else chunks of 8
+  // (the last one may be short).  A launch with fewer workgroups than two per CU (a TP shard with one KV head; a short
+  // chunk) cannot balance tiles of very different context lengths: split the GQA group over two workgroups there.
+  // Measured, 8k prompt: 7 heads / 1 KV head (S-A at TP=4) 0.216 -> 0.194 ms per layer in one chunk, 0.480 -> 0.401 in
+  // chunks of 2048; 8 / 1 heads of 64 dims (S-B at TP=2) 0.188 -> 0.152 and 0.432 -> 0.351
+  // (profiles/r02_prefill_shard_shapes.log).  MI_PREFILL_HPW overrides.
+  int hpw = kv_group <= 8 ? kv_group : 8;
+  {
+    const int64_t tiles = (max_query_len + 31) / 32;
+    if (tiles * num_seqs * num_kv_heads < 2 * 256 && hpw > 4) hpw = (hpw + 1) / 2;
+  }
+  if (forced_hpw > 0) hpw = forced_hpw < kv_group ? forced_hpw : kv_group;
+  if (hpw > 8) hpw = 8;
+  pl.hpw = hpw;
+  // Column tiles per wave of the 16x16x32 kernel: 2 (32 query tokens per workgroup) once the chunk is long enough to use
+  // them; a short chunk (decode-like mixed batches, tails) keeps 16-token tiles so that rows are not wasted.
+  pl.nc = forced_nc ? forced_nc : (max_query_len > kColTile ? 2 : 1);
+  pl.kernel32 = head_dim == 128 && pl.nc >= 2 && !mm16;
+  pl.w4 = pl.kernel32 && w4 && hpw >= 4;
+  if (pl.w4) {
+    // (experiment, off) 4..8 heads as FOUR waves x 2 tiles x 32 columns, one wave per SIMD with the 512-register file.
+    // Measured 668-706 TFLOP/s against 842-889 for the 8-wave kernel at the 8k prompt: hipcc keeps the 128 accumulators
+    // in the accumulation half but copies 110-190 registers between the halves in every step.
+    pl.waves = 4;
+    pl.qt = 256 / hpw;
+  } else if (pl.kernel32) {
+    // one 32-column tile per wave: one wave per head and 32-token tiles when the head count is a power of two, else the
+    // next power of two of waves and as many tokens as fill their columns
+    pl.waves = hpw;
+    pl.qt = 32;
+    if (flat && (hpw & (hpw - 1))) {
+      pl.waves = hpw > 4 ? 8 : 4;
+      pl.qt = 32 * pl.waves / hpw;
+    }
+  } else {
+    pl.waves = hpw;
+    pl.qt = kColTile * (pl.nc >= 2 ? 2 : 1);
+  }
+  // Context segments.  Automatic: only a launch with fewer than two workgroups per CU is split — the ragged last chunk
+  // of a long prompt (77 tokens on 16k of context are 12 workgroups of 500 steps each), a TP shard with one KV head —
+  // into enough segments for about four workgroups per CU, each at least 16 steps (512 keys) long.
+  // force_segments: 1 = never, n > 1 = n segments (tests; at least 4 steps each).
+  pl.nseg = 1;
+  pl.seg_steps = 1 << 28;
+  if (max_seq_len > 0 && force_segments != 1) {
+    const int chunks = (kv_group + hpw - 1) / hpw;
+    const int64_t base = (int64_t)((max_query_len + pl.qt - 1) / pl.qt) * num_seqs * num_kv_heads * chunks;
+    const int t_max = (max_seq_len + kStep - 1) / kStep;
+    int want = 1, cap = t_max / 16;
+    if (force_segments > 1) {
+      want = force_segments;
+      cap = t_max / 4;
+    } else if (base < 2 * 256) {
+      want = (int)((4 * 256 + base - 1) / base);
+    }
+    int n = want < cap ? want : cap;
+    if (n > 64) n = 64;
+    if (n > 1) {
+      pl.seg_steps = ((t_max + n - 1) / n + 3) & ~3;
+      pl.nseg = (t_max + pl.seg_steps - 1) / pl.seg_steps;
+      if (pl.nseg <= 1) {
+        pl.nseg = 1;
+        pl.seg_steps = 1 << 28;
+      }
+    }
+  }
+  return pl;
+}
+
+template <typename Tag, int HD>
+int launch_prefill(PrefillParams p, const PrefillPlan& pl, int num_kv_heads, int max_query_len, hipStream_t s) {
+  const int nz = num_kv_heads * ((p.kv_group + pl.hpw - 1) / pl.hpw);
+  const dim3 grid(((max_query_len + pl.qt - 1) / pl.qt) * nz * pl.nseg, p.num_seqs, 1), block(64 * pl.waves);
+  p.qt = pl.qt;
+  bool launched = false;
+  if constexpr (HD == 128) {
+    if (pl.kernel32) {
+      if (pl.w4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 2>), grid, block, 0, s, p);
+      else if (pl.waves >= 4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 1>), grid, block, 0, s, p);
+      else if (pl.waves >= 2) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 2, 1>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 1, 1>), grid, block, 0, s, p);
+      launched = true;
+    }
+  }
+  if (!launched) {
+    if (pl.nc >= 2) {
+      if (pl.waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4, 2>), grid, block, 0, s, p);
+      else if (pl.waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2, 2>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1, 2>), grid, block, 0, s, p);
+    } else {
+      if (pl.waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4, 1>), grid, block, 0, s, p);
+      else if (pl.waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2, 1>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1, 1>), grid, block, 0, s, p);
+    }
+  }
+  const int rc = launch_status();
+  if (rc != MI_OK) return rc;
+  return launch_prefill_merge<Tag, HD>(p, max_query_len, s);
 }
 
 }  // namespace
@@ -946,14 +1090,27 @@ extern "C" int mi_debug_prefill_ticks(unsigned long long* out) {
 }
 #endif
 
-extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
-                                     const int32_t* block_table, const int32_t* seq_lens,
-                                     const int32_t* query_start_loc, int32_t num_seqs, int32_t num_tokens,
-                                     int32_t max_query_len, int32_t num_q_heads, int32_t num_kv_heads,
-                                     int32_t head_dim, int32_t block_size, int32_t block_table_stride,
-                                     float scale, int64_t q_token_stride, int64_t out_token_stride,
-                                     int64_t cache_block_stride, int64_t cache_token_stride,
-                                     int64_t cache_head_stride, int dtype, void* stream) {
+extern "C" int64_t mi_paged_attn_prefill_workspace_bytes(int32_t num_tokens, int32_t num_seqs, int32_t max_query_len,
+                                                         int32_t max_seq_len, int32_t num_q_heads, int32_t num_kv_heads,
+                                                         int32_t head_dim, int32_t force_segments) {
+  using namespace mi;
+  if (num_tokens <= 0 || num_seqs <= 0 || max_query_len <= 0 || num_q_heads <= 0 || num_kv_heads <= 0 ||
+      num_q_heads % num_kv_heads || (head_dim != 64 && head_dim != 128))
+    return 0;
+  const PrefillPlan pl = prefill_plan(max_query_len, num_seqs, num_q_heads, num_kv_heads, head_dim, max_seq_len, force_segments);
+  return pl.nseg > 1 ? (int64_t)num_tokens * num_q_heads * pl.nseg * (head_dim + 1) * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int mi_paged_attn_prefill_split(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                           const int32_t* block_table, const int32_t* seq_lens,
+                                           const int32_t* query_start_loc, int32_t num_seqs, int32_t num_tokens,
+                                           int32_t max_query_len, int32_t num_q_heads, int32_t num_kv_heads,
+                                           int32_t head_dim, int32_t block_size, int32_t block_table_stride,
+                                           float scale, int64_t q_token_stride, int64_t out_token_stride,
+                                           int64_t cache_block_stride, int64_t cache_token_stride,
+                                           int64_t cache_head_stride, int dtype, int32_t max_seq_len,
+                                           int32_t force_segments, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
   using namespace mi;
   if (num_seqs == 0 || num_tokens == 0) return MI_OK;
   if (!out || !q || !k_cache || !v_cache || !block_table || !seq_lens || !query_start_loc)
@@ -965,30 +1122,17 @@ extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cac
   if (head_dim != 128 && head_dim != 64) return MI_ERR_UNSUPPORTED;
   if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
   if (!is_pow2(block_size) || block_size < 16) return MI_ERR_UNSUPPORTED;
-  const int kv_group = num_q_heads / num_kv_heads;
-  // Query heads (= waves) per workgroup: the whole GQA group when it fits 8 waves (256-VGPR budget), else
-  // chunks of 8 (the last one may be short).  Measured (8k prompt, 28/4 heads): one 7-wave workgroup per CU
-  // 563 TFLOP/s, two independent 4-wave workgroups 476 — the second K/V stream costs more than the
-  // phase interleaving gains.  MI_PREFILL_HPW overrides (tools/bench_prefill_kernel.py).
-  static const int forced_hpw = [] {
-    const char* e = getenv("MI_PREFILL_HPW");
-    return e ? atoi(e) : 0;
-  }();
-  int heads_per_wg = kv_group <= 8 ? kv_group : 8;
-  // A launch with fewer workgroups than two per CU (a TP shard with one KV head; a short chunk) cannot balance tiles
-  // of very different context lengths: split the GQA group over two workgroups there.  Measured, 8k prompt: 7 heads /
-  // 1 KV head (S-A at TP=4) 0.216 -> 0.194 ms per layer in one chunk, 0.480 -> 0.401 in chunks of 2048; 8 / 1 heads of
-  // 64 dims (S-B at TP=2) 0.188 -> 0.152 and 0.432 -> 0.351 (profiles/r02_prefill_shard_shapes.log).
-  {
-    const int64_t tiles = (max_query_len + 31) / 32;
-    if (tiles * num_seqs * num_kv_heads < 2 * 256 && heads_per_wg > 4) heads_per_wg = (heads_per_wg + 1) / 2;
-  }
-  if (forced_hpw > 0) heads_per_wg = forced_hpw < kv_group ? forced_hpw : kv_group;
-  if (heads_per_wg > 8) heads_per_wg = 8;
   if (q_token_stride % 8 || out_token_stride % 8 || cache_block_stride % 8 || cache_token_stride % 8 ||
       cache_head_stride % 8)
     return MI_ERR_INVALID_ARG;
   if (((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) & 15) return MI_ERR_INVALID_ARG;
+  const PrefillPlan pl = prefill_plan(max_query_len, num_seqs, num_q_heads, num_kv_heads, head_dim,
+                                      workspace ? max_seq_len : 0, force_segments);
+  if (pl.nseg > 1) {
+    if (((uintptr_t)workspace & 15)) return MI_ERR_INVALID_ARG;
+    if (workspace_bytes < (int64_t)num_tokens * num_q_heads * pl.nseg * (head_dim + 1) * (int64_t)sizeof(float))
+      return MI_ERR_WORKSPACE;
+  }
   PrefillParams p;
   p.out = out;
   p.q = q;
@@ -999,8 +1143,8 @@ extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cac
   p.query_start_loc = query_start_loc;
   p.num_seqs = num_seqs;
   p.num_q_heads = num_q_heads;
-  p.kv_group = kv_group;
-  p.heads_per_wg = heads_per_wg;
+  p.kv_group = num_q_heads / num_kv_heads;
+  p.heads_per_wg = pl.hpw;
   p.bs_log2 = __builtin_ctz((unsigned)block_size);
   p.block_table_stride = block_table_stride;
   p.scale_log2e = scale * kLog2e;
@@ -1009,10 +1153,28 @@ extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cac
   p.blk_stride = cache_block_stride;
   p.tok_stride = cache_token_stride;
   p.head_stride = cache_head_stride;
+  p.qt = pl.qt;
+  p.nseg = pl.nseg;
+  p.seg_steps = pl.seg_steps;
+  p.ws = reinterpret_cast<float*>(workspace);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == MI_DTYPE_BF16)
-    return head_dim == 128 ? launch_prefill<bf16_tag, 128>(p, num_kv_heads, max_query_len, s)
-                           : launch_prefill<bf16_tag, 64>(p, num_kv_heads, max_query_len, s);
-  return head_dim == 128 ? launch_prefill<f16_tag, 128>(p, num_kv_heads, max_query_len, s)
-                         : launch_prefill<f16_tag, 64>(p, num_kv_heads, max_query_len, s);
+    return head_dim == 128 ? launch_prefill<bf16_tag, 128>(p, pl, num_kv_heads, max_query_len, s)
+                           : launch_prefill<bf16_tag, 64>(p, pl, num_kv_heads, max_query_len, s);
+  return head_dim == 128 ? launch_prefill<f16_tag, 128>(p, pl, num_kv_heads, max_query_len, s)
+                         : launch_prefill<f16_tag, 64>(p, pl, num_kv_heads, max_query_len, s);
+}
+
+extern "C" int mi_paged_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                     const int32_t* block_table, const int32_t* seq_lens,
+                                     const int32_t* query_start_loc, int32_t num_seqs, int32_t num_tokens,
+                                     int32_t max_query_len, int32_t num_q_heads, int32_t num_kv_heads,
+                                     int32_t head_dim, int32_t block_size, int32_t block_table_stride,
+                                     float scale, int64_t q_token_stride, int64_t out_token_stride,
+                                     int64_t cache_block_stride, int64_t cache_token_stride,
+                                     int64_t cache_head_stride, int dtype, void* stream) {
+  return mi_paged_attn_prefill_split(out, q, k_cache, v_cache, block_table, seq_lens, query_start_loc, num_seqs, num_tokens,
+                                     max_query_len, num_q_heads, num_kv_heads, head_dim, block_size, block_table_stride,
+                                     scale, q_token_stride, out_token_stride, cache_block_stride, cache_token_stride,
+                                     cache_head_stride, dtype, 0, 1, nullptr, 0, stream);
 }

@@ -47,6 +47,11 @@ SIGNATURES = {
     "mi_paged_attn_prefill": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                                        c_int64, c_int64, c_int64, c_int64, c_int64, c_int, _P]),
+    "mi_paged_attn_prefill_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mi_paged_attn_prefill_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32,
+                                             c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+                                             c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int32, c_int32,
+                                             _P, c_int64, _P]),
     "mi_rms_norm": (c_int, [_P, _P, _P, c_float, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_fused_add_rms_norm": (c_int, [_P, _P, _P, c_float, c_int32, c_int32, c_int64, c_int64,
                                        c_int, _P]),

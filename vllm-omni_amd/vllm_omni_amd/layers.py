@@ -224,7 +224,8 @@ class Attention:
             t0 = nd  # decodes come first and have one token each
             ops.paged_attn_prefill(out[t0:md.num_actual_tokens], q[t0:md.num_actual_tokens], self._kb, self._vb,
                                    md.block_table[nd:md.num_reqs], md.seq_lens[nd:md.num_reqs],
-                                   md.query_start_loc[nd:md.num_reqs + 1] - nd, md.max_query_len, self.scale)
+                                   md.query_start_loc[nd:md.num_reqs + 1] - nd, md.max_query_len, self.scale,
+                                   max_seq_len=md.max_seq_len)   # lets a small launch split its tiles' context
         return out
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, output: Optional[torch.Tensor] = None):

@@ -172,10 +172,19 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
 
 
 # --------------------------------------------------------------------------- A6
+_PREFILL_WS: dict = {}   # device -> grow-only fp32 workspace of the split-context prefill (never captured in a graph)
+
+
 def paged_attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                        block_table: torch.Tensor, seq_lens: torch.Tensor, query_start_loc: torch.Tensor,
-                       max_query_len: int, scale: float) -> torch.Tensor:
-    """Varlen causal attention of query chunks against the paged cache (chunked prefill)."""
+                       max_query_len: int, scale: float, max_seq_len: Optional[int] = None,
+                       segments: int = 0) -> torch.Tensor:
+    """Varlen causal attention of query chunks against the paged cache (chunked prefill).
+
+    ``max_seq_len`` (host upper bound of ``seq_lens``) lets a launch that would leave most CUs idle — the ragged last
+    chunk of a long prompt, a TP shard with one KV head — split every tile's context into segments run by separate
+    workgroups and merged afterwards (``mi_paged_attn_prefill_split``).  Without it nothing is split.
+    ``segments``: 0 automatic, 1 never, n > 1 force n (tests)."""
     _gpu(out, q, k_cache, v_cache, block_table, seq_lens, query_start_loc)
     nb, bs, hkv, d = k_cache.shape
     t = q.shape[0]
@@ -184,10 +193,19 @@ def paged_attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor
     cb, ct, ch = _cache_strides(k_cache, v_cache)
     if t == 0 or s == 0:
         return out
-    check("mi_paged_attn_prefill", lib.mi_paged_attn_prefill(
+    ws, ws_bytes, msl = None, 0, 0
+    if max_seq_len is not None and segments != 1:
+        msl = int(max_seq_len)
+        ws_bytes = int(lib.mi_paged_attn_prefill_workspace_bytes(t, s, int(max_query_len), msl, nq, hkv, d, int(segments)))
+        if ws_bytes:
+            ws = _PREFILL_WS.get(q.device)
+            if ws is None or ws.numel() * 4 < ws_bytes:
+                ws = _PREFILL_WS[q.device] = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=q.device)
+    check("mi_paged_attn_prefill_split", lib.mi_paged_attn_prefill_split(
         _p(out), _p(q), _p(k_cache), _p(v_cache), _p(block_table), _p(seq_lens), _p(query_start_loc),
         s, t, int(max_query_len), nq, hkv, d, bs, block_table.stride(0), float(scale),
-        q.stride(0), out.stride(0), cb, ct, ch, _dt(q.dtype), _stream()))
+        q.stride(0), out.stride(0), cb, ct, ch, _dt(q.dtype), msl, int(segments) if ws is not None else 1,
+        _p(ws) if ws is not None else None, ws.numel() * 4 if ws is not None else 0, _stream()))
     return out
 
 
