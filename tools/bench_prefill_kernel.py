@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--segments", type=int, default=0, help="0 automatic (as the runner calls it), 1 never split the context")
     a = ap.parse_args()
     d = a.d
     dev = torch.device("cuda:0")
@@ -45,7 +46,7 @@ def main():
         def run():
             for i in range(n):
                 ops.paged_attn_prefill(out[i * chunk:(i + 1) * chunk], q[i * chunk:(i + 1) * chunk], kb, vb, table, sls[i],
-                                       qsl, chunk, d ** -0.5)
+                                       qsl, chunk, d ** -0.5, max_seq_len=(i + 1) * chunk, segments=a.segments)
         run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
