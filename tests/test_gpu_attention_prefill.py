@@ -143,6 +143,28 @@ def test_prefill_automatic_segments_on_a_small_launch(dev):
     assert _C.lib.mi_paged_attn_prefill_workspace_bytes(77, 1, 77, 6077, 28, 4, 128, 1) == 0
 
 
+def test_prefill_segments_with_a_low_context_bound(dev):
+    """``max_seq_len`` is a host-side bound; if it is too LOW the last segment still runs to the end of every tile (the
+    launch is less balanced, no key is dropped)."""
+    from vllm_omni_amd import ops
+
+    nq, nkv, d, bs = 28, 4, 128, 16
+    ctx, chunk = 3000, 50
+    g = torch.Generator().manual_seed(41)
+    total = ctx + chunk
+    nblk = (total + bs - 1) // bs
+    kv = torch.randn(nblk + 2, 2, bs, nkv, d, generator=g).to(torch.bfloat16)
+    table = (torch.randperm(nblk + 1, generator=g)[:nblk] + 1).view(1, -1).to(torch.int32)
+    q = torch.randn(chunk, nq, d, generator=g).to(torch.bfloat16)
+    sl, qsl = torch.tensor([total], dtype=torch.int32), torch.tensor([0, chunk], dtype=torch.int32)
+    ref = ref_ops.paged_attention_prefill(q, kv[:, 0], kv[:, 1], table, sl, qsl, d ** -0.5)
+    kvg = kv.to(dev)
+    out = torch.full((chunk, nq * d), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.paged_attn_prefill(out, q.view(chunk, -1).to(dev), kvg[:, 0], kvg[:, 1], table.to(dev), sl.to(dev), qsl.to(dev),
+                           chunk, d ** -0.5, max_seq_len=1024, segments=4)   # the sequence is three times as long
+    torch.testing.assert_close(out.cpu().float().view(chunk, nq, d), ref, rtol=4e-3, atol=8e-3)
+
+
 def test_prefill_equals_decode_for_single_token_chunks(dev):
     """q_len == 1 everywhere: the prefill kernel must agree with the decode kernel (same P rounding)."""
     from vllm_omni_amd import ops

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const int t_full = (limit + kStep - 1) / kStep;          // steps of the whole tile
   const int t_begin = seg * p.seg_steps;                   // this workgroup's run of them (a multiple of 4: stages)
   if (t_begin >= t_full) return;                           // whole workgroup, before any barrier
-  const int t_end = min(t_full, t_begin + p.seg_steps);
+  // the LAST segment runs to the end of the tile whatever the host's bound on seq_lens was: a low bound costs balance,
+  // never keys
+  const int t_end = seg == p.nseg - 1 ? t_full : min(t_full, t_begin + p.seg_steps);
   const bool split = t_full > p.seg_steps;                 // the tile has more than one segment: partials + merge
   const int qpos0 = ctx_off + tile0 + col;                 // absolute position of my column in tile 0
 
@@ -597,7 +599,9 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   const int t_full = (limit + kStep - 1) / kStep;          // steps of the whole tile
   const int t_begin = seg * p.seg_steps;                   // this workgroup's run of them (a multiple of 4: stages)
   if (t_begin >= t_full) return;                           // whole workgroup, before any barrier
-  const int t_end = min(t_full, t_begin + p.seg_steps);
+  // the LAST segment runs to the end of the tile whatever the host's bound on seq_lens was: a low bound costs balance,
+  // never keys
+  const int t_end = seg == p.nseg - 1 ? t_full : min(t_full, t_begin + p.seg_steps);
   const bool split = t_full > p.seg_steps;                 // the tile has more than one segment: partials + merge
 
   typedef const __attribute__((address_space(4))) int32_t cint32_t;
@@ -921,7 +925,7 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(const PrefillParams 
   const int limit = p.seq_lens[seq] - q_len + tile0 + rows;
   const int t_full = (limit + kStep - 1) / kStep;
   if (t_full <= p.seg_steps) return;
-  const int ns = (t_full + p.seg_steps - 1) / p.seg_steps;
+  const int ns = min((t_full + p.seg_steps - 1) / p.seg_steps, p.nseg);
   constexpr int Q = HD / 4;   // float4 groups per head row
   for (int i = threadIdx.x; i < p.num_q_heads * Q; i += 256) {
     const int d4 = i % Q, hq = i / Q;
