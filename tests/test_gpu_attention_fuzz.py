@@ -70,11 +70,15 @@ def test_prefill_random_geometry(dev, seed):
     kvg = kv.to(dev)
     kbg, vbg = (kvg[:, 0].permute(0, 2, 1, 3), kvg[:, 1].permute(0, 2, 1, 3)) if head_major else (kvg[:, 0], kvg[:, 1])
     out = torch.full((T, nq * d), float("nan"), dtype=dtype, device=dev)
-    ops.paged_attn_prefill(out, q.view(T, -1).to(dev), kbg, vbg, table.to(dev), seq_lens.to(dev), qsl.to(dev), max(chunks),
-                           d ** -0.5)
-    torch.cuda.synchronize()
-    got = out.cpu().float().view(T, nq, d)
-    assert torch.isfinite(got).all()
     atol = 8e-3 if dtype == torch.bfloat16 else 1e-3
-    torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol,
-                               msg=lambda m: f"d={d} nq={nq} nkv={nkv} bs={bs} ctxs={ctxs} chunks={chunks} hm={head_major}: {m}")
+    # once as a whole, once with every tile's context cut into a random number of segments (merged on the device)
+    for segments in (1, int(torch.randint(2, 6, (1,), generator=g))):
+        out.fill_(float("nan"))
+        ops.paged_attn_prefill(out, q.view(T, -1).to(dev), kbg, vbg, table.to(dev), seq_lens.to(dev), qsl.to(dev), max(chunks),
+                               d ** -0.5, max_seq_len=max(lens), segments=segments)
+        torch.cuda.synchronize()
+        got = out.cpu().float().view(T, nq, d)
+        assert torch.isfinite(got).all()
+        torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol,
+                                   msg=lambda m: f"d={d} nq={nq} nkv={nkv} bs={bs} ctxs={ctxs} chunks={chunks} hm={head_major} "
+                                                 f"segments={segments}: {m}")
