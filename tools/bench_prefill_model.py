@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=2048)
     ap.add_argument("--config", default="qwen2_5_omni_talker")
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--host-profile", action="store_true", help="cProfile of one prompt: where the host time of a step goes")
     a = ap.parse_args()
     from vllm_omni_amd import ops
     from vllm_omni_amd.kv_cache import KVCacheManager
@@ -34,6 +35,8 @@ def main():
 
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    if os.environ.get("MI_BLAS"):   # experiment: which library serves GEMM shapes TunableOp has no entry for
+        torch.backends.cuda.preferred_blas_library(os.environ["MI_BLAS"])
     cfg = TalkerConfig.from_json(a.config)
     bs = 16
     runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=4, max_model_len=a.prompt + bs,
@@ -54,6 +57,10 @@ def main():
         e1.record()
         attn_events.append((e0, e1))
         return r
+
+    # MI_PREFILL_STEP_MS=1: wall time of every step.  On this pool a box can be shared: a step that takes 80 ms where its
+    # neighbours take 8 is another tenant's time slice, not this code (seen: every third step, eager and captured alike)
+    step_ms = [] if os.environ.get("MI_PREFILL_STEP_MS") else None
 
     def one_prompt(i, instrument=False):
         r = Request(f"p{i}", rng.integers(0, cfg.vocab_size, size=a.prompt).tolist(), SamplingParams(temperature=0.0))
@@ -76,8 +83,12 @@ def main():
                                                num_computed_tokens=[done], num_output_tokens=[0])
                     so = SchedulerOutput(scheduled_cached_reqs=cached, num_scheduled_tokens={r.request_id: n},
                                          total_num_scheduled_tokens=n)
+                t_s = time.perf_counter()
                 runner.execute_model(so)
                 runner.sample_tokens()
+                if step_ms is not None:
+                    torch.cuda.synchronize()
+                    step_ms.append(round((time.perf_counter() - t_s) * 1e3, 2))
                 done += n
                 r.num_computed_tokens = done
         finally:
@@ -93,6 +104,16 @@ def main():
         one_prompt(1 + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
+    if a.host_profile:
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        one_prompt(50)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
     one_prompt(99, instrument=True)
     torch.cuda.synchronize()
     attn_ms = sum(e0.elapsed_time(e1) for e0, e1 in attn_events)
@@ -100,9 +121,15 @@ def main():
     d = cfg.head_dim
     attn_flops = nl * sum(2 * 2 * d * cfg.num_attention_heads * c * (i * a.chunk + (c + 1) / 2)
                           for i, c in enumerate([min(a.chunk, a.prompt - s) for s in range(0, a.prompt, a.chunk)]))
-    print(f"{a.config}: prompt {a.prompt} in chunks of {a.chunk}: {dt * 1e3:.1f} ms = {a.prompt / dt:,.0f} prompt tokens/s; "
-          f"attention {attn_ms:.1f} ms ({attn_ms / (dt * 1e3):.0%} of the prefill, {attn_flops / attn_ms / 1e9:.0f} TFLOP/s over "
-          f"{len(attn_events)} launches)")
+    if step_ms:
+        print("wall ms per step (every prompt, in order):", step_ms)
+    line = f"{a.config}: prompt {a.prompt} in chunks of {a.chunk}: {dt * 1e3:.1f} ms = {a.prompt / dt:,.0f} prompt tokens/s; "
+    if attn_ms > 0:
+        line += (f"attention {attn_ms:.1f} ms ({attn_ms / (dt * 1e3):.0%} of the prefill, {attn_flops / attn_ms / 1e9:.0f} TFLOP/s over "
+                 f"{len(attn_events)} eager launches)")
+    else:
+        line += "no eager attention launch was seen"
+    print(line)
 
 
 if __name__ == "__main__":
