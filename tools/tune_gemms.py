@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--tps", default="1,2,4")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tunableop_gfx950.csv"))
     ap.add_argument("--max-ms", type=int, default=2000)
+    ap.add_argument("--code-predictor", action="store_true",
+                    help="the Qwen3-Omni code predictor's linears (H 1024, 16/8 heads of 128, I 3072, vocab 2048) at --batches "
+                         "rows and twice as many (its 2-token prefill) instead of a talker config")
     a = ap.parse_args()
     import torch.cuda.tunable as tn
     from vllm_omni_amd.talker import TalkerConfig
@@ -51,9 +54,21 @@ def main():
     tn.set_filename(a.out)
     dev = torch.device("cuda:0")
     seen = set()
+    def predictor_shapes():
+        from vllm_omni_amd.code_predictor import CodePredictorConfig
+
+        c = CodePredictorConfig()
+        h, d = c.hidden_size, c.head_dim
+        return [("cp.qkv_proj", (c.num_attention_heads + 2 * c.num_key_value_heads) * d, h, c.attention_bias),
+                ("cp.o_proj", h, c.num_attention_heads * d, False), ("cp.gate_up_proj", 2 * c.intermediate_size, h, False),
+                ("cp.down_proj", h, c.intermediate_size, False), ("cp.lm_head", c.vocab_size, h, False)]
+
+    if a.code_predictor:
+        a.tps = "1"
+        a.batches = ",".join(str(x) for m in a.batches.split(",") for x in (int(m), 2 * int(m)))
     for tp in [int(x) for x in a.tps.split(",")]:
         try:
-            shp = shapes(cfg, tp)
+            shp = predictor_shapes() if a.code_predictor else shapes(cfg, tp)
         except ValueError as e:
             print(f"tp={tp}: skipped ({e})")
             continue
