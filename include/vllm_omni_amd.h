@@ -305,7 +305,7 @@ int mi_kv_pack(void* dst, const uint64_t* k_layers, const uint64_t* v_layers, co
  * `Sampler`: penalties -> temperature -> top-k/top-p -> random_sample) for
  * the talker loop; shipped stage config: T 0.9, top_p 0.8, top_k 40,
  * repetition_penalty 1.05 (platforms/rocm/stage_configs/qwen2_5_omni.yaml:51-59).
- * One launch, one workgroup per row, row in LDS (vocab <= 16304):
+ * One launch, one workgroup per row, row in LDS (vocab <= 15744):
  *   v = logits[r, :]; seen tokens: v = v > 0 ? v / rep : v * rep; v /= T
  *   top-k: keep v >= k-th largest (ties kept);  p = softmax(v)
  *   top-p: keep an element while the mass of strictly larger p is < top_p

@@ -9,9 +9,10 @@
 // argmax).  The shipped talker stage samples with T = 0.9, top_p = 0.8, top_k = 40, repetition_penalty =
 // 1.05 (vllm_omni/platforms/rocm/stage_configs/qwen2_5_omni.yaml:51-59).
 //
-// No sort: both cut-offs are found by a search over the order-preserving integer key of the fp32 values — four key
-// bits per block-wide step (15 candidate thresholds counted / summed at once: 8 steps each instead of the 32 of a
-// bit-by-bit bisection; counts by ballot, masses summed by DPP rotations and row swaps) — which is exact for top-k (ties with the k-th value are kept, as upstream's
+// No sort: both cut-offs are found over the order-preserving integer key of the fp32 values — top-k by a radix select
+// (four key bits per step, per-wave LDS histograms); top-p by one wave bisecting the key over the survivors' compacted
+// lists when a top-k has left few of them, else block-wide four bits at a time — which is exact for top-k
+(ties with the k-th value are kept, as upstream's
 // `logits_sort < kth` mask does) and, for top-p, keeps every element tied with the last kept VALUE (upstream
 // breaks such ties by sort position, i.e. arbitrarily).  The draw is the exponential race upstream uses:
 // id = argmax_i p_i / q_i, q_i = -ln(u_i), with u_i from Philox4x32-10 keyed by the request's seed and
@@ -132,7 +133,7 @@ struct BlockReduce {
 template <int DT>
 __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
   scalar_cache_acquire();
-  extern __shared__ float vals[];  // [vocab] then 4 floats + 4 uints + 2 ints (+ pad) + [4][16] words
+  extern __shared__ float vals[];  // [vocab] then 4 floats + 4 uints + 2 ints (+ pad) + [4][16] words + survivor lists
   float* fbuf = vals + p.vocab;
   uint32_t* ubuf = reinterpret_cast<uint32_t*>(fbuf + 4);
   int* ibuf = reinterpret_cast<int*>(ubuf + 4);
@@ -163,22 +164,31 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
     // 2. top-k: key of the k-th largest value, built bit by bit (largest tau with count(key >= tau) >= k)
     const int k = p.top_k ? p.top_k[row] : 0;
     if (k > 0 && k < V) {
-      uint32_t tau = 0;
-      for (int sh = 28; sh >= 0; sh -= 4) {   // digit = the largest d with count(key >= tau | d << sh) >= k (counts fall with d)
-        uint32_t c[15];
-#pragma unroll
-        for (int d = 0; d < 15; ++d) c[d] = 0;
+      // radix select, four key bits per step: a 16-bin histogram (one per wave: LDS atomics) of the keys that share the
+      // digits found so far; the digit is the largest d whose bins d..15 hold the kk-th largest of them
+      uint32_t tau = 0, kk = (uint32_t)k;
+      uint32_t* hist = reinterpret_cast<uint32_t*>(mbuf);   // [4][16]
+      for (int sh = 28; sh >= 0; sh -= 4) {
+        if (tid < 64) hist[tid] = 0u;
+        __syncthreads();
         for (int i = tid; i < V; i += 256) {
           const uint32_t key = fkey(vals[i]);
-#pragma unroll
-          for (int d = 0; d < 15; ++d) c[d] += (uint32_t)__popcll(__ballot(key >= (tau | ((uint32_t)(d + 1) << sh))));
+          if (sh == 28 || (key >> (sh + 4)) == (tau >> (sh + 4))) atomicAdd(&hist[(tid >> 6) * 16 + ((key >> sh) & 15u)], 1u);
         }
-        red.count15(c, reinterpret_cast<uint32_t*>(mbuf));
-        uint32_t dig = 0;
+        __syncthreads();
+        uint32_t above = 0, dig = 0;
 #pragma unroll
-        for (int d = 0; d < 15; ++d)
-          if (c[d] >= (uint32_t)k) dig = d + 1;
+        for (int d = 15; d >= 0; --d) {
+          const uint32_t c = hist[d] + hist[16 + d] + hist[32 + d] + hist[48 + d];
+          if (above + c >= kk) {
+            dig = (uint32_t)d;
+            break;
+          }
+          above += c;
+        }
+        kk -= above;
         tau |= dig << sh;
+        __syncthreads();   // every thread has read the bins before they are zeroed again
       }
       for (int i = tid; i < V; i += 256)
         if (fkey(vals[i]) < tau) vals[i] = -INFINITY;
@@ -200,6 +210,57 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
     const float tp = p.top_p ? p.top_p[row] : 1.f;
     uint32_t cut = 0;
     if (tp < 1.f) {
+      // After a top-k the survivors are few: each wave compacts its own (ballot + prefix count, in index order) into a
+      // 64-entry list, and ONE wave bisects the key over those lists — a compare, a DPP / row-swap sum and a scalar
+      // broadcast per step, no barrier.  More than 64 survivors in some wave (no top-k, or many ties): the block-wide
+      // search below.
+      float* cp = mbuf + 64;                                     // [4][64] probabilities
+      uint32_t* ck = reinterpret_cast<uint32_t*>(cp + 256);      // [4][64] their keys
+      uint32_t* cnt = ck + 256;                                  // [4] survivors per wave
+      const int lane = tid & 63, w = tid >> 6;
+      uint32_t woff = 0;
+      for (int i0 = 0; i0 < V; i0 += 256) {
+        const int i = i0 + tid;
+        const float pr = i < V ? vals[i] * inv : 0.f;
+        const bool on = pr > 0.f;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+          const uint32_t pos = woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (pos < 64u) {
+            cp[w * 64 + pos] = pr;
+            ck[w * 64 + pos] = fkey(pr);
+          }
+        }
+        woff += (uint32_t)__popcll(m);
+      }
+      if (lane == 0) cnt[w] = woff;
+      __syncthreads();
+      const bool small = cnt[0] <= 64u && cnt[1] <= 64u && cnt[2] <= 64u && cnt[3] <= 64u;
+      if (small) {
+        if (w == 0) {
+          float pj[4];
+          uint32_t kj[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool have = (uint32_t)lane < cnt[j];
+            pj[j] = have ? cp[j * 64 + lane] : 0.f;
+            kj[j] = have ? ck[j * 64 + lane] : 0u;
+          }
+          uint32_t lo = 0, hi = 0xffffffffu;   // the smallest key c with mass(key > c) < top_p
+          while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            float mm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm += kj[j] > mid ? pj[j] : 0.f;
+            mm = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, BlockReduce::wave_sum(mm))));
+            if (mm < tp) hi = mid; else lo = mid + 1;
+          }
+          if (lane == 0) ubuf[0] = lo;
+        }
+        __syncthreads();
+        cut = ubuf[0];
+        __syncthreads();
+      } else {
       // the smallest key c with mass(key > c) < top_p, digit by digit: the smallest d whose bucket's LAST key
       // (prefix | d << sh | ones below) satisfies it; d = 15 when none of 0..14 does (the mass above the largest key
       // is 0 < top_p).  The predicate is monotone in c — the masses are sums of non-negative terms in a fixed
@@ -225,6 +286,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
         pre |= dig << sh;
       }
       cut = pre;
+      }
     }
     // 5. exponential race over the survivors
     const uint64_t sd = p.seed[row], off = p.offset[row];
@@ -275,11 +337,11 @@ extern "C" int mi_sample_tokens(int64_t* ids, const void* logits, int32_t num_ro
   if (num_rows == 0) return MI_OK;
   if (!ids || !logits || !temperature || !seed || !offset || num_rows < 0 || vocab <= 0 || row_stride < vocab)
     return MI_ERR_INVALID_ARG;
-  if (vocab > 16304) return MI_ERR_UNSUPPORTED;  // the fp32 row lives in 64 KB of LDS (talker vocabularies: 3072 / 8448)
+  if (vocab > 15744) return MI_ERR_UNSUPPORTED;  // the fp32 row lives in 64 KB of LDS (talker vocabularies: 3072 / 8448)
   if (seen_bitmap && bitmap_words_per_row * 32 < vocab) return MI_ERR_INVALID_ARG;
   SamplerParams p{ids, logits, row_stride, vocab, temperature, top_k, top_p, rep_penalty, seen_bitmap, seen_row,
                   bitmap_words_per_row, update_seen, seed, offset};
-  const size_t lds = (size_t)vocab * 4 + 64 + 256;
+  const size_t lds = (size_t)vocab * 4 + 64 + 256 + 2048 + 16;   // row, scalars, [4][16] words, survivor lists + counts
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(num_rows), block(256);
   switch (logits_dtype) {

@@ -415,7 +415,7 @@ class GPUARModelRunner:
             on_gpu = torch.device(self.device).type == "cuda"
             self._out_codes_cpu = [torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, pin_memory=on_gpu) for _ in range(k)]
             self._out_codes_stage = [torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, device=self.device) for _ in range(k)]
-        if torch.device(self.device).type == "cuda" and self.config.vocab_size <= 16304:
+        if torch.device(self.device).type == "cuda" and self.config.vocab_size <= 15744:
             self.sampling_state = SamplingState(self.max_num_reqs, self.config.vocab_size, self.device, self.seed or 0)
         if self.max_reply_rows:
             self._reply_pool = torch.zeros(self.max_reply_rows, self.config.embedding_size, dtype=self.dtype,
@@ -861,7 +861,7 @@ class GPUARModelRunner:
         states = [self.requests[r] for r in ib.req_ids[:n]]
         if SamplingState.needed([s_.sampling_params for s_ in states]):
             if self.sampling_state is None:
-                raise RuntimeError("non-greedy sampling needs the device sampler (GPU, vocabulary <= 16304): "
+                raise RuntimeError("non-greedy sampling needs the device sampler (GPU, vocabulary <= 15744): "
                                    "there is no host fallback")
             pending = 1 if (self._last_output is not None and not self._last_output.done) else 0
             ids = self.sampling_state.sample(st.logits, states, self.sampled_ids_gpu, drawn_ahead=pending)
