@@ -12,7 +12,7 @@
 // No sort: both cut-offs are found over the order-preserving integer key of the fp32 values — top-k by a radix select
 // (four key bits per step, per-wave LDS histograms); top-p by one wave bisecting the key over the survivors' compacted
 // lists when a top-k has left few of them, else block-wide four bits at a time — which is exact for top-k
-(ties with the k-th value are kept, as upstream's
+// (ties with the k-th value are kept, as upstream's
 // `logits_sort < kth` mask does) and, for top-p, keeps every element tied with the last kept VALUE (upstream
 // breaks such ties by sort position, i.e. arbitrarily).  The draw is the exponential race upstream uses:
 // id = argmax_i p_i / q_i, q_i = -ln(u_i), with u_i from Philox4x32-10 keyed by the request's seed and
