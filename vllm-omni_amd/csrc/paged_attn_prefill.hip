@@ -25,7 +25,10 @@
 //     diagonal evaluate it; the context loop stops at the last position any column may see; tiles
 //     are dispatched longest first over all kv heads;
 //   * head_dim 128 with chunks longer than 16 tokens runs the 32x32x16 formulation further down
-//     (`prefill_mfma32_kernel`): same ring, same DMA, one 32-column tile per wave.
+//     (`prefill_mfma32_kernel`): same ring, same DMA, one 32-column tile per wave;
+//   * a launch too small to fill the chip (the ragged last chunk of a long prompt, a TP shard with one KV head) cuts
+//     every tile's keys into segments — separate workgroups of the same kernels over a key range, normalised fp32
+//     partials + log-sum-exp in a workspace — and `prefill_merge_kernel` combines them (`prefill_plan` decides).
 // FLOPs per layer: 2 * S^2 * d * n_q (causal).  MFMA-bound by design; K/V bytes are read once per
 // (16*NC query tokens x G heads) and served from L2/MALL for any but the first tile of a sequence.
 #include <cstdlib>
