@@ -497,6 +497,16 @@ def main():
                 "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
 
     def measure(tp: int, dp: int, label: str, role: str, eager: bool = False, allreduce: str = "rccl") -> dict:
+        # fault injection for rehearsing the safety net (never set by the driver): "skip:<text>", "raise:<text>",
+        # "hang:<text>" act on the stage whose label contains <text>
+        kind, _, what = os.environ.get("MI_BENCH_INJECT_FAULT", "").partition(":")
+        if kind and what in label:
+            if kind == "skip":
+                raise StageSkipped("injected")
+            if kind == "raise":
+                raise RuntimeError("injected")
+            if kind == "hang":
+                time.sleep(10 ** 6)
         elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal, eager, allreduce)
         ms = elapsed / a.steps * 1e3
         res = {"parallelism": label, "role": role, "tp": tp, "allreduce": allreduce if tp > 1 else "none",
