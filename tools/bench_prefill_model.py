@@ -58,8 +58,8 @@ def main():
         attn_events.append((e0, e1))
         return r
 
-    # MI_PREFILL_STEP_MS=1: wall time of every step.  On this pool a box can be shared: a step that takes 80 ms where its
-    # neighbours take 8 is another tenant's time slice, not this code (seen: every third step, eager and captured alike)
+    # MI_PREFILL_STEP_MS=1: wall time of every step (a step at 80 ms among steps at 8 was the container's CPU quota being
+    # exhausted by torch's intra-op thread pool: profiles/r02_host_threads.md; MI_PREFILL_HOST_TRACE=1 times the host side)
     step_ms = [] if os.environ.get("MI_PREFILL_STEP_MS") else None
 
     def one_prompt(i, instrument=False):
@@ -98,6 +98,46 @@ def main():
         mgr.free(r)
 
     one_prompt(0)                      # warm-up: TunableOp picks, allocator
+    if os.environ.get("MI_PREFILL_HOST_TRACE"):
+        # where does the HOST stall?  perf_counter around every decoder layer and every C-ABI / F.linear call inside it,
+        # garbage-collector runs, and the caching allocator's device-malloc counter; prints the calls over 3 ms
+        import gc
+        import torch.nn.functional as F
+
+        slow = []
+        gc_t = {}
+
+        def gc_cb(phase, info):
+            if phase == "start":
+                gc_t["t"] = time.perf_counter()
+            else:
+                slow.append(("gc gen%d" % info["generation"], (time.perf_counter() - gc_t["t"]) * 1e3))
+        gc.callbacks.append(gc_cb)
+
+        def wrap(owner, name, label):
+            f = getattr(owner, name)
+
+            def g(*x, **k):
+                m0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+                t = time.perf_counter()
+                r = f(*x, **k)
+                d = (time.perf_counter() - t) * 1e3
+                if d > 3.0:
+                    slow.append((label, round(d, 2), "device mallocs +%d" % (torch.cuda.memory_stats().get("num_device_alloc", 0) - m0)))
+                return r
+            setattr(owner, name, g)
+        for n in ("fused_moe", "moe_route", "silu_and_mul", "fused_add_rms_norm", "rms_norm", "paged_attn_prefill",
+                  "rope_neox_and_cache"):
+            if hasattr(ops, n):
+                wrap(ops, n, "ops." + n)
+        wrap(F, "linear", "F.linear")
+        wrap(torch, "empty", "torch.empty")
+        one_prompt(70)
+        one_prompt(71)
+        torch.cuda.synchronize()
+        for x in slow:
+            print("host stall:", x)
+        return
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.iters):

@@ -28,67 +28,95 @@ namespace {
 // T = 512, 32 pairs per expert on average: 190 tiles of 32 for 128 experts = 1.5x the weight bytes).
 
 // ---------------------------------------------------------------- route
+// wave-wide max on the VALU: DPP row rotations inside the 16-lane rows, then the row exchange (common.h).  The
+// `__shfl_xor` form is a ds_bpermute and an lgkmcnt wait per step; the k arg-max rounds of a token are one dependent
+// chain, and with twelve of those per round a token took ~5 us.  max is order-independent: same bits.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {   // lane l of a 16-lane row <- lane (l + N) % 16
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_max_valu(float v) {
+  v = fmaxf(v, row_ror<8>(v));   // fmaxf: a NaN operand loses, as in the first pass over the logits
+  v = fmaxf(v, row_ror<4>(v));
+  v = fmaxf(v, row_ror<2>(v));
+  v = fmaxf(v, row_ror<1>(v));
+  return rows_allreduce_max(v);
+}
+
 template <int DT, int EPL>  // EPL = experts per lane = E / 64
-__global__ __launch_bounds__(256) void moe_route_kernel(const void* __restrict__ logits, int64_t row_stride,
-                                                        int32_t* __restrict__ ids, float* __restrict__ weights,
-                                                        int32_t* __restrict__ counts, int T, int top_k, int norm,
-                                                        int round_dt) {
+__global__ __launch_bounds__(1024) void moe_route_kernel(const void* __restrict__ logits, int64_t row_stride,
+                                                         int32_t* __restrict__ ids, float* __restrict__ weights,
+                                                         int32_t* __restrict__ counts, int T, int top_k, int norm,
+                                                         int round_dt) {
   scalar_cache_acquire();
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
-  float p[EPL];
-  float mx = -INFINITY;
+  // One wave per token, 16 waves per workgroup, a strided loop over tokens.  The per-expert counts are gathered in
+  // LDS and flushed once per workgroup with consecutive lanes on consecutive counters: T * top_k single-lane global
+  // atomics on E addresses (the first version) serialise in L2 — 65536 of them cost 128 us at T = 8192.
+  __shared__ int32_t hist[64 * EPL];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 64 * EPL; e += 1024) hist[e] = 0;
+  __syncthreads();
+  for (int t = blockIdx.x * 16 + wid; t < T; t += gridDim.x * 16) {
+    float p[EPL];
+    float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    const int e = lane + 64 * i;
-    if constexpr (DT == MI_DTYPE_F32) p[i] = reinterpret_cast<const float*>(logits)[t * row_stride + e];
-    else if constexpr (DT == MI_DTYPE_BF16)
-      p[i] = Elem<bf16_tag>::from_bits(reinterpret_cast<const uint16_t*>(logits)[t * row_stride + e]);
-    else p[i] = Elem<f16_tag>::from_bits(reinterpret_cast<const uint16_t*>(logits)[t * row_stride + e]);
-    mx = fmaxf(mx, p[i]);
-  }
-  mx = wave_allreduce_max(mx);
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    p[i] = __expf(p[i] - mx);
-    s += p[i];
-  }
-  s = wave_allreduce_sum(s);
-  const float inv = 1.f / s;
-  float wsum = 0.f, myw = 0.f;
-  int mye = 0;
-  for (int j = 0; j < top_k; ++j) {  // k rounds of wave arg-max, lowest expert id on ties
-    float best = -1.f;
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int i = 0; i < EPL; ++i)
-      if (p[i] > best) { best = p[i]; bi = lane + 64 * i; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    for (int i = 0; i < EPL; ++i) {
+      const int e = lane + 64 * i;
+      if constexpr (DT == MI_DTYPE_F32) p[i] = reinterpret_cast<const float*>(logits)[t * row_stride + e];
+      else if constexpr (DT == MI_DTYPE_BF16)
+        p[i] = Elem<bf16_tag>::from_bits(reinterpret_cast<const uint16_t*>(logits)[t * row_stride + e]);
+      else p[i] = Elem<f16_tag>::from_bits(reinterpret_cast<const uint16_t*>(logits)[t * row_stride + e]);
+      mx = fmaxf(mx, p[i]);
     }
+    mx = wave_max_valu(mx);
+    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < EPL; ++i)
-      if (lane + 64 * i == bi) p[i] = -1.f;  // taken
-    if (bi == 0x7fffffff) {  // NaN logits: no comparison succeeds.  Never let an out-of-range id reach the
-      bi = j;                // counters or the grouping; experts 0..k-1 with weight NaN keep the poison visible
-      best = __builtin_nanf("");
+    for (int i = 0; i < EPL; ++i) {
+      p[i] = __expf(p[i] - mx);
+      s += p[i];
     }
-    const float w = best * inv;
-    wsum += w;
-    if (lane == j) { myw = w; mye = bi; }
+    s = wave_allreduce_sum(s);
+    const float inv = 1.f / s;
+    float wsum = 0.f, myw = 0.f;
+    int mye = 0;
+    for (int j = 0; j < top_k; ++j) {  // k rounds of wave arg-max, lowest expert id on ties
+      // the largest remaining probability, then the lowest expert id that holds it
+      float best = -1.f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) best = p[i] > best ? p[i] : best;   // NaN never wins
+      best = wave_max_valu(best);
+      int bi = 0x7fffffff;
+      if (best >= 0.f) {
+#pragma unroll
+        for (int i = EPL - 1; i >= 0; --i) {
+          const uint64_t m = __ballot(p[i] == best);
+          if (m) bi = __builtin_ctzll(m) + 64 * i;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < EPL; ++i)
+        if (lane + 64 * i == bi) p[i] = -1.f;  // taken
+      if (bi == 0x7fffffff) {  // NaN logits: no comparison succeeds.  Never let an out-of-range id reach the
+        bi = j;                // counters or the grouping; experts 0..k-1 with weight NaN keep the poison visible
+        best = __builtin_nanf("");
+      }
+      const float w = best * inv;
+      wsum += w;
+      if (lane == j) { myw = w; mye = bi; }
+    }
+    if (lane < top_k) {
+      float w = norm ? myw / wsum : myw;
+      if (round_dt == MI_DTYPE_BF16) w = Elem<bf16_tag>::from_bits(Elem<bf16_tag>::to_bits(w));
+      else if (round_dt == MI_DTYPE_F16) w = Elem<f16_tag>::from_bits(Elem<f16_tag>::to_bits(w));
+      ids[t * top_k + lane] = mye;
+      weights[t * top_k + lane] = w;
+      atomicAdd(&hist[mye], 1);
+    }
   }
-  if (lane < top_k) {
-    float w = norm ? myw / wsum : myw;
-    if (round_dt == MI_DTYPE_BF16) w = Elem<bf16_tag>::from_bits(Elem<bf16_tag>::to_bits(w));
-    else if (round_dt == MI_DTYPE_F16) w = Elem<f16_tag>::from_bits(Elem<f16_tag>::to_bits(w));
-    ids[t * top_k + lane] = mye;
-    weights[t * top_k + lane] = w;
-    atomicAdd(&counts[mye], 1);
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * EPL; e += 1024) {
+    const int c = hist[e];
+    if (c) atomicAdd(&counts[e], c);
   }
 }
 
@@ -334,7 +362,9 @@ extern "C" int mi_moe_route(int32_t* topk_ids, float* topk_weights, int32_t* exp
   // (a kernel, not hipMemsetAsync: twenty memset nodes inside the decode hipGraph of the 20-layer talker ended in
   //  "write access to a read-only page" at replay on this stack, while the same graph with 2-3 of them was fine)
   hipLaunchKernelGGL(moe_zero_counts_kernel, dim3(1), dim3(256), 0, s, expert_counts, num_experts);
-  const dim3 grid((num_tokens + 3) / 4), block(256);
+  // tokens per wave: 1 for decode batches (latency), up to 4 for prefill chunks (fewer, fuller count flushes)
+  const int tpw = num_tokens >= 8192 ? 4 : num_tokens >= 1024 ? 2 : 1;
+  const dim3 grid((num_tokens + 16 * tpw - 1) / (16 * tpw)), block(1024);
 #define MI_ROUTE(DT, EPL)                                                                                        \
   hipLaunchKernelGGL((moe_route_kernel<DT, EPL>), grid, block, 0, s, router_logits, logits_row_stride, topk_ids, \
                      topk_weights, expert_counts, num_tokens, top_k, norm_topk_prob, weight_round_dtype)

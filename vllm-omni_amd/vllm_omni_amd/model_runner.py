@@ -269,6 +269,22 @@ class AsyncOmniModelRunnerOutput:
         return self._out
 
 
+def _limit_host_threads() -> None:
+    """One intra-op CPU thread per worker unless the user asked for more — what vLLM does for its GPU workers
+    (``OMP_NUM_THREADS`` defaults to 1 there; the reference's workers inherit it).  The step's host-side tensor work is a
+    few index arrays; with torch's default (one OpenMP thread per visible core: 256 on an MI355X host) every array
+    over the parallel grain wakes the whole pool, the idle threads spin, and a container with a CPU quota is throttled
+    for the rest of the scheduler period.  Measured on a 16-core-quota box: chunked prefill of the MoE talker
+    (8192 tokens in chunks of 2048) 165 ms -> 29 ms, `nr_throttled` 14 -> 0 (profiles/r02_host_threads.md).
+    ``VLLM_OMNI_AMD_HOST_THREADS`` or ``OMP_NUM_THREADS`` override."""
+    want = os.environ.get("VLLM_OMNI_AMD_HOST_THREADS")
+    if want is None and "OMP_NUM_THREADS" in os.environ:
+        return
+    n = max(1, int(want)) if want else 1
+    if torch.get_num_threads() != n:
+        torch.set_num_threads(n)
+
+
 class GPUARModelRunner:
     OUT_SLOTS = 4   # ring of pinned output buffers: a step's hidden-state views live for OUT_SLOTS - 1 more steps
 
@@ -286,6 +302,7 @@ class GPUARModelRunner:
         from .compat import is_vllm_config, worker_config_from_vllm_config
         from .distributed import get_parallel_state
 
+        _limit_host_threads()
         wc = None
         if is_vllm_config(config):
             # ``GPUARModelRunner(self.vllm_config, self.device)`` (gpu_ar_worker.py:102): everything else comes
