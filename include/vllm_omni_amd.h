@@ -394,7 +394,8 @@ int mi_int8_dequant(void* out, const int32_t* acc, const float* x_scale, const f
 
 /* ------------------------------------------------------------------------
  * Decode-batch linear layer: out[m, n] = x[m, k] . weight[n, k]^T (+ bias[n]),
- * m <= 256 — the projections of one decode step (qkv_proj / o_proj /
+ * m <= 512 (two row blocks of 256 above 256) — the projections of one decode
+ * step (qkv_proj / o_proj /
  * gate_up_proj / down_proj of vllm_omni/model_executor/models/qwen2_5_omni/
  * qwen2_5_omni_talker.py, which the reference runs as library GEMMs through
  * vLLM's ColumnParallelLinear / RowParallelLinear).  Weight-streaming kernel:

@@ -22,6 +22,10 @@ SHAPES = [
     (100, 48, 128, False),       # one k block, n smaller than a tile
     (128, 6144, 2048, True),
     (255, 160, 384, True),
+    (512, 4096, 1024, False),    # two row blocks of 256 (grid.y): the code predictor's projections at batch 512
+    (512, 1024, 3072, True),     # ... with split-K
+    (300, 1024, 2048, True),     # ragged second row block
+    (257, 160, 384, False),
 ]
 
 
@@ -74,9 +78,9 @@ def test_linear_deterministic():
 
 def test_linear_rejects_unsupported():
     from vllm_omni_amd import ops
-    x = torch.zeros(300, 256, device="cuda", dtype=torch.bfloat16)
+    x = torch.zeros(600, 256, device="cuda", dtype=torch.bfloat16)
     w = torch.zeros(64, 256, device="cuda", dtype=torch.bfloat16)
-    assert not ops.linear_supported(300, 64, 256, torch.bfloat16)
+    assert not ops.linear_supported(600, 64, 256, torch.bfloat16)
     with pytest.raises(RuntimeError):
         ops.linear(x, w)
     with pytest.raises(RuntimeError):
@@ -109,7 +113,7 @@ def test_row_parallel_linear_routes_deep_projections_to_the_kernel(monkeypatch):
 
 
 @pytest.mark.parametrize("m,inter,k", [(256, 18944, 3584), (256, 1024, 512), (100, 80, 128), (17, 4736, 1024),
-                                        (64, 96, 256), (128, 9472, 3584)])
+                                        (64, 96, 256), (128, 9472, 3584), (512, 3072, 1024), (333, 80, 128)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_linear_silu_mul_matches_unfused_pair(m, inter, k, dtype):
     """gate_up_proj + SiluAndMul in one launch against the same two steps done apart with the rounding the unfused

@@ -817,10 +817,20 @@ int forced_split() {   // MI_LINEAR_SPLIT=<S>: tuning override of the split-K fa
 }
 }  // namespace
 
+namespace {
+// 16-bit plan for up to 512 rows: 257-512 rows run as two row blocks per weight tile (grid.y), with the split halved so
+// the grid still fits one round — the same arrangement as the W8A8 entry points below
+mi::SkinnyPlan linear_plan(int m, int n, int k) {
+  mi::SkinnyPlan pl = mi::skinny_plan(m > 256 ? 256 : m, n, k, forced_split());
+  if (m > 256 && forced_split() <= 0) pl.split = pl.split > 1 ? (pl.split + 1) / 2 : 1;
+  return pl;
+}
+}  // namespace
+
 extern "C" int64_t mi_linear_workspace_bytes(int32_t m, int32_t n, int32_t k) {
   using namespace mi;
   if (m <= 0 || n <= 0 || k <= 0) return 0;
-  const SkinnyPlan pl = skinny_plan(m, n, k, forced_split());
+  const SkinnyPlan pl = linear_plan(m, n, k);
   return pl.split > 1 ? (int64_t)pl.split * m * n * (int64_t)sizeof(float) : 0;
 }
 
@@ -830,10 +840,10 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
   using namespace mi;
   if (m == 0 || n == 0) return MI_OK;
   if (!out || !x || !weight || m < 0 || n < 0 || k <= 0) return MI_ERR_INVALID_ARG;
-  if (m > 256 || k % 64 || n % 16 || x_row_stride % 8 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if (m > 512 || k % 64 || n % 16 || x_row_stride % 8 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
   if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)weight) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
-  const SkinnyPlan pl = skinny_plan(m, n, k, forced_split());
+  const SkinnyPlan pl = linear_plan(m, n, k);
   if (pl.split > 1 && (!workspace || ((uintptr_t)workspace & 15))) return MI_ERR_INVALID_ARG;
   if (pl.split > 1 && workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(float)) return MI_ERR_WORKSPACE;
   SkinnyParams p;
@@ -868,10 +878,10 @@ extern "C" int mi_linear_partials(const void* x, const void* weight, int32_t m, 
                                   int dtype, void* stream) {
   using namespace mi;
   if (!x || !weight || !split_out || m <= 0 || n <= 0 || k <= 0) return MI_ERR_INVALID_ARG;
-  if (m > 256 || k % 64 || n % 16 || x_row_stride % 8) return MI_ERR_UNSUPPORTED;
+  if (m > 512 || k % 64 || n % 16 || x_row_stride % 8) return MI_ERR_UNSUPPORTED;
   if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)weight) & 15) return MI_ERR_INVALID_ARG;
-  const SkinnyPlan pl = skinny_plan(m, n, k, forced_split());
+  const SkinnyPlan pl = linear_plan(m, n, k);
   if (pl.split <= 1) return MI_ERR_UNSUPPORTED;   // nothing to defer: mi_linear writes the output directly
   if (!workspace || ((uintptr_t)workspace & 15)) return MI_ERR_INVALID_ARG;
   if (workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(float)) return MI_ERR_WORKSPACE;
@@ -916,12 +926,12 @@ extern "C" int mi_linear_silu_mul(void* out, const void* x, const void* weight, 
   using namespace mi;
   if (m == 0 || inter == 0) return MI_OK;
   if (!out || !x || !weight || m < 0 || inter < 0 || k <= 0) return MI_ERR_INVALID_ARG;
-  if (m > 256 || k % 64 || inter % 16 || x_row_stride % 8 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if (m > 512 || k % 64 || inter % 16 || x_row_stride % 8 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
   if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)weight) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
   // a tile = 16 NSLAB output columns (gate + up rows of each); no split-K: the activation needs the whole sum
   SkinnyPlan pl;
-  pl.mt = m <= 64 ? 4 : m <= 128 ? 8 : 16;
+  pl.mt = m <= 64 ? 4 : m <= 128 ? 8 : 16;   // 257-512 rows: two row blocks of 16 m-tiles (grid.y)
   const int t80 = (inter + 79) / 80, t64 = (inter + 63) / 64;
   if (t80 > 128 && t80 <= 256) { pl.nslab = 5; pl.tiles = t80; }
   else { pl.nslab = 4; pl.tiles = t64; }

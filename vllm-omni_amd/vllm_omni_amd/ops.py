@@ -368,12 +368,13 @@ _LINEAR_WS_RETIRED: list = []   # outgrown workspaces stay allocated: a captured
 
 
 def linear_supported(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
-    """Shape envelope of ``mi_linear`` (decode batches): rows <= 256, k a multiple of 128, n of 16."""
-    return 0 < m <= 256 and k % 128 == 0 and n % 16 == 0 and dtype in (torch.bfloat16, torch.float16)
+    """Shape envelope of ``mi_linear`` (decode batches): rows <= 512 (two row blocks of 256 above 256), k a multiple
+    of 128, n of 16."""
+    return 0 < m <= 512 and k % 128 == 0 and n % 16 == 0 and dtype in (torch.bfloat16, torch.float16)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x W^T (+ b) for a decode batch (<= 256 rows) by the weight-streaming kernel of csrc/skinny_gemm.hip;
+    """y = x W^T (+ b) for a decode batch (<= 512 rows) by the weight-streaming kernel of csrc/skinny_gemm.hip;
     stands in for the library GEMM behind vLLM's ColumnParallelLinear / RowParallelLinear on the decode path."""
     _gpu(x, weight, bias)
     x2 = x.reshape(-1, x.shape[-1])
