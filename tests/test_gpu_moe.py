@@ -23,12 +23,18 @@ def _weights(cfg, seed, dtype):
     return w
 
 
-@pytest.mark.parametrize("E,k,T,norm", [(128, 8, 40, False), (128, 8, 1, False), (64, 4, 33, True), (256, 2, 7, False)])
+@pytest.mark.parametrize("E,k,T,norm", [(128, 8, 40, False), (128, 8, 1, False), (64, 4, 33, True), (256, 2, 7, False),
+                                        (128, 8, 1500, True),    # two tokens per wave, ragged last workgroup
+                                        (128, 8, 8197, False),   # four tokens per wave (prefill chunk)
+                                        (64, 6, 4099, True), (256, 8, 1027, False)])
 def test_route_matches_oracle(dev, E, k, T, norm):
     from vllm_omni_amd import ops
 
     g = torch.Generator().manual_seed(E + T)
     logits = torch.randn(T, E, generator=g) * 2
+    if T > 1000:   # thousands of rows: keep every row's values >= 0.02 apart, so that no two probabilities can round to
+        # the same fp32 value on one side only (the device's exp is not torch's)
+        logits = (torch.argsort(torch.rand(T, E, generator=g), dim=-1).float() * 0.02 + torch.rand(T, 1, generator=g))
     ids, w, counts = ops.moe_route(logits.to(dev), k, norm)
     p = torch.softmax(logits, -1)
     rw, re = torch.topk(p, k, -1)
@@ -37,6 +43,24 @@ def test_route_matches_oracle(dev, E, k, T, norm):
     assert torch.equal(ids.cpu().long(), re)
     torch.testing.assert_close(w.cpu(), rw, rtol=2e-5, atol=1e-7)
     assert torch.equal(counts.cpu().long(), torch.bincount(re.reshape(-1), minlength=E))
+
+
+def test_route_ties_take_the_lowest_expert_and_counts_add_up(dev):
+    """Logits drawn from four distinct values: every row is full of exact ties.  The kernel's order is descending
+    probability, lowest expert id first among equals (a stable sort); the per-expert counts are the histogram of the ids
+    whatever the number of tokens a workgroup handles."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for T, E, k in [(9, 128, 8), (2050, 128, 8), (8200, 64, 4)]:
+        logits = torch.randint(0, 4, (T, E), generator=g).float()
+        ids, w, counts = ops.moe_route(logits.to(dev), k, False)
+        p = torch.softmax(logits, -1)
+        order = torch.sort(p, dim=-1, descending=True, stable=True).indices[:, :k]
+        assert torch.equal(ids.cpu().long(), order)
+        torch.testing.assert_close(w.cpu(), torch.gather(p, 1, order), rtol=2e-5, atol=1e-7)
+        assert torch.equal(counts.cpu().long(), torch.bincount(order.reshape(-1), minlength=E))
+        assert int(counts.sum()) == T * k
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
