@@ -2,6 +2,8 @@
 head counts and GQA groups, head_dim 64/128, block sizes 16..128, the three cache layouts, both dtypes, ragged
 lengths that straddle block / step / partition boundaries, forced partition sizes, host upper bounds larger than
 the longest sequence.  Complements the hand-picked cases of test_gpu_attention_{decode,prefill}.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,10 @@ from oracle import ref_ops
 from test_gpu_attention_decode import _mk_case, _run, _tol
 
 pytestmark = pytest.mark.gpu
+
+# MI_FUZZ_EXTRA=<n>: n further seeds per test with LONGER geometries (contexts of thousands of tokens, chunks of hundreds)
+# — a sweep to run by hand on a GPU box (`MI_FUZZ_EXTRA=64 pytest tests/test_gpu_attention_fuzz.py`); 0 by default
+_EXTRA = int(os.environ.get("MI_FUZZ_EXTRA", "0"))
 
 
 def _geometry(rng):
@@ -20,18 +26,22 @@ def _geometry(rng):
     return d, nkv, group * nkv, bs
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + list(range(100, 100 + _EXTRA)))
 def test_decode_random_geometry(dev, seed):
     rng = np.random.default_rng(1000 + seed)
     d, nkv, nq, bs = _geometry(rng)
     S = int(rng.integers(1, 6))
     edges = [1, bs - 1, bs, bs + 1, 31, 32, 33, 255, 256, 257, 511, 513]
-    lens = [int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, 700)) for _ in range(S)]
+    hi = 700
+    if seed >= 100:
+        edges += [1023, 1024, 1025, 2047, 2049, 4095, 4097]
+        hi = 6000
+    lens = [int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, hi)) for _ in range(S)]
     dtype = torch.bfloat16 if rng.random() < 0.5 else torch.float16
     layout = str(rng.choice(["nb2", "2nb", "head_major"]))
     kv, kb, vb, table, q, seq_lens = _mk_case(S, nq, nkv, d, bs, lens, dtype, seed=seed, layout=layout)
     ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
-    part = int(rng.choice([0, 0, 32, 64, 128, 256]))
+    part = int(rng.choice([0, 0, 32, 64, 128, 256] + ([512, 1024] if seed >= 100 else [])))
     msl = max(lens) + int(rng.choice([0, 0, 1, 100]))
     for mode in ("exact", "fast"):
         got = _run(dev, kv, layout, table, q, seq_lens, torch.float32, partition_size=part, max_seq_len=msl, mode=mode)
@@ -40,7 +50,7 @@ def test_decode_random_geometry(dev, seed):
                                    msg=lambda m: f"[{mode}] d={d} nq={nq} nkv={nkv} bs={bs} lens={lens} part={part} {layout}: {m}")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", list(range(16)) + list(range(100, 100 + _EXTRA)))
 def test_prefill_random_geometry(dev, seed):
     from vllm_omni_amd import ops
 
@@ -49,6 +59,11 @@ def test_prefill_random_geometry(dev, seed):
     S = int(rng.integers(1, 4))
     ctxs = [int(rng.choice([0, 0, 1, bs - 1, bs, 31, 33, 100])) for _ in range(S)]
     chunks = [int(rng.choice([1, 15, 16, 17, 31, 32, 33, 64, 90])) for _ in range(S)]
+    if seed >= 100:
+        ctxs = [int(rng.choice([0, 1, 127, 128, 129, 511, 1000, 2049, 3000])) if rng.random() < 0.6 else int(rng.integers(0, 3000))
+                for _ in range(S)]
+        chunks = [int(rng.choice([1, 8, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 400])) if rng.random() < 0.6
+                  else int(rng.integers(1, 400)) for _ in range(S)]
     dtype = torch.bfloat16 if rng.random() < 0.5 else torch.float16
     g = torch.Generator().manual_seed(seed)
     lens = [c + q for c, q in zip(ctxs, chunks)]
