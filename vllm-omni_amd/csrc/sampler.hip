@@ -40,10 +40,23 @@ struct SamplerParams {
   const uint64_t* offset;     // [rows] draw counter of the request
 };
 
-// order-preserving map fp32 -> uint32 (larger float <=> larger key; -0 < +0)
+// order-preserving map fp32 -> uint32 (larger float <=> larger key; -0 and +0 share a key: they compare equal, and a
+// top-k whose k-th value is +0 keeps the -0 entries too, as the comparison `logit < kth` upstream does)
 __device__ __forceinline__ uint32_t fkey(float f) {
-  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  uint32_t b = __builtin_bit_cast(uint32_t, f);
+  if ((b << 1) == 0u) b = 0u;
   return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+// -log(u) for u = (n + 0.5) 2^-24, n a 24-bit draw.  n + 0.5 is exact in fp32 only below 2^23; above, work from the
+// complement w = 1 - u = (2^24 - n - 0.5) 2^-24, which is: a series where w is small (the race is decided by the
+// SMALLEST exponentials, i.e. by u next to 1, where log(u) computed from a rounded u is off by tens of percent, and
+// n = 2^24 - 1 gave u = 1, -log = 0 and a candidate that could never win), the library log elsewhere.
+__device__ __forceinline__ float neg_log_u24(uint32_t n) {
+  if (n < (1u << 23)) return -__logf(((float)n + 0.5f) * (1.f / 16777216.f));
+  const float w = ((float)((1u << 24) - n) - 0.5f) * (1.f / 16777216.f);
+  if (w < 0.015625f) return w * (1.f + w * (0.5f + w * ((1.f / 3.f) + w * 0.25f)));
+  return -__logf(1.f - w);
 }
 
 // Philox4x32-10 (Salmon et al., SC'11), first output word
@@ -295,8 +308,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
       if (pr > 0.f && fkey(pr) >= cut) {
         const uint32_t x = philox_first((uint32_t)i, 0u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)sd,
                                         (uint32_t)(sd >> 32));
-        const float u = ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1), 24 bits
-        const float sc = pr / -__logf(u);
+        const float sc = pr / neg_log_u24(x >> 8);   // u in (0, 1), 24 bits
         if (sc > best_s || (sc == best_s && i < best_i)) { best_s = sc; best_i = i; }
       }
     }
