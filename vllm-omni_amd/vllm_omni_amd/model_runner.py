@@ -106,9 +106,10 @@ class SamplingState:
         return any(p.temperature > 0 or p.repetition_penalty != 1.0 for p in params)
 
     def sample(self, logits: torch.Tensor, states: list[CachedRequestState], ids: torch.Tensor,
-               drawn_ahead: int = 0) -> torch.Tensor:
+               drawn_ahead: int = 0, discard: Optional[np.ndarray] = None) -> torch.Tensor:
         """``drawn_ahead``: draws already made for these requests whose tokens are not yet in ``output_token_ids``
-        (an async output still pending on the host)."""
+        (an async output still pending on the host).  ``discard``: rows whose draw will be thrown away (unfinished
+        prompt): it must not enter the request's seen set."""
         n = len(states)
         for i, st in enumerate(states):
             sp = st.sampling_params
@@ -116,7 +117,10 @@ class SamplingState:
             self.top_p.np[i] = sp.top_p
             self.rep.np[i] = sp.repetition_penalty if st.seen_slot >= 0 else 1.0
             self.top_k.np[i] = sp.top_k
-            self.seen_row.np[i] = st.seen_slot if st.seen_slot >= 0 else self.scratch_slot
+            keep = st.seen_slot >= 0 and not (discard is not None and discard[i])
+            self.seen_row.np[i] = st.seen_slot if keep else self.scratch_slot
+            if not keep:
+                self.rep.np[i] = 1.0
             self.seed.np[i] = st.sample_seed
             self.offset.np[i] = len(st.output_token_ids) + drawn_ahead
         return ops.sample_tokens(logits[:n], self.temperature.copy_to_gpu(n), self.seed.copy_to_gpu(n),
@@ -175,6 +179,7 @@ class InputBatch:
         self.req_id_to_index: dict[str, int] = {}
         self.num_computed_tokens_cpu = np.zeros(max_num_reqs, dtype=np.int64)
         self.num_prompt_tokens = np.zeros(max_num_reqs, dtype=np.int64)
+        self.decode_from = np.zeros(max_num_reqs, dtype=np.int64)   # a one-token step at >= this many computed tokens is a decode
         self.last_token_ids_cpu = np.zeros(max_num_reqs, dtype=np.int64)
         self.reply_offset = np.full(max_num_reqs, -1, dtype=np.int64)   # row of the next reply vector, -1 = none
         self.reply_end = np.zeros(max_num_reqs, dtype=np.int64)
@@ -192,7 +197,16 @@ class InputBatch:
         self.req_ids.append(st.req_id)
         self.req_id_to_index[st.req_id] = i
         self.num_computed_tokens_cpu[i] = st.num_computed_tokens
-        self.num_prompt_tokens[i] = len(st.prompt_token_ids)
+        # upstream's length_from_prompt_token_ids_or_embeds: a prompt may come as embeddings only
+        self.num_prompt_tokens[i] = len(st.prompt_token_ids) if st.prompt_token_ids else (
+            int(st.prompt_embeds.shape[0]) if st.prompt_embeds is not None else 0)
+        # A one-token step is a DECODE (input = embedding of the last token, + the thinker's reply row) once the prompt is
+        # behind it.  A prompt given as EMBEDDINGS (every talker prompt the reference builds) must be consumed from the
+        # embeddings to its last row, so the rule is strict; for a token-id prompt the last prompt token alone in a
+        # step goes through the decode path too — same token (`last_token_ids_cpu` starts at prompt[-1]), and what the
+        # synthetic steady-state batches of bench.py / the tests schedule ("everything but this token is cached").
+        self.decode_from[i] = self.num_prompt_tokens[i] if st.prompt_embeds is not None else max(
+            int(self.num_prompt_tokens[i]) - 1, 0)
         last = st.output_token_ids[-1] if st.output_token_ids else (st.prompt_token_ids[-1] if st.prompt_token_ids else 0)
         self.last_token_ids_cpu[i] = last
         self.reply_offset[i] = -1
@@ -210,7 +224,7 @@ class InputBatch:
             moved = self.req_ids[last]
             self.req_ids[i] = moved
             self.req_id_to_index[moved] = i
-            for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.last_token_ids_cpu,
+            for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.decode_from, self.last_token_ids_cpu,
                         self.reply_offset, self.reply_end):
                 arr[i] = arr[last]
             self.block_table.move_row(last, i)
@@ -223,8 +237,8 @@ class InputBatch:
         ra, rb = self.req_ids[a], self.req_ids[b]
         self.req_ids[a], self.req_ids[b] = rb, ra
         self.req_id_to_index[ra], self.req_id_to_index[rb] = b, a
-        for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.last_token_ids_cpu, self.reply_offset,
-                    self.reply_end):
+        for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.decode_from, self.last_token_ids_cpu,
+                    self.reply_offset, self.reply_end):
             arr[[a, b]] = arr[[b, a]]
         self.block_table.swap_row(a, b)
 
@@ -241,6 +255,10 @@ class ExecuteModelState:
     num_tokens: int
     query_start_loc_np: np.ndarray
     kv_extracted_req_ids: Optional[list[str]]
+    num_decodes: int = 0
+    # rows whose prompt is not finished after this step (a chunk of a chunked prefill): their sampled token is
+    # discarded, as upstream's bookkeeping does (`discard_sampled_tokens_req_indices`)
+    partial: Optional[np.ndarray] = None
 
 
 class AsyncOmniModelRunnerOutput:
@@ -548,12 +566,19 @@ class GPUARModelRunner:
         self.input_batch.reply_end[row] = st.reply_base + st.reply_rows
 
     # ----------------------------------------------------------- input preparation
+    def _is_decode(self, num_sched: np.ndarray, n: int) -> np.ndarray:
+        """A decode row: ONE scheduled token and the prompt behind it (``InputBatch.decode_from``).  A one-token row that
+        is still inside its prompt (the tail of a chunked prefill of prompt embeddings, a one-row prompt) is a prefill
+        row: its input is the prompt's embedding at that position, not the last sampled token."""
+        ib = self.input_batch
+        return (num_sched[:n] == 1) & (ib.num_computed_tokens_cpu[:n] >= ib.decode_from[:n])
+
     def _reorder_decodes_first(self, num_sched: np.ndarray) -> np.ndarray:
-        """Stable partition: requests with one scheduled token first (the attention metadata
-        assumes decodes-first, as upstream backends request through ``reorder_batch``)."""
+        """Partition: decode rows first (the attention metadata assumes decodes-first, as upstream backends request
+        through ``reorder_batch``)."""
         ib = self.input_batch
         n = ib.num_reqs
-        is_dec = num_sched[:n] == 1
+        is_dec = self._is_decode(num_sched, n)
         if is_dec.all() or not is_dec.any():
             return num_sched
         i, j = 0, n - 1
@@ -595,7 +620,7 @@ class GPUARModelRunner:
             raise RuntimeError(f"sequence length {max_seq_len} exceeds max_model_len {self.max_model_len}")
         ib.block_table.compute_slot_mapping(req_idx, pos)
         self.logits_indices.np[:n] = qsl[1:n + 1] - 1
-        num_decodes = int((num_sched == 1).sum())
+        num_decodes = int(self._is_decode(num_sched, n).sum())
         return n, total, num_sched, max_seq_len, num_decodes
 
     def _commit_inputs(self, n: int, total: int, padded_reqs: int = 0):
@@ -708,11 +733,13 @@ class GPUARModelRunner:
         logits, ids = self.model.compute_logits_and_greedy(sample_h, self.sampled_ids_gpu[:n])
         return hidden, logits, ids
 
-    def _can_use_graph(self, n: int, total: int) -> bool:
+    def _can_use_graph(self, n: int, total: int, num_decodes: Optional[int] = None) -> bool:
         """Pure-decode batches replay a hipGraph.  With TP > 1 the graph contains the all-reduces (RCCL collectives
         are capturable, probed on this stack with tools/probe_rccl_graph.py; the in-tree two-shot all-reduce is a
         plain kernel launch); VLLM_OMNI_AMD_TP_GRAPH=0 keeps TP > 1 eager."""
         if self.enforce_eager or total != n or torch.device(self.device).type != "cuda":
+            return False
+        if num_decodes is not None and num_decodes != n:   # a one-token row still inside its prompt
             return False
         return self.parallel.tp_size == 1 or os.environ.get("VLLM_OMNI_AMD_TP_GRAPH", "1") == "1"
 
@@ -808,7 +835,7 @@ class GPUARModelRunner:
             self._h2d_done.synchronize()
             self._h2d_pending = False
         n, total, num_sched, max_seq_len, num_decodes = self._prepare_inputs(scheduler_output)
-        use_graph = self._can_use_graph(n, total)
+        use_graph = self._can_use_graph(n, total, num_decodes)
         if use_graph:
             b = self.graph_batch_size(n)
             self._commit_inputs(n, total, b)
@@ -829,8 +856,11 @@ class GPUARModelRunner:
                 self._h2d_pending = True
             md = self._build_metadata(n, total, int(num_sched.max()), max_seq_len, num_decodes)
             hidden, logits, ids = self._forward(n, total, md)
+        ib = self.input_batch
+        partial = (ib.num_computed_tokens_cpu[:n] + num_sched[:n]) < ib.num_prompt_tokens[:n]
         self.execute_model_state = ExecuteModelState(scheduler_output, logits, ids, hidden, n, total,
-                                                     self.query_start_loc.np[:n + 1].copy(), kv_done)
+                                                     self.query_start_loc.np[:n + 1].copy(), kv_done,
+                                                     num_decodes=num_decodes, partial=partial if partial.any() else None)
         return None
 
     def _steady_decode(self, so: SchedulerOutput) -> bool:
@@ -881,7 +911,8 @@ class GPUARModelRunner:
                 raise RuntimeError("non-greedy sampling needs the device sampler (GPU, vocabulary <= 15744): "
                                    "there is no host fallback")
             pending = 1 if (self._last_output is not None and not self._last_output.done) else 0
-            ids = self.sampling_state.sample(st.logits, states, self.sampled_ids_gpu, drawn_ahead=pending)
+            ids = self.sampling_state.sample(st.logits, states, self.sampled_ids_gpu, drawn_ahead=pending,
+                                             discard=st.partial)
         want_hidden = self.engine_output_type != "text"
         slot = self._out_slot
         self._out_slot = (slot + 1) % self.OUT_SLOTS
@@ -890,7 +921,7 @@ class GPUARModelRunner:
         if self.copy_stream is not None:
             cur = torch.cuda.current_stream()
             # feed the drawn ids to the next step's embedding lookup on the device (pure-decode batches)
-            if st.num_tokens == n:
+            if st.num_decodes == n:
                 self.last_token_ids.gpu[:n].copy_(ids[:n])
                 self._ids_on_device_for = tuple(ib.req_ids[:n])
             else:
@@ -930,7 +961,9 @@ class GPUARModelRunner:
         ib = self.input_batch
         # bookkeeping: last token per row feeds the next step's embedding lookup.  Rows are addressed by request
         # id: the batch may have been reordered since the step ran.
-        for rid, tok in zip(out.req_ids, ids_np.tolist()):
+        for i, (rid, tok) in enumerate(zip(out.req_ids, ids_np.tolist())):
+            if st.partial is not None and st.partial[i]:
+                continue   # the prompt is not finished: nothing was generated
             req = self.requests.get(rid)
             if req is not None:
                 req.output_token_ids.append(tok)
@@ -938,6 +971,8 @@ class GPUARModelRunner:
             if row is not None:
                 ib.last_token_ids_cpu[row] = tok
         sampled = ids_np.reshape(n, 1).tolist()
+        if st.partial is not None:
+            sampled = [[] if st.partial[i] else t for i, t in enumerate(sampled)]
         pooler: list[Optional[dict[str, Any]]]
         if self.engine_output_type != "text":
             q = st.query_start_loc_np
@@ -947,7 +982,7 @@ class GPUARModelRunner:
             pooler = [{"hidden": c} for c in torch.split(hidden, np.diff(q).tolist())]
         else:
             pooler = [None] * n
-        if self.code_predictor is not None and st.num_tokens == n:
+        if self.code_predictor is not None and st.num_decodes == n:
             # the codes that produced THIS step's talker input (multimodal output `code_predictor_codes`,
             # qwen3_omni.py:480-494), one row of G codes per decode request
             codes = self._out_codes_cpu[slot][:n]
