@@ -160,8 +160,12 @@ class MI355XCodePredictor:
             return outs
         return self._run(b, layer0_code, layer0_embed, last_talker_hidden, seed, offset, do_sample, return_logits)
 
+    @torch.inference_mode()
     def capture(self, b: int) -> None:
-        """Capture the whole call for batch size ``b`` (device-only work: no host synchronisation inside)."""
+        """Capture the whole call for batch size ``b`` (device-only work: no host synchronisation inside).  Always under
+        ``inference_mode``, like every capture the runner makes: torch creates the generator's graph-state tensors at the
+        first capture of the process, and a capture outside inference mode after one inside it fails on them ("inplace
+        update to inference tensor")."""
         if torch.device(self.device).type != "cuda" or b in self._graphs:
             return
         args = (self._in_code[:b], self._in_embed[:b], self._in_hidden[:b], self._in_seed[:b], self._in_offset[:b])
