@@ -38,7 +38,8 @@ def test_random_schedule_matches_oracle(dev, seed):
     bs, nb, max_reqs, budget = 16, 96, 5, 80
     eager = bool(rng.random() < 0.5)
     runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=max_reqs, max_model_len=192,
-                              max_num_batched_tokens=budget, block_size=bs, enforce_eager=eager, seed=0)
+                              max_num_batched_tokens=budget, block_size=bs, enforce_eager=eager, seed=0,
+                              max_reply_rows=64)
     runner.load_model()
     w = ref_talker.random_weights(cfg, seed=11 + seed)
     runner.model.load_weights({k: v.to(dev) for k, v in w.items()})
@@ -57,6 +58,13 @@ def test_random_schedule_matches_oracle(dev, seed):
             emb = (torch.randn(n, cfg.embedding_size, generator=g) * 0.5).to(torch.bfloat16) if self.use_embeds else None
             toks = torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist()
             self.r = Request(rid, toks, SamplingParams(temperature=0.0), prompt_embeds=emb)
+            # the thinker's reply rows, one added to the input of each decode step until they run out (a request that
+            # sits a step out keeps its cursor); with prompts of embeddings only — the reference's talker flow
+            self.reply = None
+            if self.use_embeds and rng.random() < 0.6:
+                self.reply = (torch.randn(int(rng.integers(1, 5)), cfg.embedding_size, generator=g) * 0.5).to(torch.bfloat16)
+                self.r.additional_information = {"thinker_reply_part": self.reply}
+            self.n_decoded = 0
             self.plen = n
             self.max_new = int(rng.integers(1, 7))
             self.out = []                 # tokens the device generated
@@ -92,7 +100,8 @@ def test_random_schedule_matches_oracle(dev, seed):
             assert blk is not None
             if not q.known:
                 new_reqs.append(NewRequestData(q.r.request_id, q.r.prompt_token_ids, q.r.sampling_params,
-                                               mgr.get_block_ids(q.r.request_id), 0, prompt_embeds=q.r.prompt_embeds))
+                                               mgr.get_block_ids(q.r.request_id), 0, prompt_embeds=q.r.prompt_embeds,
+                                               additional_information=q.r.additional_information))
                 q.known = True
             else:
                 c_ids.append(q.r.request_id)
@@ -126,7 +135,9 @@ def test_random_schedule_matches_oracle(dev, seed):
             table[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
             c = q.computed
             if c >= q.plen:                                          # decode: embedding of the last generated token
-                emb_rows.append(ref_talker.decode_embeds(w, torch.tensor([q.out[-1]]), None, torch.bfloat16))
+                vec = q.reply[q.n_decoded:q.n_decoded + 1] if (q.reply is not None and q.n_decoded < q.reply.shape[0]) else None
+                emb_rows.append(ref_talker.decode_embeds(w, torch.tensor([q.out[-1]]), vec, torch.bfloat16))
+                q.n_decoded += 1
             elif q.use_embeds:
                 emb_rows.append(q.r.prompt_embeds[c:c + n].float())
                 n_one_token_prompt_rows += int(n == 1)

@@ -333,3 +333,89 @@ def test_graph_batch_size_ladder():
     r = GPUARModelRunner(TalkerConfig.from_json("mini_talker"), torch.device("cpu"), max_num_reqs=250, max_model_len=64)
     assert [r.graph_batch_size(n) for n in (1, 2, 3, 4, 5, 8, 9, 64, 249, 250)] == [1, 2, 4, 4, 8, 8, 16, 64, 250, 250]
     assert len({r.graph_batch_size(n) for n in range(1, 251)}) <= 250 // 8 + 4
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_block_manager_random_operations_keep_their_invariants(seed):
+    """Random allocate / grow / finish / KV-hand-off sequences over the C++ pool against a plain-Python model:
+    no block is ever owned twice, block 0 (the null block) is never handed out, a request owns exactly
+    ceil(tokens / block_size) blocks in allocation order, a failed allocation changes nothing, free + owned == pool,
+    blocks of a request whose KV transfer is active survive `free` until `on_kv_extracted`, and freed blocks come back
+    tail first (the order the next allocations see)."""
+    import numpy as np
+
+    from vllm_omni_amd.kv_cache import KVCacheManager
+    from vllm_omni_amd.sched_output import Request, SamplingParams
+
+    rng = np.random.default_rng(seed)
+    bs = int(rng.choice([4, 8, 16]))
+    nb = int(rng.integers(8, 40))
+    mgr = KVCacheManager(nb, bs, track_new_block_ids=True)
+    usable = mgr.block_pool.get_num_free_blocks()
+    assert usable == nb - 1                                   # block 0 is the null block
+    live: dict[str, Request] = {}
+    owned: dict[str, list[int]] = {}                          # the model
+    held: dict[str, Request] = {}                             # freed while their transfer is active
+    nxt = 0
+    for _ in range(400):
+        op = rng.random()
+        if op < 0.45 and (live or nxt == 0) or not live:
+            if rng.random() < 0.4 or not live:                # a new request
+                r = Request(f"r{nxt}", [1], SamplingParams())
+                nxt += 1
+                live[r.request_id], owned[r.request_id] = r, []
+            else:
+                r = live[str(rng.choice(sorted(live)))]
+            n = int(rng.integers(0, 3 * bs))
+            look = int(rng.integers(0, 3)) if rng.random() < 0.2 else 0
+            free_before = mgr.block_pool.get_num_free_blocks()
+            before = list(mgr.get_block_ids(r.request_id)[0])
+            got = mgr.allocate_slots(r, n, num_lookahead_tokens=look)
+            need = max(0, -(-(r.num_computed_tokens + n + look) // bs) - len(before))
+            if got is None:
+                assert need > free_before                                      # only exhaustion fails ...
+                assert list(mgr.get_block_ids(r.request_id)[0]) == before      # ... and leaves everything as it was
+                assert mgr.block_pool.get_num_free_blocks() == free_before
+            else:
+                new = got.get_block_ids()[0]
+                assert len(new) == need and 0 not in new
+                owned[r.request_id] += new
+                assert list(mgr.get_block_ids(r.request_id)[0]) == owned[r.request_id]
+                assert mgr.take_new_block_ids() == new
+                r.num_computed_tokens += n                                     # the step ran
+        elif op < 0.75:
+            rid = str(rng.choice(sorted(live)))
+            r = live.pop(rid)
+            if rng.random() < 0.4:                            # its KV goes to the next stage first
+                info = mgr.mark_request_for_kv_transfer(rid, r.num_computed_tokens)
+                assert info["block_ids"] == owned[rid][: -(-r.num_computed_tokens // bs)]
+                mgr.free(r)
+                assert list(mgr.get_block_ids(rid)[0]) == owned[rid]           # still held
+                held[rid] = r
+            else:
+                free_before = mgr.block_pool.get_num_free_blocks()
+                mgr.free(r)
+                assert mgr.block_pool.get_num_free_blocks() == free_before + len(owned.pop(rid))
+        elif held:
+            rid = str(rng.choice(sorted(held)))
+            held.pop(rid)
+            assert mgr.on_kv_extracted([rid]) == [rid]
+            owned.pop(rid)
+            assert list(mgr.get_block_ids(rid)[0]) == []
+        flat = [b for ids in owned.values() for b in ids]
+        assert len(flat) == len(set(flat)) and 0 not in flat                   # nothing owned twice
+        assert mgr.block_pool.get_num_free_blocks() + len(flat) == usable      # nothing lost
+        assert all(mgr.block_pool.ref_cnt(b) == 1 for b in flat[:8])
+    # tail-first reuse: free one request, the next allocation of as many blocks returns them LAST block first
+    for rid in list(held):
+        mgr.on_kv_extracted([rid])
+        owned.pop(rid)
+    for r in list(live.values()):
+        mgr.free(r)
+        owned.pop(r.request_id)
+    assert mgr.block_pool.get_num_free_blocks() == usable
+    a = Request("tail", [1], SamplingParams())
+    ids = mgr.allocate_slots(a, 3 * bs).get_block_ids()[0]
+    mgr.free(a)
+    drain = mgr.block_pool.get_new_blocks(usable)
+    assert drain[-3:] == list(reversed(ids))
