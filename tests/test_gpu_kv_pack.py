@@ -1,5 +1,6 @@
 """GPU parity: fused KV extract + head slice + pack (mi_kv_pack) vs the oracle — bit-exact bytes."""
 import json
+import os
 import struct
 
 import numpy as np
@@ -34,6 +35,33 @@ def _np(t):
     (torch.float16, (2, 2, 64, 16, [3, 99, -1, 5], 1000, (0, 2))),  # invalid ids dropped, seq_len longer than the rows
 ])
 def test_pack_matches_oracle_bytes(dev, layout, dtype, case):
+    _check_pack(dev, layout, dtype, case)
+
+
+@pytest.mark.parametrize("seed", list(range(6)) + list(range(100, 100 + int(os.environ.get("MI_FUZZ_EXTRA", "0")))))
+def test_pack_random_sweep(dev, seed):
+    """Seeded sweep (more seeds with MI_FUZZ_EXTRA on a GPU box): layer counts, head geometries, block sizes, ragged and
+    over-long seq_len, invalid / repeated block ids, sender-side head slices, every cache layout — bit-exact bytes."""
+    rng = np.random.default_rng(6000 + seed)
+    layout = str(rng.choice(["nb2", "2nb", "head_major"]))
+    dtype = [torch.bfloat16, torch.float16, torch.float32][int(rng.integers(0, 3))]
+    nl, h = int(rng.integers(1, 5)), int(rng.choice([1, 2, 4, 8]))
+    d, bs = int(rng.choice([32, 64, 128])), int(rng.choice([4, 8, 16, 32]))
+    nids = int(rng.integers(1, 9))
+    ids = [int(x) for x in rng.integers(0, 12, size=nids)]
+    if rng.random() < 0.3:
+        ids[int(rng.integers(0, nids))] = int(rng.choice([-1, 12, 99]))          # invalid: dropped
+    seq_len = int(rng.choice([1, bs - 1, bs, bs + 1, nids * bs - 1, nids * bs, nids * bs + 7, 1000]))
+    hs = None
+    if h > 1 and rng.random() < 0.5:                                              # (offset in the shard, number of slices)
+        ns = int(rng.choice([x for x in (2, 4, 8) if h % x == 0]))
+        hs = (int(rng.integers(0, ns)), ns)
+    if not [b for b in ids if 0 <= b < 12]:
+        ids.append(int(rng.integers(0, 12)))                                      # at least one valid block
+    _check_pack(dev, layout, dtype, (nl, h, d, bs, ids, max(seq_len, 1), hs))
+
+
+def _check_pack(dev, layout, dtype, case):
     from vllm_omni_amd import kv_transfer as kt
 
     nl, h, d, bs, ids, seq_len, hs = case
