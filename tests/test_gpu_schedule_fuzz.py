@@ -5,8 +5,10 @@ the pure-decode steps — against the CPU oracle stepping the same schedule on i
 What it pins beyond the scripted steps of test_gpu_talker_step.py: the persistent batch (add / remove / condense /
 decodes-first reorder) over many steps, block tables growing a block at a time, a chunk of a prompt continuing where the
 previous one stopped, a one-token step that is still inside its prompt taking its input from the PROMPT (not from the last
-sampled token), and the bookkeeping rule that an unfinished prompt generates nothing (``sampled_token_ids[i] == []``,
-upstream's discarded samples).
+sampled token), the bookkeeping rule that an unfinished prompt generates nothing (``sampled_token_ids[i] == []``,
+upstream's discarded samples), and preemption: a request that lost its blocks comes back as a RESUMED request with a new
+block list and recomputes its prompt and the tokens it had generated (prefill rows, nothing generated) before it decodes
+again.
 
 Tolerances as in test_gpu_talker_step.py (hidden states rtol / atol 3e-2 after 2 bf16 layers, a lone element to 5e-2), greedy ids wherever the
 oracle's top-2 logit margin exceeds 0.05; the oracle is teacher-forced with the tokens the device drew."""
@@ -65,6 +67,8 @@ def test_random_schedule_matches_oracle(dev, seed):
                 self.reply = (torch.randn(int(rng.integers(1, 5)), cfg.embedding_size, generator=g) * 0.5).to(torch.bfloat16)
                 self.r.additional_information = {"thinker_reply_part": self.reply}
             self.n_decoded = 0
+            self.recompute_until = 0      # preempted and resumed: the tokens it recomputes before it decodes again
+            self.resume = False           # the next time it is scheduled it comes back as a RESUMED request
             self.plen = n
             self.max_new = int(rng.integers(1, 7))
             self.out = []                 # tokens the device generated
@@ -72,7 +76,7 @@ def test_random_schedule_matches_oracle(dev, seed):
             self.known = False            # the runner has seen it
 
     live, finished_last, next_id, steps_with_graph = [], set(), 0, 0
-    n_partial = n_one_token_prompt_rows = n_mixed = 0
+    n_partial = n_one_token_prompt_rows = n_mixed = n_recomputed = 0
     for step in range(int(rng.integers(14, 22))):
         # ---- a random schedule for this step ----
         while len(live) < max_reqs and rng.random() < (0.6 if len(live) < 2 else 0.3):
@@ -80,21 +84,30 @@ def test_random_schedule_matches_oracle(dev, seed):
             next_id += 1
         left = budget
         plan = []
+        # preemption (recompute): a running request loses its blocks and starts over at token 0 when it is scheduled
+        # again, as a resumed request with a new block list; it recomputes prompt + generated tokens before it decodes
         for q in live:
-            if q.computed >= q.plen:
+            if q.known and q.reply is None and q.computed > 0 and not q.resume and rng.random() < 0.06:
+                mgr.free(q.r)
+                q.r.num_computed_tokens = q.computed = 0
+                q.recompute_until = q.plen + len(q.out)
+                q.resume = True
+        for q in live:
+            target = max(q.plen, q.recompute_until)
+            if q.computed >= target:
                 n = 1                                                # decode
             else:
-                rem = q.plen - q.computed
+                rem = target - q.computed
                 n = rem if rng.random() < 0.4 else int(rng.integers(1, rem + 1))
                 if rng.random() < 0.15:
                     n = 1                                            # a one-token chunk inside the prompt
-            if n > left or (q.known is False and rng.random() < 0.2) or rng.random() < 0.1:
+            if n > left or (q.known is False and rng.random() < 0.2) or rng.random() < 0.1 or (q.resume and rng.random() < 0.5):
                 continue                                             # not scheduled this step
             left -= n
             plan.append((q, n))
         if not plan:
             continue
-        new_reqs, c_ids, c_blocks, c_computed, c_nout = [], [], [], [], []
+        new_reqs, c_ids, c_blocks, c_computed, c_nout, resumed = [], [], [], [], [], set()
         for q, n in plan:
             blk = mgr.allocate_slots(q.r, n)
             assert blk is not None
@@ -105,13 +118,18 @@ def test_random_schedule_matches_oracle(dev, seed):
                 q.known = True
             else:
                 c_ids.append(q.r.request_id)
-                c_blocks.append(blk.get_block_ids() if blk.blocks[0] else None)
+                if q.resume:
+                    resumed.add(q.r.request_id)
+                    q.resume = False
+                    c_blocks.append(mgr.get_block_ids(q.r.request_id))            # the whole new list
+                else:
+                    c_blocks.append(blk.get_block_ids() if blk.blocks[0] else None)
                 c_computed.append(q.computed)
                 c_nout.append(len(q.out))
         so = SchedulerOutput(
             scheduled_new_reqs=new_reqs,
-            scheduled_cached_reqs=CachedRequestData(req_ids=c_ids, new_block_ids=c_blocks, num_computed_tokens=c_computed,
-                                                    num_output_tokens=c_nout),
+            scheduled_cached_reqs=CachedRequestData(req_ids=c_ids, resumed_req_ids=resumed, new_block_ids=c_blocks,
+                                                    num_computed_tokens=c_computed, num_output_tokens=c_nout),
             num_scheduled_tokens={q.r.request_id: n for q, n in plan}, total_num_scheduled_tokens=sum(n for _, n in plan),
             finished_req_ids=set(finished_last))
         finished_last = set()
@@ -121,7 +139,8 @@ def test_random_schedule_matches_oracle(dev, seed):
         assert sorted(out.req_ids) == sorted(by_id)
         order = [by_id[rid] for rid in out.req_ids]
         # decode rows first (the runner's reorder), in the runner's order
-        is_dec = [q.computed >= (q.plen if q.use_embeds else max(q.plen - 1, 0)) and n == 1 for q, n in order]
+        is_dec = [n == 1 and q.computed >= (q.plen if q.use_embeds else max(q.plen - 1, 0))
+                  and q.computed + 1 >= q.recompute_until for q, n in order]
         assert is_dec == sorted(is_dec, reverse=True)
         if all(is_dec) and not eager:
             steps_with_graph += 1
@@ -134,15 +153,23 @@ def test_random_schedule_matches_oracle(dev, seed):
             ids = mgr.get_block_ids(q.r.request_id)[0]
             table[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
             c = q.computed
-            if c >= q.plen:                                          # decode: embedding of the last generated token
+            if c >= max(q.plen, q.recompute_until):                  # decode: embedding of the last generated token
                 vec = q.reply[q.n_decoded:q.n_decoded + 1] if (q.reply is not None and q.n_decoded < q.reply.shape[0]) else None
                 emb_rows.append(ref_talker.decode_embeds(w, torch.tensor([q.out[-1]]), vec, torch.bfloat16))
                 q.n_decoded += 1
-            elif q.use_embeds:
-                emb_rows.append(q.r.prompt_embeds[c:c + n].float())
-                n_one_token_prompt_rows += int(n == 1)
-            else:
-                emb_rows.append(ref_talker.decode_embeds(w, torch.tensor(q.r.prompt_token_ids[c:c + n]), None, torch.bfloat16))
+            else:                                                    # prompt rows, then (recomputation) generated tokens
+                a = min(n, max(0, q.plen - c))
+                if a:
+                    if q.use_embeds:
+                        emb_rows.append(q.r.prompt_embeds[c:c + a].float())
+                        n_one_token_prompt_rows += int(n == 1)
+                    else:
+                        emb_rows.append(ref_talker.decode_embeds(w, torch.tensor(q.r.prompt_token_ids[c:c + a]), None, torch.bfloat16))
+                if a < n:
+                    toks = q.out[c + a - q.plen:c + n - q.plen]
+                    assert len(toks) == n - a
+                    emb_rows.append(ref_talker.decode_embeds(w, torch.tensor(toks), None, torch.bfloat16))
+                    n_recomputed += n - a
             pos_rows.append(torch.arange(c, c + n))
             ns.append(n)
         qsl = torch.tensor([0] + list(np.cumsum(ns)), dtype=torch.int32)
@@ -165,7 +192,7 @@ def test_random_schedule_matches_oracle(dev, seed):
         top2 = logits.topk(2, -1).values
         for i, (q, n) in enumerate(order):
             q.computed += n
-            if q.computed < q.plen:                                  # the prompt is not finished: nothing is generated
+            if q.computed < max(q.plen, q.recompute_until):          # prompt (or recomputation) not finished: nothing is generated
                 assert out.sampled_token_ids[i] == [], (seed, step, q.r.request_id)
                 n_partial += 1
                 continue
@@ -185,7 +212,7 @@ def test_random_schedule_matches_oracle(dev, seed):
                 mgr.free(q.r)
     # the schedule exercised what the test is about (deterministic per seed; checked over the default seeds together below)
     test_random_schedule_matches_oracle.stats = getattr(test_random_schedule_matches_oracle, "stats", [])
-    test_random_schedule_matches_oracle.stats.append((n_partial, n_one_token_prompt_rows, n_mixed, steps_with_graph))
+    test_random_schedule_matches_oracle.stats.append((n_partial, n_one_token_prompt_rows, n_mixed, steps_with_graph, n_recomputed))
 
 
 def test_schedules_covered_the_cases():
@@ -194,3 +221,5 @@ def test_schedules_covered_the_cases():
         pytest.skip("runs after test_random_schedule_matches_oracle")
     tot = np.asarray(stats).sum(0)
     assert tot[0] > 0 and tot[1] > 0 and tot[2] > 0, f"partial chunks / one-token prompt rows / mixed steps: {tot}"
+    if len(stats) >= 20:
+        assert tot[4] > 0, "no schedule recomputed generated tokens after a preemption"

@@ -53,6 +53,7 @@ class CachedRequestState:
     reply_base: int = -1                                  # first row of the request's thinker_reply_part in the device pool
     reply_rows: int = 0                                   # rows it owns there
     reply_cursor: int = 0                                 # rows consumed so far (the reference's `q[1:]` queue, qwen2_5_omni.py:771-774)
+    recompute_until: int = 0                              # resumed after a preemption: tokens to recompute before it decodes again
 
     @property
     def num_tokens(self) -> int:
@@ -180,6 +181,9 @@ class InputBatch:
         self.num_computed_tokens_cpu = np.zeros(max_num_reqs, dtype=np.int64)
         self.num_prompt_tokens = np.zeros(max_num_reqs, dtype=np.int64)
         self.decode_from = np.zeros(max_num_reqs, dtype=np.int64)   # a one-token step at >= this many computed tokens is a decode
+        # a request resumed after a preemption recomputes the tokens it already has: prefill rows, nothing generated,
+        # until it has this many computed tokens again (0 = not recomputing)
+        self.recompute_until = np.zeros(max_num_reqs, dtype=np.int64)
         self.last_token_ids_cpu = np.zeros(max_num_reqs, dtype=np.int64)
         self.reply_offset = np.full(max_num_reqs, -1, dtype=np.int64)   # row of the next reply vector, -1 = none
         self.reply_end = np.zeros(max_num_reqs, dtype=np.int64)
@@ -207,6 +211,7 @@ class InputBatch:
         # synthetic steady-state batches of bench.py / the tests schedule ("everything but this token is cached").
         self.decode_from[i] = self.num_prompt_tokens[i] if st.prompt_embeds is not None else max(
             int(self.num_prompt_tokens[i]) - 1, 0)
+        self.recompute_until[i] = st.recompute_until
         last = st.output_token_ids[-1] if st.output_token_ids else (st.prompt_token_ids[-1] if st.prompt_token_ids else 0)
         self.last_token_ids_cpu[i] = last
         self.reply_offset[i] = -1
@@ -224,8 +229,8 @@ class InputBatch:
             moved = self.req_ids[last]
             self.req_ids[i] = moved
             self.req_id_to_index[moved] = i
-            for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.decode_from, self.last_token_ids_cpu,
-                        self.reply_offset, self.reply_end):
+            for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.decode_from, self.recompute_until,
+                        self.last_token_ids_cpu, self.reply_offset, self.reply_end):
                 arr[i] = arr[last]
             self.block_table.move_row(last, i)
         self.block_table.clear_row(last)
@@ -237,8 +242,8 @@ class InputBatch:
         ra, rb = self.req_ids[a], self.req_ids[b]
         self.req_ids[a], self.req_ids[b] = rb, ra
         self.req_id_to_index[ra], self.req_id_to_index[rb] = b, a
-        for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.decode_from, self.last_token_ids_cpu,
-                    self.reply_offset, self.reply_end):
+        for arr in (self.num_computed_tokens_cpu, self.num_prompt_tokens, self.decode_from, self.recompute_until,
+                    self.last_token_ids_cpu, self.reply_offset, self.reply_end):
             arr[[a, b]] = arr[[b, a]]
         self.block_table.swap_row(a, b)
 
@@ -536,6 +541,8 @@ class GPUARModelRunner:
             else:
                 assert new_ids is not None
                 st.block_ids = tuple(list(b) for b in new_ids)
+                plen = len(st.prompt_token_ids) or (int(st.prompt_embeds.shape[0]) if st.prompt_embeds is not None else 0)
+                st.recompute_until = plen + len(st.output_token_ids)
             idx = ib.req_id_to_index.get(rid)
             if idx is None:
                 to_add.append(st)
@@ -569,9 +576,12 @@ class GPUARModelRunner:
     def _is_decode(self, num_sched: np.ndarray, n: int) -> np.ndarray:
         """A decode row: ONE scheduled token and the prompt behind it (``InputBatch.decode_from``).  A one-token row that
         is still inside its prompt (the tail of a chunked prefill of prompt embeddings, a one-row prompt) is a prefill
-        row: its input is the prompt's embedding at that position, not the last sampled token."""
+        row: its input is the prompt's embedding at that position, not the last sampled token.
+        A request that recomputes after a preemption is a prefill row until it is back at the frontier of the tokens it
+        already has (``recompute_until``): its inputs are those tokens, not the last one."""
         ib = self.input_batch
-        return (num_sched[:n] == 1) & (ib.num_computed_tokens_cpu[:n] >= ib.decode_from[:n])
+        computed = ib.num_computed_tokens_cpu[:n]
+        return (num_sched[:n] == 1) & (computed >= ib.decode_from[:n]) & (computed + 1 >= ib.recompute_until[:n])
 
     def _reorder_decodes_first(self, num_sched: np.ndarray) -> np.ndarray:
         """Partition: decode rows first (the attention metadata assumes decodes-first, as upstream backends request
@@ -674,7 +684,13 @@ class GPUARModelRunner:
             k = int(num_sched[i])
             c = int(ib.num_computed_tokens_cpu[i])
             if st.prompt_embeds is not None:
-                self.inputs_embeds[t0:t0 + k].copy_(st.prompt_embeds[c:c + k].to(self.dtype), non_blocking=True)
+                pl = int(st.prompt_embeds.shape[0])
+                a = min(k, max(0, pl - c))
+                if a:
+                    self.inputs_embeds[t0:t0 + a].copy_(st.prompt_embeds[c:c + a].to(self.dtype), non_blocking=True)
+                if a < k:   # recomputation after a preemption runs over tokens the request generated: their embeddings
+                    ids = torch.as_tensor(st.output_token_ids[c + a - pl:c + k - pl], dtype=torch.int64)
+                    self.inputs_embeds[t0 + a:t0 + k] = self.model.embed_input_ids(ids.to(self.device))
             else:
                 ids = torch.as_tensor((st.prompt_token_ids + st.output_token_ids)[c:c + k], dtype=torch.int64)
                 self.inputs_embeds[t0:t0 + k] = self.model.embed_input_ids(ids.to(self.device))
@@ -857,7 +873,10 @@ class GPUARModelRunner:
             md = self._build_metadata(n, total, int(num_sched.max()), max_seq_len, num_decodes)
             hidden, logits, ids = self._forward(n, total, md)
         ib = self.input_batch
-        partial = (ib.num_computed_tokens_cpu[:n] + num_sched[:n]) < ib.num_prompt_tokens[:n]
+        # (a request recomputing after a preemption is partial until it is back at its frontier, prompt + the tokens it
+        #  had generated — upstream's `seq_len < req_state.num_tokens`)
+        partial = (ib.num_computed_tokens_cpu[:n] + num_sched[:n]) < np.maximum(ib.num_prompt_tokens[:n],
+                                                                                ib.recompute_until[:n])
         self.execute_model_state = ExecuteModelState(scheduler_output, logits, ids, hidden, n, total,
                                                      self.query_start_loc.np[:n + 1].copy(), kv_done,
                                                      num_decodes=num_decodes, partial=partial if partial.any() else None)
