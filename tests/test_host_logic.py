@@ -326,6 +326,40 @@ def test_reply_cursor_survives_unscheduling_and_live_rows_are_never_overwritten(
     assert r.requests["c"].reply_base == 3 and r._reply_alloc.num_free == 8 - 3 - 2
 
 
+def test_cached_request_update_replaces_the_reply_queue():
+    """`scheduled_cached_reqs.additional_information[rid]` (gpu_model_runner.py:1100-1116): a key's new value replaces
+    the old one.  For the thinker's reply queue (async chunks arriving while the talker decodes) the request's segment of
+    the device pool is swapped for the new rows: old rows freed, cursor back at the first new row."""
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SamplingParams, SchedulerOutput
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_talker")
+    r = GPUARModelRunner(cfg, torch.device("cpu"), torch.bfloat16, max_num_reqs=4, max_model_len=64,
+                         max_num_batched_tokens=16, block_size=16, enforce_eager=True, max_reply_rows=12)
+    r._reply_pool = torch.zeros(12, cfg.embedding_size, dtype=torch.bfloat16)
+    new = [NewRequestData(n, [1, 2, 3], SamplingParams(), ([1 + i],), 3,
+                          additional_information={"thinker_reply_part": torch.full((3, cfg.embedding_size), float(i + 1))})
+           for i, n in enumerate(("a", "b"))]
+    r._update_states(SchedulerOutput(scheduled_new_reqs=new, num_scheduled_tokens={"a": 1, "b": 1}, total_num_scheduled_tokens=2))
+    ib = r.input_batch
+    ib.reply_offset[:2] += 2                                                   # two decode steps consumed two rows each
+    cached = CachedRequestData(req_ids=["a", "b"], new_block_ids=[None, None], num_computed_tokens=[5, 5], num_output_tokens=[2, 2],
+                               additional_information={"a": {"thinker_reply_part": torch.full((4, cfg.embedding_size), 9.0),
+                                                             "other": 7},
+                                                       "gone": {"thinker_reply_part": torch.ones(1, cfg.embedding_size)}})
+    r._update_states(SchedulerOutput(scheduled_cached_reqs=cached, num_scheduled_tokens={"a": 1, "b": 1}, total_num_scheduled_tokens=2))
+    a = r.requests["a"]
+    row_a, row_b = ib.req_id_to_index["a"], ib.req_id_to_index["b"]
+    assert a.reply_rows == 4 and a.reply_cursor == 0 and a.additional_information["other"] == 7
+    assert int(ib.reply_offset[row_a]) == a.reply_base and int(ib.reply_end[row_a]) == a.reply_base + 4
+    assert float(r._reply_pool[a.reply_base, 0]) == 9.0 and float(r._reply_pool[a.reply_base + 3, 0]) == 9.0
+    b = r.requests["b"]
+    assert (int(ib.reply_offset[row_b]), int(ib.reply_end[row_b])) == (b.reply_base + 2, b.reply_base + 3)   # untouched
+    assert float(r._reply_pool[b.reply_base, 0]) == 2.0
+    assert r._reply_alloc.num_free == 12 - 4 - 3                                # a's old three rows went back to the pool
+
+
 def test_graph_batch_size_ladder():
     from vllm_omni_amd.model_runner import GPUARModelRunner
     from vllm_omni_amd.talker import TalkerConfig

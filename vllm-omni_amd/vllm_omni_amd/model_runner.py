@@ -553,6 +553,23 @@ class GPUARModelRunner:
         for st in to_add:
             i = ib.add_request(st)
             self._register_reply_part(st, i)
+        # per-request updates riding on the cached requests (`scheduled_cached_reqs.additional_information`,
+        # gpu_model_runner.py:1100-1116 -> `_update_intermediate_buffer`: a key's new value REPLACES the old one).  The
+        # one key the talker's decode step consumes is the thinker's reply queue (async chunks: the thinker is still
+        # generating while the talker decodes): the request's device segment is swapped for the new rows.
+        for rid, upd in (cached.additional_information or {}).items():
+            st = self.requests.get(rid)
+            if st is None or not isinstance(upd, dict) or not upd:
+                continue
+            st.additional_information = dict(st.additional_information or {}, **upd)
+            if "thinker_reply_part" in upd:
+                if st.reply_base >= 0:
+                    self._reply_alloc.release(st.reply_base, st.reply_rows)
+                st.reply_base, st.reply_rows, st.reply_cursor = -1, 0, 0
+                row = ib.req_id_to_index.get(rid)
+                if row is not None:
+                    ib.reply_offset[row], ib.reply_end[row] = -1, 0
+                    self._register_reply_part(st, row)
 
     def _register_reply_part(self, st: CachedRequestState, row: int) -> None:
         """Move a request's ``thinker_reply_part`` rows (one consumed per decode step) into the device-resident
