@@ -223,7 +223,8 @@ def normalize_scheduler_output(so: Any) -> SchedulerOutput:
         req_ids=req_ids, resumed_req_ids=set(resumed), new_token_ids=list(_get(c, "new_token_ids", []) or []),
         new_block_ids=nbi or [None] * len(req_ids), num_computed_tokens=list(_get(c, "num_computed_tokens", []) or []),
         num_output_tokens=list(_get(c, "num_output_tokens", []) or []),
-        additional_information=dict(_get(c, "additional_information", {}) or {}))
+        additional_information={rid: deserialize_additional_information(v)
+                                for rid, v in dict(_get(c, "additional_information", {}) or {}).items()})
     nst = dict(_get(so, "num_scheduled_tokens", {}) or {})
     return SchedulerOutput(
         scheduled_new_reqs=new, scheduled_cached_reqs=cached, num_scheduled_tokens=nst,
