@@ -135,15 +135,19 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
   __shared__ int32_t start[257];   // padded row offset of every expert
   __shared__ int32_t cursor[256];
   const int tid = threadIdx.x;
+  // padded row offset of every expert: the loads and the roundings in parallel, the short running sum by one thread
+  if (tid < E) cursor[tid] = (counts[tid] + rpt - 1) / rpt * rpt;
+  __syncthreads();
   if (tid == 0) {
     int acc = 0;
     for (int e = 0; e < E; ++e) {
       start[e] = acc;
-      acc += (counts[e] + rpt - 1) / rpt * rpt;
+      acc += cursor[e];
     }
     start[E] = acc;
     num_tiles[0] = acc / rpt;
   }
+  __syncthreads();
   for (int e = tid; e < E; e += 1024) cursor[e] = 0;
   __syncthreads();
   const int total = start[E];
@@ -151,13 +155,29 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
   for (int e = tid; e < E; e += 1024)
     for (int r = start[e]; r < start[e + 1]; r += rpt) tile_expert[r / rpt] = e;
   __syncthreads();
-  for (int i = tid; i < num_pairs; i += 1024) {
-    const int e = ids[i];
-    if (e < 0 || e >= E) { row_of_pair[i] = 0; continue; }   // caller-supplied routing out of range: row 0, never OOB
-    const int r = start[e] + atomicAdd(&cursor[e], 1);
-    if (r >= start[e + 1] || r >= max_rows) { row_of_pair[i] = 0; continue; }   // counts disagree with ids
-    sorted_pairs[r] = i;
-    row_of_pair[i] = r;
+  // four pairs per thread and trip: the id loads, the LDS atomics and the scattered stores of the four are independent,
+  // so their latencies overlap (one pair per trip was 64 dependent round trips at 8192 tokens x top-8: 45-66 us)
+  for (int i0 = tid; i0 < num_pairs; i0 += 4096) {
+    int e[4], r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 1024 * u;
+      e[u] = i < num_pairs ? ids[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = e[u] >= 0 && e[u] < E;   // caller-supplied routing out of range: row 0, never OOB
+      r[u] = ok ? start[e[u]] + atomicAdd(&cursor[e[u]], 1) : -1;
+      if (ok && (r[u] >= start[e[u] + 1] || r[u] >= max_rows)) r[u] = -1;   // counts disagree with ids
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 1024 * u;
+      if (i < num_pairs) {
+        if (r[u] >= 0) sorted_pairs[r[u]] = i;
+        row_of_pair[i] = r[u] >= 0 ? r[u] : 0;
+      }
+    }
   }
 }
 
