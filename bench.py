@@ -296,8 +296,10 @@ def validate_in_tree_allreduce(dev, rows: int, cols: int) -> None:
         with torch.cuda.stream(s):
             ar.all_reduce(buf, out)
         torch.cuda.current_stream().wait_stream(s)
+        from vllm_omni_amd.model_runner import no_gc_during_capture
+
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        with no_gc_during_capture(), torch.cuda.graph(gr):
             ar.all_reduce(buf, out)
         for _ in range(3):
             x = torch.randn(rows, cols, device=dev, generator=g).to(torch.bfloat16)

@@ -175,8 +175,10 @@ class MI355XCodePredictor:
             self._run(b, *args, True, False)      # warm-up: library handles, workspaces
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        from .model_runner import no_gc_during_capture
+
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with no_gc_during_capture(), torch.cuda.graph(graph):
             outs = self._run(b, *args, True, False)
         self._graphs[b] = (graph, outs)
 

@@ -292,6 +292,28 @@ class AsyncOmniModelRunnerOutput:
         return self._out
 
 
+class no_gc_during_capture:
+    """The cyclic garbage collector must not run while a stream is capturing: collecting a dead tensor / graph / event
+    there issues HIP calls that are illegal during capture and the process aborts (seen: "Fatal Python error: Aborted
+    ... Garbage-collecting" inside a capture, after many runners had lived in one process).  Collect first, then keep the
+    collector off until the capture has ended — what upstream does around its own captures."""
+
+    def __enter__(self):
+        import gc
+
+        self._was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+
+        if self._was_enabled:
+            gc.enable()
+        return False
+
+
 def _limit_host_threads() -> None:
     """One intra-op CPU thread per worker unless the user asked for more — what vLLM does for its GPU workers
     (``OMP_NUM_THREADS`` defaults to 1 there; the reference's workers inherit it).  The step's host-side tensor work is a
@@ -821,8 +843,8 @@ class GPUARModelRunner:
         # thread_local: another thread's HIP calls (the RCCL watchdog polling events) must not invalidate
         # the capture.  A capture that does fail leaves a sticky HIP error behind, so it is not caught:
         # failing loudly beats limping on (VLLM_OMNI_AMD_TP_GRAPH=0 / enforce_eager avoid capture).
-        with torch.cuda.graph(g, pool=self._graph_pool,
-                              capture_error_mode="thread_local" if self.parallel.tp_size > 1 else "global"):
+        with no_gc_during_capture(), torch.cuda.graph(
+                g, pool=self._graph_pool, capture_error_mode="thread_local" if self.parallel.tp_size > 1 else "global"):
             self._decode_embeds(n)
             hidden, logits, ids = self._forward(n, n, md)
         if self.parallel.tp_size > 1:
