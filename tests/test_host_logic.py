@@ -453,3 +453,47 @@ def test_block_manager_random_operations_keep_their_invariants(seed):
     mgr.free(a)
     drain = mgr.block_pool.get_new_blocks(usable)
     assert drain[-3:] == list(reversed(ids))
+
+
+def test_decode_rows_are_one_token_steps_behind_the_prompt():
+    """Which rows of a step are DECODES (input = last token, decode kernel, graph replay) — `_prepare_inputs` on the
+    host: a one-token step inside a prompt of EMBEDDINGS is a prefill row; for a token-id prompt the last prompt token
+    alone counts as a decode (same token); a request resumed after a preemption is a prefill row until it is back at the
+    frontier of the tokens it has; decodes are moved to the front of the batch."""
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.sched_output import CachedRequestData, NewRequestData, SamplingParams, SchedulerOutput
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_talker")
+    r = GPUARModelRunner(cfg, torch.device("cpu"), torch.bfloat16, max_num_reqs=8, max_model_len=64,
+                         max_num_batched_tokens=32, block_size=16, enforce_eager=True)
+    emb = torch.zeros(5, cfg.embedding_size)
+    new = [
+        NewRequestData("emb_mid", [1] * 5, SamplingParams(), ([1],), 2, prompt_embeds=emb),     # 1 token at 2 of 5: prefill
+        NewRequestData("emb_last", [1] * 5, SamplingParams(), ([2],), 4, prompt_embeds=emb),    # the LAST prompt row: prefill
+        NewRequestData("emb_done", [1] * 5, SamplingParams(), ([3],), 5, prompt_embeds=emb),    # behind the prompt: decode
+        NewRequestData("tok_mid", [1] * 5, SamplingParams(), ([4],), 2),                        # inside a token prompt: prefill
+        NewRequestData("tok_last", [1] * 5, SamplingParams(), ([5],), 4),                       # last prompt token alone: decode
+        NewRequestData("chunk", [1] * 9, SamplingParams(), ([6],), 0),                          # a 4-token chunk
+    ]
+    sched = {"emb_mid": 1, "emb_last": 1, "emb_done": 1, "tok_mid": 1, "tok_last": 1, "chunk": 4}
+    so = SchedulerOutput(scheduled_new_reqs=new, num_scheduled_tokens=sched, total_num_scheduled_tokens=9)
+    r._update_states(so)
+    n, total, num_sched, max_seq_len, num_decodes = r._prepare_inputs(so)
+    ib = r.input_batch
+    assert (n, total, num_decodes) == (6, 9, 2)
+    assert sorted(ib.req_ids[:2]) == ["emb_done", "tok_last"]                  # decodes first
+    assert sorted(ib.req_ids[2:]) == ["chunk", "emb_last", "emb_mid", "tok_mid"]
+    assert not r._can_use_graph(5, 5, 2)                                       # one-token rows, but not all decodes
+
+    # a resumed request recomputes: one-token steps behind its prompt are prefill rows until the frontier
+    st = r.requests["emb_done"]
+    st.output_token_ids += [7, 8, 9]                                           # it had generated three tokens (frontier 8)
+    cached = CachedRequestData(req_ids=["emb_done"], resumed_req_ids={"emb_done"}, new_block_ids=[([7],)],
+                               num_computed_tokens=[6], num_output_tokens=[3])
+    so = SchedulerOutput(scheduled_cached_reqs=cached, num_scheduled_tokens={"emb_done": 1}, total_num_scheduled_tokens=1)
+    r._update_states(so)
+    assert r._prepare_inputs(so)[4] == 0 and st.recompute_until == 8           # position 6 of 8: still recomputing
+    cached.resumed_req_ids, cached.new_block_ids, cached.num_computed_tokens = set(), [None], [7]
+    r._update_states(so)
+    assert r._prepare_inputs(so)[4] == 1                                       # the last known token: a decode again
