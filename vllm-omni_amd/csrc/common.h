@@ -149,7 +149,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // metadata (seq_lens, block tables, slot mapping, token ids) into SCALAR loads; those buffers are
 // rewritten by host->device copies between launches, and on this stack (gfx950, ROCm 7.x) the scalar
 // data cache was observed to serve stale lines across launches (prefill read a recycled address's
-// old block id: tools/debug_prefill.py).  s_dcache_inv is asynchronous, hence the lgkmcnt wait.
+// old block id: tests/debug/debug_prefill.py).  s_dcache_inv is asynchronous, hence the lgkmcnt wait.
 __device__ __forceinline__ void scalar_cache_acquire() {
   asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
