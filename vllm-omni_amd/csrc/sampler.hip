@@ -53,10 +53,13 @@ __device__ __forceinline__ uint32_t fkey(float f) {
 // SMALLEST exponentials, i.e. by u next to 1, where log(u) computed from a rounded u is off by tens of percent, and
 // n = 2^24 - 1 gave u = 1, -log = 0 and a candidate that could never win), the library log elsewhere.
 __device__ __forceinline__ float neg_log_u24(uint32_t n) {
-  if (n < (1u << 23)) return -__logf(((float)n + 0.5f) * (1.f / 16777216.f));
+  // one log per draw and no divergent branch: both forms of u are exact in fp32 on their half of the range, the series
+  // (four fused multiply-adds) is selected where w < 2^-6
+  const bool hi = n >= (1u << 23);
   const float w = ((float)((1u << 24) - n) - 0.5f) * (1.f / 16777216.f);
-  if (w < 0.015625f) return w * (1.f + w * (0.5f + w * ((1.f / 3.f) + w * 0.25f)));
-  return -__logf(1.f - w);
+  const float u = hi ? 1.f - w : ((float)n + 0.5f) * (1.f / 16777216.f);
+  const float series = w * (1.f + w * (0.5f + w * ((1.f / 3.f) + w * 0.25f)));
+  return (hi && w < 0.015625f) ? series : -__logf(u);
 }
 
 // Philox4x32-10 (Salmon et al., SC'11), first output word
