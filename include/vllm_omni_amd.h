@@ -123,16 +123,21 @@ int mi_rope_neox_and_cache_splitk(void* q_out, const void* partials, int32_t spl
  * on seq_lens[] that sizes the grid, so the launch is graph-replayable while
  * sequences grow.  seq_lens[s] == 0 writes zeros.
  * out_dtype: MI_DTYPE_F32 is accepted for parity measurement.
- * flags: MI_DECODE_PACKED_PV allows the (unnormalised) probabilities to be rounded to
- * the cache dtype before P.V (what flash-style kernels, incl. the reference's
- * TRITON_ATTN backend, do).  That selects the matrix-core kernel where it is built
- * (head_dim 128, block_size >= 16, partition a multiple of 32) and the dot2 form of
- * the VALU kernel elsewhere; without the flag P stays fp32 (VALU kernel, exact mode).
- * MI_DECODE_FORCE_VALU keeps the VALU kernel even with PACKED_PV (A/B measurements).
+ * flags: MI_DECODE_PACKED_PV lets P.V run on 16-bit operands.  That selects the matrix-core
+ * kernel where it is built (head_dim 64/128, block_size >= 16, partition a multiple of 32),
+ * which carries each (unnormalised, fp32) probability as a hi + lo PAIR of cache-dtype values
+ * (16 / 22 significant bits for bf16 / f16) and so stays within rtol 1e-3 / atol 1e-4 of the
+ * fp32 oracle; elsewhere the VALU kernel with P in fp32 (what a call without the flag always
+ * gets).
+ * MI_DECODE_FORCE_VALU | MI_DECODE_PACKED_PV: the dot2 form of the VALU kernel, which rounds P
+ * once to the cache dtype (A/B measurements only).
+ * MI_DECODE_ROUNDED_P: matrix-core kernel with P rounded ONCE to the cache dtype (the flash-style
+ * `dot(P.to(V.dtype), V)`; 2^-9 / 2^-12 relative per term) — A/B measurements only.
  * ---------------------------------------------------------------------- */
 #define MI_DECODE_PACKED_PV 1
 #define MI_DECODE_FORCE_VALU 2
 #define MI_DECODE_NONTEMPORAL 4 /* nt cache policy on the K/V stream (matrix-core kernel) */
+#define MI_DECODE_ROUNDED_P 8
 int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
                                              int32_t head_dim, int32_t max_seq_len,
                                              int32_t partition_size);

@@ -2,10 +2,12 @@
 
 Tolerances (north_star: "fp16/bf16 logits within 1e-3 rtol"): the kernel is asked for an
 fp32 output so accumulation accuracy is measured without the final 16-bit rounding:
-  * exact mode (P kept fp32) vs the fp32 oracle: rtol 1e-3, atol 1e-4 — the north_star bar;
-  * packed mode (MI_DECODE_PACKED_PV: P rounded to the cache dtype before PV, as flash
-    kernels do) vs the fp32 oracle: rtol 1e-3 + atol 6e-3 (bf16) / 1e-3 (f16) — the P
-    rounding itself is worth up to 2^-9 relative per term (|out| <= max|V| ~ 4);
+  * exact mode (VALU kernel, P kept fp32) AND fast mode (the production matrix-core kernel: P carried
+    as a hi + lo pair of cache-dtype values) vs the fp32 oracle: rtol 1e-3, atol 1e-4 — the north_star bar;
+  * packed_valu / rounded_p (A/B forms that round P ONCE to the cache dtype before PV, as flash
+    kernels do; not what the product runs where the matrix-core kernel is built) vs the fp32 oracle:
+    rtol 1e-3 + atol 6e-3 (bf16) / 1e-3 (f16) — the P rounding itself is worth up to 2^-9 relative per
+    term (|out| <= max|V| ~ 4);
   * 16-bit output == round(fp32 output) bit-exactly.
 Block-table indexing is checked bit-exactly with integer-valued V (one-hot attention).
 """
@@ -38,13 +40,14 @@ def _mk_case(S, nq, nkv, d, bs, seq_lens, dtype, seed=0, nb_extra=7, layout="nb2
     return kv, kb, vb, table, q, torch.tensor(seq_lens, dtype=torch.int32)
 
 
-MODES = ["exact", "packed_valu", "fast"]   # fast = MFMA kernel where built, else packed VALU
+# fast = production: MFMA kernel (split P) where built, else the fp32-P VALU kernel
+MODES = ["exact", "packed_valu", "fast", "rounded_p"]
 
 
 def _tol(mode, dtype):
-    """(rtol, atol) vs the fp32 oracle.  exact: the north_star bar.  packed/fast: P rounded to the cache
-    dtype (2^-9 / 2^-12 relative per term, |out| <= max|V| ~ 4)."""
-    if mode == "exact":
+    """(rtol, atol) vs the fp32 oracle.  exact / fast: the north_star bar.  packed_valu / rounded_p (A/B forms):
+    P rounded once to the cache dtype (2^-9 / 2^-12 relative per term, |out| <= max|V| ~ 4)."""
+    if mode in ("exact", "fast"):
         return 1e-3, 1e-4
     return (1e-3, 6e-3) if dtype == torch.bfloat16 else (1e-3, 1e-3)
 
@@ -64,7 +67,7 @@ def _run(dev, kv, layout, table, q, seq_lens, out_dtype, partition_size=0, max_s
     msl = int(seq_lens.max()) if max_seq_len is None else max_seq_len
     ops.paged_attn_decode(out, q.view(S, nq * d).to(dev), kb, vb, table.to(dev), seq_lens.to(dev),
                           max(msl, 1), d ** -0.5, partition_size=partition_size, packed_pv=mode != "exact",
-                          force_valu=mode == "packed_valu")
+                          force_valu=mode == "packed_valu", rounded_p=mode == "rounded_p")
     torch.cuda.synchronize()
     return out.cpu().view(S, nq, d)
 

@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--layout", default="NB2")
     ap.add_argument("--parts", default="0,256,512,1024,2048,4096")
-    ap.add_argument("--modes", default="0,1,2", help="0 = exact fp32-P VALU, 1 = packed dot2 VALU, 2 = MFMA, 3 = MFMA + nt")
+    ap.add_argument("--modes", default="0,1,2", help="0 = exact fp32-P VALU, 1 = packed dot2 VALU, 2 = MFMA, 3 = MFMA + nt (production), "
+                    "4 = MFMA + nt with the single-rounding P of round 2 (A/B)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -48,24 +49,24 @@ def main():
     print(f"layout={a.layout} batch={a.batch} ctx={a.ctx} nq={a.nq} nkv={a.nkv} d={a.d} "
           f"algorithmic bytes/launch={algo_bytes / 1e9:.3f} GB")
     for mode in [int(x) for x in a.modes.split(",")]:
-        packed, force_valu, nt = mode != 0, mode == 1, mode == 3
+        packed, force_valu, nt, rp = mode != 0, mode == 1, mode >= 3, mode == 4
         for ps in [int(x) for x in a.parts.split(",")]:
             eff = ops.decode_auto_partition(a.batch, a.nkv, a.ctx, a.bs, ps)
             ws = torch.empty(max(1, ops.decode_workspace_bytes(a.batch, a.nq, a.d, a.ctx, eff)), dtype=torch.uint8,
                              device=dev)
             for _ in range(10):
                 ops.paged_attn_decode(out, q, kb, vb, table, seq_lens, a.ctx, a.d ** -0.5, partition_size=eff,
-                                      workspace=ws, packed_pv=packed, force_valu=force_valu, nontemporal=nt)
+                                      workspace=ws, packed_pv=packed, force_valu=force_valu, nontemporal=nt, rounded_p=rp)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
                 ops.paged_attn_decode(out, q, kb, vb, table, seq_lens, a.ctx, a.d ** -0.5, partition_size=eff,
-                                      workspace=ws, packed_pv=packed, force_valu=force_valu, nontemporal=nt)
+                                      workspace=ws, packed_pv=packed, force_valu=force_valu, nontemporal=nt, rounded_p=rp)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
-            print(f"mode={['exact_valu', 'packed_valu', 'mfma', 'mfma_nt'][mode]:11s} partition={eff:5d}{'(auto)' if ps == 0 else '      '} "
+            print(f"mode={['exact_valu', 'packed_valu', 'mfma', 'mfma_nt', 'mfma_nt_rndP'][mode]:12s} partition={eff:5d}{'(auto)' if ps == 0 else '      '} "
                   f"{ms * 1e3:9.1f} us  {algo_bytes / ms / 1e6:8.1f} GB/s  ({algo_bytes / ms / 1e6 / 8000:.1%} of 8 TB/s)")
 
 

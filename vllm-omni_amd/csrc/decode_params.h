@@ -25,6 +25,6 @@ struct DecodeParams {
 
 // paged_attn_decode_mfma.hip
 int launch_decode_mfma(const DecodeParams& p, int heads_per_wave, int head_dim, int dtype, bool nontemporal,
-                       hipStream_t stream);
+                       bool split_p, hipStream_t stream);
 
 }  // namespace mi

@@ -20,8 +20,14 @@
 //     (a k-slot permutation shared by both operands); V^T fragments come from the row-major V
 //     image through `ds_read_b64_tr_b16`.
 //   * O^T accumulates over all tokens of the wave inside the MFMA, so no end-of-wave merge.
-// Numerics: fp32 scores/statistics/accumulators; P is rounded to the cache dtype for the MFMA
-// (as the reference's TRITON_ATTN kernel does before `tl.dot(P, V)`).
+// Numerics: fp32 scores/statistics/accumulators.  The MFMA's B operand is 16-bit, so P (fp32, in [0, 1])
+// is carried as TWO cache-dtype values, p = hi + lo with hi = rnd16(p), lo = rnd16(p - hi): 16 (bf16) /
+// 22 (f16) significant bits instead of 8 / 11, which is what brings this kernel inside north_star's
+// rtol 1e-3 (atol 1e-4) against the fp32 oracle.  The PV contraction is a K = 32 MFMA whose k-slots are
+// the step's two 16-token sub-tiles; the hi and the lo fragments each take one MFMA against the SAME V
+// operand, so the split costs no LDS traffic: 2 x 16x16x32 per d-tile where the single-rounding form
+// (SPLIT = false, MI_DECODE_ROUNDED_P: flash-style `dot(P.to(V.dtype), V)`, kept for A/B) issues
+// 2 x 16x16x16.
 #include <cstdlib>
 #include <type_traits>
 
@@ -33,7 +39,7 @@ namespace mi {
 namespace {
 
 // AUX = cache-policy bits of the DMA loads (0 = default, 2 = nt: K/V bytes are read exactly once).
-template <typename Tag, int HD, int AUX>
+template <typename Tag, int HD, int AUX, bool SPLIT>
 __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p, const int gh) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -253,10 +259,20 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
     }
     const f32x2_t ls = (v[0] + v[1]) + (v[2] + v[3]);
     l += ls[0] + ls[1];
-    // P^T fragments (B operand of the K=16 MFMA): lane (head h, tokens 4g+0..3) of each sub-tile —
-    // exactly the four scores the lane already holds
+    // P^T fragments: lane (head h, tokens 4g+0..3) of each sub-tile — exactly the four scores the lane
+    // already holds.  k-slot (g, j) of the K = 32 operand = token 4g + j of sub-tile 0 for j < 4, token
+    // 4g + j - 4 of sub-tile 1 for j >= 4: the B operand is {pb0, pb1}, the A operand {a0[n], a1[n]}.
     const u32x2_t pb0 = {E::pack(v[0][0], v[0][1]), E::pack(v[1][0], v[1][1])};
     const u32x2_t pb1 = {E::pack(v[2][0], v[2][1]), E::pack(v[3][0], v[3][1])};
+    uint4 p_hi = make_uint4(pb0[0], pb0[1], pb1[0], pb1[1]), p_lo = p_hi;
+    if constexpr (SPLIT) {
+      // lo = rnd16(p - hi): the subtraction is exact in fp32 (hi is p's leading bits)
+      const uint32_t w[4] = {pb0[0], pb0[1], pb1[0], pb1[1]};
+      uint32_t lo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lo[i] = E::pack(v[i][0] - E::lo(w[i]), v[i][1] - E::hi(w[i]));
+      p_lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
     // V(t) landed?  issued after it: K(t+1) V(t+1) when step t+1 exists, K(t+2) when step t+2 does
     wait_groups((has1 ? 2 : 0) + (has2 ? 1 : 0));
     // ---- O^T[n] += V^T[n] . P^T, four d-tiles (8 transposed reads) per wait -------------------
@@ -265,9 +281,15 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
       u32x2_t a0[4], a1[4];
       lds_read_tr8<SB, SB + 16 * ROWB>(&v_rd[nb], a0, a1);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {  // one transposed read == one A operand: no register shuffling
-        acc[nb + n] = mfma16_k16<Tag>(a0[n], pb0, acc[nb + n]);
-        acc[nb + n] = mfma16_k16<Tag>(a1[n], pb1, acc[nb + n]);
+      for (int n = 0; n < 4; ++n) {  // one transposed read == half an A operand: no register shuffling
+        if constexpr (SPLIT) {
+          const uint4 a = make_uint4(a0[n][0], a0[n][1], a1[n][0], a1[n][1]);
+          acc[nb + n] = mfma16<Tag>(a, p_hi, acc[nb + n]);
+          acc[nb + n] = mfma16<Tag>(a, p_lo, acc[nb + n]);
+        } else {
+          acc[nb + n] = mfma16_k16<Tag>(a0[n], pb0, acc[nb + n]);
+          acc[nb + n] = mfma16_k16<Tag>(a1[n], pb1, acc[nb + n]);
+        }
       }
     }
     if (has2) issue_v(t + 2, ST);  // every read of this stage's V image has retired
@@ -320,14 +342,20 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 
 // Launch the MFMA decode kernel.  Caller guarantees: head_dim in {64, 128}, block_size >= 16,
 // partition a multiple of 32 tokens and <= 64 blocks.
-int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, bool nt, hipStream_t stream) {
+int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, bool nt, bool split_p,
+                       hipStream_t stream) {
   const int64_t waves = (int64_t)p.num_seqs * (p.num_q_heads / gh) * p.num_parts;
   if (waves > INT32_MAX) return MI_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)waves), block(64);
 #define MI_LAUNCH(TAG, HDIM)                                                                            \
   do {                                                                                                  \
-    if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2>), grid, block, 0, stream, p, gh);      \
-    else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0>), grid, block, 0, stream, p, gh);         \
+    if (split_p) {                                                                                      \
+      if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2, true>), grid, block, 0, stream, p, gh);  \
+      else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0, true>), grid, block, 0, stream, p, gh);     \
+    } else {                                                                                            \
+      if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2, false>), grid, block, 0, stream, p, gh); \
+      else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0, false>), grid, block, 0, stream, p, gh);    \
+    }                                                                                                   \
   } while (0)
   if (dtype == MI_DTYPE_BF16) {
     if (head_dim == 128) MI_LAUNCH(bf16_tag, 128); else MI_LAUNCH(bf16_tag, 64);

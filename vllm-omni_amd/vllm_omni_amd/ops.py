@@ -142,14 +142,16 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
                       block_table: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, scale: float,
                       partition_size: int = 0, workspace: Optional[torch.Tensor] = None,
                       packed_pv: Optional[bool] = None, force_valu: bool = False,
-                      nontemporal: Optional[bool] = None) -> torch.Tensor:
+                      nontemporal: Optional[bool] = None, rounded_p: bool = False) -> torch.Tensor:
     """out[s, h] = softmax(q[s,h] . K^T * scale) . V over the paged cache (one query per sequence).
 
     q, out: [S, nq*d] (or [S, nq, d]); block_table int32 [S, max_blocks]; seq_lens int32 [S].
     ``max_seq_len`` is a host-side upper bound of seq_lens (sizes the launch).
     ``out`` may be fp32 for parity measurement.  ``packed_pv`` (None = module default
-    ``DECODE_PACKED_PV``): allow P rounded to the cache dtype (MFMA kernel / dot2 form);
-    ``force_valu`` keeps the VALU kernel.  Returns ``out``.
+    ``DECODE_PACKED_PV``): P.V on 16-bit operands — the MFMA kernel (P carried as a hi + lo pair of
+    cache-dtype values, inside the fp32-P tolerance) where it is built, the dot2 VALU form elsewhere;
+    ``force_valu`` keeps the VALU kernel; ``rounded_p`` asks the MFMA kernel for the single-rounding
+    P of flash kernels (A/B measurements only).  Returns ``out``.
     """
     _gpu(out, q, k_cache, v_cache, block_table, seq_lens, workspace)
     nb, bs, hkv, d = k_cache.shape
@@ -174,6 +176,7 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
         _dt(q.dtype), _dt(out.dtype),
         (_C.MI_DECODE_PACKED_PV if (DECODE_PACKED_PV if packed_pv is None else packed_pv) else 0)
         | (_C.MI_DECODE_FORCE_VALU if force_valu else 0)
+        | (_C.MI_DECODE_ROUNDED_P if rounded_p else 0)
         | (_C.MI_DECODE_NONTEMPORAL if (DECODE_NONTEMPORAL if nontemporal is None else nontemporal) else 0),
         _stream()))
     return out
