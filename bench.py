@@ -550,11 +550,18 @@ def main():
             staged.append((tp, dp, label, role, False, ar))   # 4. captured, library collectives inside the graph
         ordered = staged
 
+    # A stage that hung or raised has touched the GPU and may have left kernels / collectives behind: the process
+    # reports what it measured BEFORE that stage (one JSON line, `failed_plans` + `exit_code` inside) and then ends
+    # with a distinct NON-ZERO code, so torchrun and the driver do not record a hang as a clean run.
+    EXIT_STAGE_FAILED = 4
+
     def emit_and_exit(reason: str, what: str) -> None:      # watchdog thread
         failures.append({"parallelism": what, "error": reason})
         if rank == 0 and results:
-            print(json.dumps(compose(results, failures)), flush=True)
-        os._exit(0 if results else 3)
+            line = compose(results, failures)
+            line["exit_code"] = EXIT_STAGE_FAILED
+            print(json.dumps(line), flush=True)
+        os._exit(EXIT_STAGE_FAILED if results else 3)
 
     t_bench0 = time.monotonic()
     budget = float(os.environ.get("MI_BENCH_BUDGET_S", "420"))   # no further stage is STARTED past this many seconds
@@ -590,8 +597,10 @@ def main():
                 guard.cancel()
             # a failed capture / collective leaves the process group in an unknown state: report and leave
             if rank == 0:
-                print(json.dumps(compose(results, failures)), flush=True)
-            os._exit(0)
+                line = compose(results, failures)
+                line["exit_code"] = EXIT_STAGE_FAILED
+                print(json.dumps(line), flush=True)
+            os._exit(EXIT_STAGE_FAILED)
         finally:
             if guard is not None:
                 guard.cancel()

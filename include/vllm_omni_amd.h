@@ -493,8 +493,21 @@ int mi_allreduce_destroy(mi_allreduce* ar);
  * block and never handed out.  Thread-compatible: caller serialises.
  *   alloc: pops `n` ids into out_ids, or returns MI_ERR_EXHAUSTED and pops
  *          nothing (the façade turns that into `None`).
- *   ref:   +1 on an allocated block (prefix sharing).
- *   free:  -1; at zero the block goes back to the free list.
+ *   ref:   +1 on an allocated block (prefix sharing), or on a FREE block that
+ *          is still indexed by its content hash (a prefix-cache hit: the block
+ *          leaves the free list).
+ *   free:  -1; at zero the block goes back to the free list, keeping its hash.
+ * Prefix cache (what upstream's `KVCacheManager.get_computed_blocks` /
+ * `cache_blocks` do under `enable_prefix_caching`, reached from
+ * omni_ar_scheduler.py:188 `super().schedule()`; consumed by
+ * vllm_omni/core/prefix_cache.py:255-264 `block_table[req, :num_computed // b]`):
+ *   cache_insert: index an ALLOCATED full block under a 128-bit content hash
+ *          (first writer wins; a block's hash never changes while indexed).
+ *   cache_lookup: ids of the longest indexed PREFIX of `n` hashes
+ *          (hashes[2*i], hashes[2*i+1] = lo, hi); returns the hit count.
+ *   alloc  evicts: popping a free block that still carries a hash drops the
+ *          entry; `take_evicted` drains the ids (KV-cache events).
+ *   reset_cache: drop every entry; MI_ERR_STATE while any block is in use.
  * ---------------------------------------------------------------------- */
 typedef struct mi_blockpool mi_blockpool;
 mi_blockpool* mi_blockpool_create(int32_t num_blocks);
@@ -505,6 +518,12 @@ int mi_blockpool_alloc(mi_blockpool* pool, int32_t n, int32_t* out_ids);
 int mi_blockpool_ref(mi_blockpool* pool, const int32_t* ids, int32_t n);
 int mi_blockpool_free(mi_blockpool* pool, const int32_t* ids, int32_t n);
 int32_t mi_blockpool_refcount(const mi_blockpool* pool, int32_t id);
+int mi_blockpool_cache_insert(mi_blockpool* pool, int32_t id, uint64_t hash_lo, uint64_t hash_hi);
+int32_t mi_blockpool_cache_lookup(const mi_blockpool* pool, const uint64_t* hashes, int32_t n,
+                                  int32_t* out_ids);
+int32_t mi_blockpool_num_cached(const mi_blockpool* pool);
+int mi_blockpool_reset_cache(mi_blockpool* pool);
+int32_t mi_blockpool_take_evicted(mi_blockpool* pool, int32_t* out_ids, int32_t capacity);
 
 /* A3 — slot mapping on the host: slot[t] = block_table[req, pos/bs]*bs + pos%bs
  * for the tokens scheduled this step (vectorised restatement of upstream's

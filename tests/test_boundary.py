@@ -85,10 +85,19 @@ def test_entry_point_to_worker_construction_from_a_vllm_config():
             w.init_device()
     with pytest.raises(TypeError):
         worker_cls(vllm_config=object())
-    # data-parallel local rank shifts the device index: DP_LOCAL_RANK * TP + TP_LOCAL_RANK (gpu_ar_worker.py:40-60)
+    # data-parallel local rank shifts the device index, in init_device and only under the reference's condition:
+    # DP_LOCAL_RANK * TP + TP_LOCAL_RANK unless ray / an external launcher (torchrun) already hands every worker its
+    # device index, the DP backend is ray, or DP spans nodes (gpu_ar_worker.py:34-49)
     vc2 = make_vllm_config(tp=2)
     vc2.parallel_config.data_parallel_rank_local = 1
-    assert worker_cls(vllm_config=vc2, local_rank=1, rank=3).local_rank == 3
+    w2 = worker_cls(vllm_config=vc2, local_rank=1, rank=3)
+    assert w2.local_rank == 1 and w2.dp_adjusted_local_rank() == 3
+    for field, value in (("distributed_executor_backend", "external_launcher"), ("distributed_executor_backend", "ray"),
+                         ("data_parallel_backend", "ray"), ("nnodes_within_dp", 2)):
+        vc3 = make_vllm_config(tp=2)
+        vc3.parallel_config.data_parallel_rank_local = 1
+        setattr(vc3.parallel_config, field, value)
+        assert worker_cls(vllm_config=vc3, local_rank=1, rank=3).dp_adjusted_local_rank() == 1, field
 
 
 def test_runner_is_constructed_from_vllm_config_and_device():

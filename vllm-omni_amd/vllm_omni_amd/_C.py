@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 # VLLM_OMNI_AMD_LIB: an alternative build of the same ABI (kernel experiments: csrc/Makefile `make variant`)
 _LIB_PATH = os.environ.get("VLLM_OMNI_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
@@ -104,6 +104,11 @@ SIGNATURES = {
     "mi_blockpool_ref": (c_int, [_P, POINTER(c_int32), c_int32]),
     "mi_blockpool_free": (c_int, [_P, POINTER(c_int32), c_int32]),
     "mi_blockpool_refcount": (c_int32, [_P, c_int32]),
+    "mi_blockpool_cache_insert": (c_int, [_P, c_int32, c_uint64, c_uint64]),
+    "mi_blockpool_cache_lookup": (c_int32, [_P, POINTER(c_uint64), c_int32, POINTER(c_int32)]),
+    "mi_blockpool_num_cached": (c_int32, [_P]),
+    "mi_blockpool_reset_cache": (c_int, [_P]),
+    "mi_blockpool_take_evicted": (c_int32, [_P, POINTER(c_int32), c_int32]),
     "mi_compute_slot_mapping": (c_int, [_P, _P, c_int32, _P, _P, c_int32, c_int32]),
 }
 

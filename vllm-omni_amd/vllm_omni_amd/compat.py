@@ -134,7 +134,11 @@ def worker_config_from_vllm_config(vc: Any):
         engine_output_type=str(_get(mc, "engine_output_type", "latent") or "latent"),
         device_type=dev_type, distributed_backend=str(_get(vc, "dist_backend", "nccl")),
         seed=int(_get(mc, "seed", 0) or 0), quantization=None if quant is None else "int8",
-        dp_local_rank=int(_get(pc, "data_parallel_rank_local", None) or _get(pc, "data_parallel_index", 0) or 0))
+        dp_local_rank=int(_get(pc, "data_parallel_rank_local", None) or _get(pc, "data_parallel_index", 0) or 0),
+        distributed_executor_backend=_get(pc, "distributed_executor_backend"),
+        data_parallel_backend=_get(pc, "data_parallel_backend"),
+        nnodes_within_dp=int(_get(pc, "nnodes_within_dp", 1) or 1),
+        enable_prefix_caching=bool(_get(cc, "enable_prefix_caching", False)))
 
 
 # ------------------------------------------------------------------------------------ request payloads

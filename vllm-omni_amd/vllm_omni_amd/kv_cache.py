@@ -11,6 +11,8 @@
   * ``take_events()``                     omni_ar_scheduler.py:480
   * ``get_num_common_prefix_blocks``      omni_generation_scheduler.py:210
   * ``take_new_block_ids``                omni_generation_scheduler.py:256
+  * ``get_computed_blocks`` / ``cache_blocks`` / ``reset_prefix_cache``: upstream's prefix caching, reached from
+    ``super().schedule()`` (omni_ar_scheduler.py:188) when ``enable_prefix_caching`` is set
 
 The free list / reference counts live in the C++ pool behind the C ABI
 (``mi_blockpool_*``); block id 0 is the reserved null block.  One KV-cache group only (the
@@ -76,6 +78,38 @@ class BlockPool:
     def ref_cnt(self, block_id: int) -> int:
         return int(lib.mi_blockpool_refcount(self._h, block_id))
 
+    # -- prefix-cache index (full blocks by 128-bit content hash) -------------------
+    def cache_insert(self, block_id: int, digest: bytes) -> None:
+        lo, hi = int.from_bytes(digest[:8], "little"), int.from_bytes(digest[8:16], "little")
+        _C.check("mi_blockpool_cache_insert", lib.mi_blockpool_cache_insert(self._h, block_id, lo, hi))
+
+    def cache_lookup(self, digests: Sequence[bytes]) -> list[int]:
+        """Block ids of the longest indexed PREFIX of ``digests``."""
+        n = len(digests)
+        if n == 0:
+            return []
+        words = (ctypes.c_uint64 * (2 * n)).from_buffer_copy(b"".join(digests))
+        out = (ctypes.c_int32 * n)()
+        hits = int(lib.mi_blockpool_cache_lookup(self._h, words, n, out))
+        if hits < 0:
+            _C.check("mi_blockpool_cache_lookup", hits)
+        return list(out[:hits])
+
+    def num_cached(self) -> int:
+        return int(lib.mi_blockpool_num_cached(self._h))
+
+    def reset_cache(self) -> bool:
+        return int(lib.mi_blockpool_reset_cache(self._h)) == _C.MI_OK
+
+    def take_evicted(self) -> list[int]:
+        out = []
+        buf = (ctypes.c_int32 * 256)()
+        while True:
+            n = int(lib.mi_blockpool_take_evicted(self._h, buf, 256))
+            out.extend(buf[:n])
+            if n < 256:
+                return out
+
     @property
     def usage(self) -> float:
         total = self.num_blocks - 1
@@ -108,16 +142,93 @@ class BlockRemoved:
     request_id: str
 
 
+# ----------------------------------------------------------------------- hashing
+def _request_tokens(request) -> Sequence[int]:
+    toks = getattr(request, "all_token_ids", None)
+    if toks is not None:
+        return toks
+    return list(request.prompt_token_ids) + list(getattr(request, "output_token_ids", []) or [])
+
+
+def _prompt_rows(request) -> int:
+    pe = getattr(request, "prompt_embeds", None)
+    return int(pe.shape[0]) if isinstance(pe, torch.Tensor) else 0
+
+
+def _has_reply_rows(request) -> bool:
+    info = getattr(request, "additional_information", None)
+    return isinstance(info, dict) and info.get("thinker_reply_part") is not None
+
+
+def block_content_hash(parent: bytes, token_ids: Sequence[int], extra: bytes = b"") -> bytes:
+    """Chained 128-bit content hash of one FULL block: blake2b-128(parent || int64 token ids || extra) — upstream
+    chains ``hash((parent_hash, token_ids, extra_keys))`` the same way.  ``extra`` carries what the token ids do not
+    determine: the rows of ``prompt_embeds`` the block covers (every talker prompt is embeddings behind placeholder ids,
+    stage_input_processors/qwen2_5_omni.py:6-61) and, for blocks that hold generated positions of a request whose decode
+    inputs also depend on per-request data (``thinker_reply_part``), the request id."""
+    import hashlib
+
+    import numpy as np
+
+    h = hashlib.blake2b(parent, digest_size=16)
+    h.update(np.asarray(token_ids, dtype=np.int64).tobytes())
+    if extra:
+        h.update(extra)
+    return h.digest()
+
+
 # ----------------------------------------------------------------------- manager
 class KVCacheManager:
-    """Request -> physical block ids.  Grows by ceil((computed + new + lookahead) / b)."""
+    """Request -> physical block ids.  Grows by ceil((computed + new + lookahead) / b); with
+    ``enable_caching`` full blocks are indexed by a chained content hash and re-used by later requests with the
+    same prefix (upstream's prefix caching, the precondition of ``OmniTensorPrefixCache``,
+    vllm_omni/core/prefix_cache.py:255-264).
 
-    def __init__(self, num_blocks: int, block_size: int, enable_kv_cache_events: bool = False,
-                 track_new_block_ids: bool = False):
+    Two ways to build it: ``KVCacheManager(num_blocks, block_size, ...)``, or upstream's own call
+    ``KVCacheManager(kv_cache_config, max_model_len, hash_block_size, enable_caching=..., enable_kv_cache_events=...)``
+    as ``vllm.v1.core.sched.scheduler.Scheduler.__init__`` makes it (``kv_cache_config.num_blocks`` and the block size
+    of its single KV-cache group are read)."""
+
+    def __init__(self, *args, **kwargs):
+        first = args[0] if args else None
+        if isinstance(first, int) or (not args and "num_blocks" in kwargs):
+            self._init(*args, **kwargs)
+        else:
+            self._init_upstream(*args, **kwargs)
+
+    def _init_upstream(self, kv_cache_config=None, max_model_len: Optional[int] = None,
+                       hash_block_size: Optional[int] = None, enable_caching: bool = True, use_eagle: bool = False,
+                       log_stats: bool = False, enable_kv_cache_events: bool = False, dcp_world_size: int = 1,
+                       pcp_world_size: int = 1, metrics_collector=None, track_new_block_ids: bool = False):
+        """upstream's own argument order, as ``Scheduler.__init__`` calls it"""
+        if kv_cache_config is None:
+            raise TypeError("KVCacheManager needs (num_blocks, block_size) or a kv_cache_config")
+        groups = list(getattr(kv_cache_config, "kv_cache_groups", []) or [])
+        if len(groups) > 1:
+            raise ValueError("one KV-cache group only (the talker is a uniform full-attention stack)")
+        block_size = int(groups[0].kv_cache_spec.block_size) if groups else hash_block_size
+        self._init(int(kv_cache_config.num_blocks), block_size, enable_kv_cache_events, track_new_block_ids,
+                   enable_caching, max_model_len=max_model_len, use_eagle=use_eagle, log_stats=log_stats,
+                   dcp_world_size=dcp_world_size, pcp_world_size=pcp_world_size)
+
+    def _init(self, num_blocks: int = None, block_size: int = None, enable_kv_cache_events: bool = False,
+              track_new_block_ids: bool = False, enable_caching: bool = False, *, max_model_len: Optional[int] = None,
+              use_eagle: bool = False, log_stats: bool = False, dcp_world_size: int = 1, pcp_world_size: int = 1):
+        if num_blocks is None or block_size is None:
+            raise TypeError("KVCacheManager needs (num_blocks, block_size) or a kv_cache_config")
+        if dcp_world_size != 1 or pcp_world_size != 1 or use_eagle:
+            raise ValueError("context-parallel / eagle block layouts are not built (not on the talker path)")
         self.block_size = block_size
         self.num_blocks = num_blocks
+        self.max_model_len = max_model_len
+        self.enable_caching = bool(enable_caching)
+        self.log_stats = log_stats
         self.block_pool = BlockPool(num_blocks)
         self.req_to_blocks: dict[str, list[int]] = {}
+        self._req_hashes: dict[str, list[bytes]] = {}       # chained hashes of the request's full blocks so far
+        self._num_cached_blocks: dict[str, int] = {}        # leading blocks of the request already indexed
+        self.prefix_cache_queries = 0                        # tokens looked up / found (upstream's PrefixCacheStats)
+        self.prefix_cache_hits = 0
         self._events: list[Any] = []
         self._events_on = enable_kv_cache_events
         self._new_block_ids: Optional[list[int]] = [] if track_new_block_ids else None
@@ -135,36 +246,119 @@ class KVCacheManager:
     def usage(self) -> float:
         return self.block_pool.usage
 
-    # -- allocation -------------------------------------------------------------
-    def allocate_slots(self, request, num_new_tokens: int, num_lookahead_tokens: int = 0,
-                       **_unused) -> Optional[KVCacheBlocks]:
-        """Make room for ``num_new_tokens`` (+ lookahead) more tokens of ``request``.
+    # -- prefix cache -----------------------------------------------------------
+    def _block_hashes(self, request, num_blocks: int) -> list[bytes]:
+        """Chained hashes of the request's first ``num_blocks`` full blocks (extended incrementally: a block's
+        content never changes once it is full)."""
+        rid = request.request_id
+        hs = self._req_hashes.setdefault(rid, [])
+        if len(hs) >= num_blocks:
+            return hs[:num_blocks]
+        toks = _request_tokens(request)
+        b = self.block_size
+        pe = getattr(request, "prompt_embeds", None)
+        rows = _prompt_rows(request)
+        salted = _has_reply_rows(request)
+        plen = max(rows, len(request.prompt_token_ids))
+        parent = hs[-1] if hs else b"\0" * 16
+        for i in range(len(hs), num_blocks):
+            lo, hi = i * b, (i + 1) * b
+            extra = b""
+            if lo < rows:   # the block covers prompt rows given as embeddings: their bytes ARE the content
+                extra = pe[lo:min(hi, rows)].detach().contiguous().cpu().view(torch.uint8).numpy().tobytes()
+            if hi > plen and salted:
+                extra += b"|" + rid.encode()
+            parent = block_content_hash(parent, toks[lo:hi], extra)
+            hs.append(parent)
+        return hs
 
-        Returns the newly allocated blocks (possibly empty) or ``None`` when the pool is
-        exhausted — callers break out and fall back (omni_generation_scheduler.py:105-110).
-        All-or-nothing: a failed call leaves the request's blocks unchanged.
-        """
-        if num_new_tokens < 0 or num_lookahead_tokens < 0:
+    def get_computed_blocks(self, request) -> tuple["KVCacheBlocks", int]:
+        """Longest cached prefix of the request: ``(blocks, num_computed_tokens)`` (upstream's
+        ``KVCacheManager.get_computed_blocks``, called for a request with no computed tokens yet).  At least the last
+        token is always recomputed — the step needs its logits (upstream: ``max_cache_hit_length = num_tokens - 1``)."""
+        if not self.enable_caching:
+            return KVCacheBlocks(([],)), 0
+        max_hit = int(request.num_tokens) - 1
+        n = max(max_hit, 0) // self.block_size
+        if n == 0:
+            return KVCacheBlocks(([],)), 0
+        hashes = self._block_hashes(request, n)
+        ids = self.block_pool.cache_lookup(hashes)
+        self.prefix_cache_queries += int(request.num_tokens)
+        self.prefix_cache_hits += len(ids) * self.block_size
+        return KVCacheBlocks((ids,)), len(ids) * self.block_size
+
+    def cache_blocks(self, request, num_computed_tokens: int) -> None:
+        """Index the request's full blocks up to ``num_computed_tokens`` (upstream's ``cache_blocks``)."""
+        if not self.enable_caching:
+            return
+        rid = request.request_id
+        blocks = self.req_to_blocks.get(rid) or []
+        n_full = min(int(num_computed_tokens) // self.block_size, len(blocks))
+        done = self._num_cached_blocks.get(rid, 0)
+        if n_full <= done:
+            return
+        hashes = self._block_hashes(request, n_full)
+        for i in range(done, n_full):
+            self.block_pool.cache_insert(blocks[i], hashes[i])
+        self._num_cached_blocks[rid] = n_full
+        if self._events_on:
+            self._events.append(BlockStored(list(blocks[done:n_full]), rid))
+
+    # -- allocation -------------------------------------------------------------
+    def allocate_slots(self, request, num_new_tokens: int, num_new_computed_tokens: int = 0,
+                       new_computed_blocks: Optional["KVCacheBlocks"] = None, num_lookahead_tokens: int = 0,
+                       num_external_computed_tokens: int = 0, delay_cache_blocks: bool = False,
+                       num_encoder_tokens: int = 0) -> Optional[KVCacheBlocks]:
+        """Make room for ``num_new_tokens`` (+ lookahead) more tokens of ``request`` — upstream's signature
+        (``Scheduler.schedule`` calls it with ``num_new_computed_tokens`` / ``new_computed_blocks`` for a request
+        that just hit the prefix cache; the reference's generation scheduler with ``num_lookahead_tokens=``,
+        omni_generation_scheduler.py:100-110,167-177).
+
+        Returns the newly allocated blocks (possibly empty; cache-hit blocks are not repeated — ``get_block_ids``
+        has the whole row) or ``None`` when the pool is exhausted: callers break out and fall back
+        (omni_generation_scheduler.py:105-110).  All-or-nothing: a failed call leaves the request's blocks unchanged."""
+        if num_new_tokens < 0 or num_lookahead_tokens < 0 or num_new_computed_tokens < 0:
             raise ValueError("token counts must be non-negative")
+        if num_external_computed_tokens or num_encoder_tokens:
+            raise ValueError("external / encoder tokens are not on the talker path")
         rid = request.request_id
         have = self.req_to_blocks.get(rid)
-        total_tokens = int(request.num_computed_tokens) + num_new_tokens + num_lookahead_tokens
-        need = cdiv(total_tokens, self.block_size) - (len(have) if have else 0)
-        if need <= 0:
-            if have is None:
-                self.req_to_blocks[rid] = []
-            return KVCacheBlocks(([],))
-        new = self.block_pool.get_new_blocks(need)
-        if new is None:
+        hit = list(new_computed_blocks.blocks[0]) if new_computed_blocks is not None else []
+        if hit and have:
+            raise ValueError("prefix-cache hits are only attached to a request without blocks")
+        computed = int(request.num_computed_tokens) + num_new_computed_tokens
+        total_tokens = computed + num_new_tokens + num_lookahead_tokens
+        if self.max_model_len is not None:
+            total_tokens = min(total_tokens, self.max_model_len)
+        need = cdiv(total_tokens, self.block_size) - (len(have) if have else 0) - len(hit)
+        if need > 0:
+            # a hit on a block that currently sits on the free list takes it OUT of the free list: it cannot also
+            # serve this allocation (upstream: `num_evictable_computed_blocks`)
+            revived = sum(1 for b in hit if self.block_pool.ref_cnt(b) == 0)
+            if need > self.block_pool.get_num_free_blocks() - revived:
+                return None
+        self.block_pool.touch(hit)
+        new = self.block_pool.get_new_blocks(max(need, 0))
+        if new is None:   # cannot happen after the check above; keep the all-or-nothing contract regardless
+            self.block_pool.free_blocks(list(reversed(hit)))
             return None
         if have is None:
-            self.req_to_blocks[rid] = new[:]
-        else:
-            have.extend(new)
+            have = self.req_to_blocks[rid] = []
+        have.extend(hit)
+        have.extend(new)
+        if hit:
+            self._num_cached_blocks[rid] = len(hit)
         if self._new_block_ids is not None:
             self._new_block_ids.extend(new)
         if self._events_on:
-            self._events.append(BlockStored(new[:], rid))
+            if self.enable_caching:   # upstream's events: a block is "stored" when indexed, "removed" when evicted
+                for b in self.block_pool.take_evicted():
+                    self._events.append(BlockRemoved([b], rid))
+            elif new:                 # without the index: allocation / release of the blocks themselves
+                self._events.append(BlockStored(new[:], rid))
+        if not delay_cache_blocks:
+            self.cache_blocks(request, min(computed + num_new_tokens, int(request.num_tokens)))
         return KVCacheBlocks((new,))
 
     def get_blocks(self, request_id: str) -> KVCacheBlocks:
@@ -209,18 +403,33 @@ class KVCacheManager:
         self._free_now(request)
 
     def _free_now(self, request) -> None:
-        blocks = self.req_to_blocks.pop(request.request_id, None)
+        rid = request.request_id
+        blocks = self.req_to_blocks.pop(rid, None)
+        self._num_cached_blocks.pop(rid, None)
         if blocks:
             self.block_pool.free_blocks(list(reversed(blocks)))
-            if self._events_on:
-                self._events.append(BlockRemoved(blocks, request.request_id))
+            if self._events_on and not self.enable_caching:
+                self._events.append(BlockRemoved(blocks, rid))
+
+    def free_block_hashes(self, request) -> None:
+        """Forget the request's hash chain (upstream calls this when the request leaves the scheduler for good; a
+        preempted request keeps it and re-hits its own blocks)."""
+        self._req_hashes.pop(request.request_id, None)
 
     def get_num_common_prefix_blocks(self, running_request_id: str) -> list[int]:
-        """Blocks shared by every running request.  Without prefix sharing that is 0 unless a
-        single request runs (then all of its blocks trivially qualify)."""
-        if len(self.req_to_blocks) == 1 and running_request_id in self.req_to_blocks:
-            return [len(self.req_to_blocks[running_request_id])]
-        return [0]
+        """Leading blocks of ``running_request_id`` shared by EVERY request that holds blocks (upstream: blocks whose
+        ``ref_cnt`` equals the number of requests; the reference forwards the result as
+        ``num_common_prefix_blocks``, omni_generation_scheduler.py:207-210)."""
+        blocks = self.req_to_blocks.get(running_request_id)
+        if not blocks:
+            return [0]
+        n_req = len(self.req_to_blocks)
+        n = 0
+        for b in blocks:
+            if self.block_pool.ref_cnt(b) != n_req:
+                break
+            n += 1
+        return [n]
 
     def take_new_block_ids(self) -> list[int]:
         if self._new_block_ids is None:
@@ -233,7 +442,18 @@ class KVCacheManager:
         return out
 
     def reset_prefix_cache(self) -> bool:
+        """Drop every cached-block entry; False (nothing dropped) while any block is still in use — upstream's
+        contract."""
+        if not self.block_pool.reset_cache():
+            return False
+        self._req_hashes.clear()
+        self._num_cached_blocks.clear()
         return True
+
+    def make_prefix_cache_stats(self) -> dict:
+        out = {"queries": self.prefix_cache_queries, "hits": self.prefix_cache_hits}
+        self.prefix_cache_queries = self.prefix_cache_hits = 0
+        return out
 
 
 # ------------------------------------------------------------------- cache tensors

@@ -261,6 +261,10 @@ class ExecuteModelState:
     query_start_loc_np: np.ndarray
     kv_extracted_req_ids: Optional[list[str]]
     num_decodes: int = 0
+    # Omni tensor prefix cache (A14): the step's slot mapping (host copy; the pinned buffer is rewritten next step) and,
+    # per request that entered on a KV prefix-cache hit, the block ids of its cached full blocks
+    slot_mapping_np: Optional[np.ndarray] = None
+    prefix_hit_blocks: Optional[dict] = None
     # rows whose prompt is not finished after this step (a chunk of a chunked prefill): their sampled token is
     # discarded, as upstream's bookkeeping does (`discard_sampled_tokens_req_indices`)
     partial: Optional[np.ndarray] = None
@@ -339,7 +343,7 @@ class GPUARModelRunner:
                  kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: Optional[bool] = None,
                  engine_output_type: Optional[str] = None, max_reply_rows: Optional[int] = None,
                  seed: Optional[int] = 0, quantization: Optional[str] = None, code_predictor=None,
-                 copy_outputs: bool = True):
+                 copy_outputs: bool = True, enable_prefix_caching: Optional[bool] = None):
         """``copy_outputs``: hand every step's ``pooler_output`` tensors back as caller-owned host tensors, as the
         reference does (``hidden_states.to("cpu")``, gpu_ar_model_runner.py:835).  False returns VIEWS of the pinned
         output ring, valid until ``OUT_SLOTS - 1`` further steps have been sampled (what bench.py uses: fresh 1.8 MB
@@ -369,6 +373,10 @@ class GPUARModelRunner:
         enforce_eager = pick(enforce_eager, wc and wc.enforce_eager, False)
         engine_output_type = pick(engine_output_type, wc and wc.engine_output_type, "latent")
         max_reply_rows = pick(max_reply_rows, wc and (wc.max_reply_rows or wc.max_num_seqs * 64), 0)
+        # `cache_config.enable_prefix_caching`: the hidden states handed to the next stage are cached per KV slot too,
+        # so a request that hits the KV prefix cache still gets ALL its rows back (gpu_model_runner.py:79-85)
+        self.enable_prefix_caching = bool(pick(enable_prefix_caching, wc and wc.enable_prefix_caching, False))
+        self.omni_prefix_cache = None
         if not isinstance(config, TalkerConfig):
             raise TypeError(f"GPUARModelRunner needs a VllmConfig-shaped object or a TalkerConfig, got {type(config).__name__}")
         self.config = config
@@ -502,6 +510,12 @@ class GPUARModelRunner:
         nbytes = ops.decode_workspace_bytes(self.max_num_reqs, a.num_heads, a.head_dim, self.max_model_len,
                                             self._decode_part)
         self._decode_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        if self.enable_prefix_caching and self.engine_output_type != "text":
+            from .prefix_cache import OmniTensorPrefixCache
+
+            # host tensor on the KV cache's own (block, offset) grid (gpu_model_runner.py:79-85)
+            self.omni_prefix_cache = OmniTensorPrefixCache(num_blocks=num_blocks, block_size=self.block_size,
+                                                           hidden_size=self.config.hidden_size, hs_dtype=self.dtype)
 
     def _zero_block_ids(self, block_ids: list[int]) -> None:
         idx = torch.as_tensor(block_ids, dtype=torch.int64, device=self.device)
@@ -514,6 +528,8 @@ class GPUARModelRunner:
     # ------------------------------------------------------------ state update
     def _update_states(self, so: SchedulerOutput) -> None:
         ib = self.input_batch
+        if self.omni_prefix_cache is not None:     # (gpu_model_runner.py:252-253)
+            self.omni_prefix_cache.reset_prefix_cached_new_req_ids()
         for rid in so.finished_req_ids:
             st = self.requests.pop(rid, None)
             if self.sampling_state is not None:
@@ -544,6 +560,10 @@ class GPUARModelRunner:
                                     tuple(list(b) for b in nr.block_ids), nr.num_computed_tokens,
                                     prompt_embeds=nr.prompt_embeds, additional_information=nr.additional_information)
             self.requests[nr.req_id] = st
+            # first scheduling with computed tokens == a hit in the KV prefix cache: the rows of the cached blocks
+            # come out of the tensor prefix cache when the step's output is packed (gpu_model_runner.py:315-320)
+            if self.omni_prefix_cache is not None and nr.num_computed_tokens > 0:
+                self.omni_prefix_cache.add_prefix_cached_new_req_id(nr.req_id)
             if self.sampling_state is not None:
                 self.sampling_state.add(st)
             if self.code_predictor is not None:
@@ -919,6 +939,16 @@ class GPUARModelRunner:
         self.execute_model_state = ExecuteModelState(scheduler_output, logits, ids, hidden, n, total,
                                                      self.query_start_loc.np[:n + 1].copy(), kv_done,
                                                      num_decodes=num_decodes, partial=partial if partial.any() else None)
+        pc = self.omni_prefix_cache
+        if pc is not None:
+            st = self.execute_model_state
+            st.slot_mapping_np = ib.block_table[0].slot_mapping.np[:total].copy()
+            hits = {}
+            for rid in pc._new_req_cache_hit_ids:
+                row = ib.req_id_to_index.get(rid)
+                if row is not None:   # block_table[req, :num_computed // block_size] (core/prefix_cache.py:255-264)
+                    hits[rid] = pc._get_cached_block_ids(row, ib).clone()
+            st.prefix_hit_blocks = hits
         return None
 
     def _steady_decode(self, so: SchedulerOutput) -> bool:
@@ -1037,7 +1067,21 @@ class GPUARModelRunner:
             hidden = self._out_hidden_cpu[slot][:st.num_tokens]   # views of the pinned ring (see __init__)
             if self.copy_outputs:                                 # caller-owned, as the reference's .to("cpu") is
                 hidden = hidden.clone()
-            pooler = [{"hidden": c} for c in torch.split(hidden, np.diff(q).tolist())]
+            chunks = list(torch.split(hidden, np.diff(q).tolist()))
+            pc = self.omni_prefix_cache
+            if pc is not None:
+                # `_maybe_update_prefix_cache` + `_maybe_get_combined_prefix_cache_tensors`
+                # (gpu_ar_model_runner.py:205-260,539,846-856), on the host copy this step already made: write the
+                # step's rows at their KV slots, then give a request that entered on a prefix hit
+                # cat([rows of its cached full blocks, this step's rows])
+                pc.update_omni_tensor_prefix_cache(hidden, None, st.num_tokens, torch.from_numpy(st.slot_mapping_np))
+                cache = pc.hidden_states_cache
+                for i, rid in enumerate(out.req_ids):
+                    blocks = (st.prefix_hit_blocks or {}).get(rid)
+                    if blocks is not None and blocks.numel():
+                        cached = cache[blocks.to(torch.int64)].reshape(-1, cache.shape[-1])
+                        chunks[i] = torch.cat([cached, chunks[i]], dim=0)
+            pooler = [{"hidden": c} for c in chunks]
         else:
             pooler = [None] * n
         if self.code_predictor is not None and st.num_decodes == n:

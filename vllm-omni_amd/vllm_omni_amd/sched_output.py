@@ -7,6 +7,7 @@ extensions (``additional_information`` on new/cached requests: vllm_omni/core/sc
 """
 from __future__ import annotations
 
+import enum
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
@@ -22,11 +23,35 @@ class SamplingParams:
     max_tokens: int = 16
     seed: Optional[int] = None
     stop_token_ids: list[int] = field(default_factory=list)
+    ignore_eos: bool = False
 
 
-@dataclass
+class RequestStatus(enum.IntEnum):
+    """Upstream's ``vllm.v1.request.RequestStatus`` as the reference uses it (omni_ar_scheduler.py:143,362-385):
+    everything after ``PREEMPTED`` is a finished state."""
+
+    WAITING = 0
+    WAITING_FOR_CHUNK = 1
+    RUNNING = 2
+    PREEMPTED = 3
+    FINISHED_STOPPED = 4
+    FINISHED_LENGTH_CAPPED = 5
+    FINISHED_ABORTED = 6
+    FINISHED_ERROR = 7
+
+    @staticmethod
+    def is_finished(status: "RequestStatus") -> bool:
+        return status > RequestStatus.PREEMPTED
+
+
+_FINISH_REASON = {RequestStatus.FINISHED_STOPPED: "stop", RequestStatus.FINISHED_LENGTH_CAPPED: "length",
+                  RequestStatus.FINISHED_ABORTED: "abort", RequestStatus.FINISHED_ERROR: "error"}
+
+
+@dataclass(eq=False)
 class Request:
-    """Scheduler-side request state (the subset the allocator and runner read)."""
+    """Scheduler-side request state (the subset of upstream's ``vllm.v1.request.Request`` the scheduler, the
+    allocator and the runner read)."""
 
     request_id: str
     prompt_token_ids: list[int]
@@ -35,10 +60,44 @@ class Request:
     additional_information: Optional[dict] = None
     num_computed_tokens: int = 0
     output_token_ids: list[int] = field(default_factory=list)
+    status: RequestStatus = RequestStatus.WAITING
+    eos_token_id: Optional[int] = None
+    client_index: int = 0
+    stop_reason: Optional[int] = None
+    num_cached_tokens: int = -1          # tokens served by the prefix cache at first scheduling (-1 = not scheduled yet)
+    num_preemptions: int = 0
+    arrival_time: float = 0.0
+    external_req_id: Optional[str] = None
+
+    @property
+    def num_prompt_tokens(self) -> int:
+        # upstream's length_from_prompt_token_ids_or_embeds: a prompt may come as embeddings only
+        if self.prompt_token_ids:
+            return len(self.prompt_token_ids)
+        return int(self.prompt_embeds.shape[0]) if self.prompt_embeds is not None else 0
+
+    @property
+    def num_output_tokens(self) -> int:
+        return len(self.output_token_ids)
 
     @property
     def num_tokens(self) -> int:
-        return len(self.prompt_token_ids) + len(self.output_token_ids)
+        return self.num_prompt_tokens + len(self.output_token_ids)
+
+    @property
+    def all_token_ids(self) -> list[int]:
+        prompt = self.prompt_token_ids if self.prompt_token_ids else [0] * self.num_prompt_tokens
+        return list(prompt) + list(self.output_token_ids)
+
+    @property
+    def max_tokens(self) -> int:
+        return int(self.sampling_params.max_tokens)
+
+    def is_finished(self) -> bool:
+        return RequestStatus.is_finished(self.status)
+
+    def get_finished_reason(self) -> Optional[str]:
+        return _FINISH_REASON.get(self.status)
 
 
 @dataclass
@@ -96,3 +155,28 @@ class OmniModelRunnerOutput:
 
 
 EMPTY_MODEL_RUNNER_OUTPUT = OmniModelRunnerOutput([], {}, [], [])
+
+
+@dataclass
+class EngineCoreOutput:
+    """One request's share of a step, as the scheduler reports it to the engine (the fields of upstream's
+    ``EngineCoreOutput`` the reference fills, omni_ar_scheduler.py:286-292,416-432)."""
+
+    request_id: str
+    new_token_ids: list[int]
+    finish_reason: Optional[str] = None
+    stop_reason: Optional[int] = None
+    pooling_output: Optional[dict] = None
+    kv_transfer_params: Optional[dict] = None
+    num_cached_tokens: int = 0
+
+    @property
+    def finished(self) -> bool:
+        return self.finish_reason is not None
+
+
+@dataclass
+class EngineCoreOutputs:
+    outputs: list[EngineCoreOutput] = field(default_factory=list)
+    finished_requests: Optional[set[str]] = None
+    scheduler_stats: Optional[dict] = None

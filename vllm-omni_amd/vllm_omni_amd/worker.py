@@ -38,6 +38,12 @@ class WorkerConfig:
     seed: int = 0
     quantization: Optional[str] = None        # None | "int8" (W8A8 decoder linears, int8_config.py)
     dp_local_rank: int = 0                    # parallel_config.data_parallel_rank_local (gpu_ar_worker.py:40-60)
+    # when the launcher already hands every worker its device index the DP offset must NOT be applied
+    # (gpu_ar_worker.py:34-38: executor backend "ray" / "external_launcher", a ray DP backend, DP across nodes)
+    distributed_executor_backend: Optional[str] = None
+    data_parallel_backend: Optional[str] = None
+    nnodes_within_dp: int = 1
+    enable_prefix_caching: bool = False       # cache_config.enable_prefix_caching: builds OmniTensorPrefixCache (A14)
     max_reply_rows: int = 0                   # device pool of thinker_reply_part rows; 0 = max_num_seqs * 64
     code_predictor: object = None             # CodePredictorConfig for the Qwen3-Omni talker_mtp step
 
@@ -65,8 +71,6 @@ class GPUARWorker:
             raise TypeError("GPUARWorker needs a VllmConfig-shaped object (model_config / cache_config / "
                             f"parallel_config / scheduler_config) or a WorkerConfig, got {type(vllm_config).__name__}")
         self.config = config
-        # DP_LOCAL_RANK * TP_PP_WORLD_SIZE + TP_LOCAL_RANK (gpu_ar_worker.py:40-60)
-        local_rank += config.dp_local_rank * config.tensor_parallel_size
         self.local_rank = local_rank
         self.rank = rank
         self.distributed_init_method = distributed_init_method
@@ -77,12 +81,24 @@ class GPUARWorker:
         self.total_bytes = 0
         self._profiler = None
 
+    def dp_adjusted_local_rank(self) -> int:
+        """``DP_LOCAL_RANK * TP_PP_WORLD_SIZE + TP_LOCAL_RANK`` — applied in ``init_device`` and only under the
+        reference's condition (gpu_ar_worker.py:34-49): not when ray / an external launcher (torchrun) already
+        gave this worker its device index, not with a ray DP backend, not when DP spans nodes.  (Pipeline
+        parallelism is refused by ``compat``, so TP_PP_WORLD_SIZE is the TP size.)"""
+        c = self.config
+        if (c.distributed_executor_backend in ("ray", "external_launcher") or c.data_parallel_backend == "ray"
+                or c.nnodes_within_dp != 1):
+            return self.local_rank
+        return self.local_rank + c.dp_local_rank * c.tensor_parallel_size
+
     def init_device(self) -> None:
         if self.config.device_type != "cuda":
             # the reference refuses anything else the same way (gpu_ar_worker.py:89-90)
             raise RuntimeError(f"Not support device type: {self.config.device_type}")
         if not torch.cuda.is_available():
             raise RuntimeError("Not support device type: no ROCm GPU visible (the HIP kernels have no CPU path)")
+        self.local_rank = self.dp_adjusted_local_rank()
         if self.local_rank >= torch.cuda.device_count():
             raise RuntimeError(f"DP adjusted local rank {self.local_rank} is out of bounds "
                                f"({torch.cuda.device_count()} visible devices)")
@@ -104,7 +120,7 @@ class GPUARWorker:
             enforce_eager=self.config.enforce_eager, engine_output_type=self.config.engine_output_type,
             seed=self.config.seed, quantization=self.config.quantization,
             max_reply_rows=self.config.max_reply_rows or self.config.max_num_seqs * 64,
-            code_predictor=self.config.code_predictor)
+            code_predictor=self.config.code_predictor, enable_prefix_caching=self.config.enable_prefix_caching)
 
     def load_model(self, weights=None) -> None:
         """Build the model on the device; ``weights`` (an iterable of ``(checkpoint name, tensor)``, e.g. a
