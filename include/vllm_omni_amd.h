@@ -470,6 +470,12 @@ int mi_linear_silu_mul(void* out, const void* x, const void* weight, int32_t m, 
  *       of calls (same count).  MI_ERR_WORKSPACE if the message exceeds max_bytes.
  *   mi_allreduce_status           host-side, synchronising: MI_ERR_STATE once any
  *       spin has timed out (sticky).
+ *   mi_allreduce_poll             the same answer WITHOUT a device round trip: the
+ *       kernel mirrors the status into a host-mapped pinned word; it covers the
+ *       launches that had completed when the caller last synchronised (the runner
+ *       polls right after the event wait of a step's device->host output copy).
+ *       After a timeout the communicator is dead: mi_allreduce_run returns
+ *       MI_ERR_STATE (this rank's call counters are out of step with its peers').
  *   mi_allreduce_destroy          closes the peer mappings, frees the region.
  * ---------------------------------------------------------------------- */
 #define MI_ALLREDUCE_MAX_RANKS 8
@@ -481,6 +487,7 @@ int mi_allreduce_register_buffer(mi_allreduce* ar, const void* ipc_handles);
 int mi_allreduce_run(mi_allreduce* ar, void* out, const void* in, int64_t count, int32_t split,
                      const void* bias, int64_t cols, int dtype, void* stream);
 int mi_allreduce_status(mi_allreduce* ar);
+int mi_allreduce_poll(mi_allreduce* ar);
 int mi_allreduce_destroy(mi_allreduce* ar);
 
 /* ------------------------------------------------------------------------

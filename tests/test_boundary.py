@@ -223,6 +223,26 @@ def test_moe_checkpoint_expert_tensors_fill_the_stacked_parameters():
     for (na, wa), (_, wb) in zip(a.named_weights(), b.named_weights()):
         assert torch.equal(wa, wb), na
 
+    # a released Qwen3-Omni talker checkpoint also carries the thinker->talker resize MLPs and the code predictor
+    # (hf_to_vllm_mapper, qwen3_omni_moe_talker.py:83-98): the former are the stage-input processor's (skipped by name
+    # and recorded), the latter has its own loader — neither may raise or land in a decoder parameter
+    c = Talker(cfg, torch.bfloat16, torch.device("cpu"), seed=2)
+
+    def full_checkpoint():
+        yield "talker.text_projection.linear_fc1.weight", torch.zeros(4, 4)
+        yield "talker.text_projection.linear_fc1.bias", torch.zeros(4)
+        yield "talker.hidden_projection.linear_fc2.weight", torch.zeros(4, 4)
+        yield "talker.code_predictor.model.codec_embedding.0.weight", torch.zeros(4, 4)
+        yield "thinker.model.layers.0.self_attn.q_proj.weight", torch.zeros(4, 4)
+        yield "code2wav.decoder.0.weight", torch.zeros(4)
+        yield from stream()
+
+    assert c.load_weights(full_checkpoint()) == set(fused.keys())
+    assert c.skipped_weights == ["talker.text_projection.linear_fc1.weight", "talker.text_projection.linear_fc1.bias",
+                                 "talker.hidden_projection.linear_fc2.weight"]
+    for (na, wa), (_, wc) in zip(a.named_weights(), c.named_weights()):
+        assert torch.equal(wa, wc), na
+
 
 def test_upstream_scheduler_output_is_normalised():
     """Upstream field names, msgspec-style payloads (engine/__init__.py:16-57), `resumed_from_preemption` flags,

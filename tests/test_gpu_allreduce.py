@@ -149,3 +149,67 @@ def test_two_shot_all_reduce_bit_exact(world):
             if p.is_alive():
                 p.kill()
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _late_peer_worker(rank, world, port, q):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "vllm-omni_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import torch.distributed as dist
+
+        from vllm_omni_amd import _C, distributed as D
+
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        D.init_distributed_environment(world, rank, world, backend="gloo", init_method=f"tcp://127.0.0.1:{port}")
+        assert D.enable_custom_all_reduce(dev, max_bytes=1 << 20, timeout_ms=300)
+        ar = D.get_parallel_state().custom_ar
+        x = _rank_input(rank, 0, (8, 64), torch.bfloat16).to(dev)
+        ar.all_reduce(x)
+        torch.cuda.synchronize()
+        ar.poll()                                    # healthy: no raise, no device round trip
+        assert torch.equal(x.cpu(), _expected(world, 0, (8, 64), torch.bfloat16))
+        for turn in range(world):                    # each rank in turn launches an all-reduce its peers never join
+            dist.barrier()
+            if rank == turn:
+                out = torch.full((8, 64), 7.0, dtype=torch.bfloat16, device=dev)
+                ar.all_reduce(_rank_input(rank, 1, (8, 64), torch.bfloat16).to(dev), out)
+                torch.cuda.synchronize()             # returns: the spin is bounded (0.3 s), the kernel skipped its phases
+                with pytest.raises(RuntimeError, match="did not arrive"):
+                    ar.poll()                        # ... and said so where the host can see it without a copy
+                assert ar.dead
+                with pytest.raises(_C.MIError) as ei:   # the communicator is dead: no further launch
+                    ar.all_reduce(out)
+                assert ei.value.code == _C.MI_ERR_STATE
+        dist.barrier()
+        D.destroy_distributed_environment()          # dead communicators skip the pre-close barrier
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()[-1800:]))
+
+
+@pytest.mark.timeout(300)
+def test_late_peer_is_reported_at_the_step_sync_point_not_silently():
+    """A peer that never joins an all-reduce: the bounded spin ends the kernel with its output unwritten; the status
+    mirrored into host-mapped memory makes ``poll()`` (what the runner calls after each step's output copy) raise, and
+    the communicator refuses further launches (no silent garbage with VLLM_OMNI_AMD_ALLREDUCE=custom)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=200))
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

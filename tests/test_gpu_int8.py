@@ -154,6 +154,32 @@ def test_tiled_int8_gated_equals_unfused_pair(dev, m, inter, k):
     assert bool(((fused.float() - unfused.float()).abs() <= tol).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1024), (1300, 3584, 3584), (513, 64, 128)])
+def test_int8_prefill_rows_run_the_tiled_kernel_in_row_blocks(dev, M, N, K, monkeypatch):
+    """More rows than one launch of the tiled kernel takes (every prefill chunk): ops.int8_linear runs it over blocks of
+    512 rows, the gated form likewise — bit-identical to the simple kernel / the unfused pair, and never the simple
+    kernel itself."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 2).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
+    wq, ws = ops.dynamic_int8_quant(w)
+    xq, xs = ops.dynamic_int8_quant(x)
+    simple = ops.int8_gemm_dequant(xq, xs, wq, ws, b, torch.bfloat16)
+    calls = []
+    real = ops.int8_linear_q
+    monkeypatch.setattr(ops, "int8_linear_q", lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1])
+    monkeypatch.setattr(ops, "int8_gemm_dequant", lambda *a, **k: pytest.fail("simple kernel used for a prefill chunk"))
+    got = ops.int8_linear(x, wq, ws, b)
+    assert torch.equal(got, simple) and sum(calls) == M and max(calls) <= 512
+    if N % 32 == 0:
+        fused = ops.int8_linear_silu_mul(x, wq, ws)
+        one = torch.cat([ops.int8_linear_silu_mul(x[r:r + 512], wq, ws) for r in range(0, M, 512)])
+        assert torch.equal(fused, one)
+
+
 def test_int8_linear_paths_agree(dev, monkeypatch):
     """ops.int8_linear: tiled kernel (default), simple MFMA kernel, library contraction + dequant: identical."""
     from vllm_omni_amd import ops

@@ -26,7 +26,10 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     shapes = [("S-A qkv", 256, 4608, 3584), ("S-A o", 256, 3584, 3584), ("S-A gate_up", 256, 37888, 3584),
               ("S-A down", 256, 3584, 18944), ("S-B qkv", 512, 1280, 1024), ("S-B o", 512, 1024, 1024),
-              ("S-B gate_up(dense stand-in)", 512, 768, 1024), ("S-B down", 512, 1024, 384)]
+              ("S-B gate_up(dense stand-in)", 512, 768, 1024), ("S-B down", 512, 1024, 384),
+              # prefill chunks (more rows than one launch of the tiled kernel takes: run in 512-row blocks)
+              ("S-B qkv prefill", 2048, 1280, 1024), ("S-A qkv prefill", 2048, 4608, 3584),
+              ("S-A down prefill", 2048, 3584, 18944)]
     for name, m, n, k in shapes:
         copies = max(2, int(600e6 // (n * k * 2)))
         copies = min(copies, 16)
@@ -44,7 +47,9 @@ def main():
             "bf16 (product policy)": lambda: (ops.linear(x, ws16[nxt()]) if m <= 256 and ops.linear_supported(m, n, k, x.dtype)
                                               and k >= 8192 else F.linear(x, ws16[nxt()])),
             "int8 quant+tiled": lambda: ops.int8_linear(x, *q[nxt()]),
-            "int8 tiled GEMM only": lambda: ops.int8_linear_q(xq, xs, *q[nxt()], None, torch.bfloat16),
+            "int8 tiled GEMM only": lambda: (ops.int8_linear_q(xq, xs, *q[nxt()], None, torch.bfloat16) if m <= 512
+                                             else ops.int8_linear(ops.QuantizedActs(xq, xs, (m,), torch.bfloat16), *q[nxt()])),
+            "int8 simple MFMA kernel GEMM only": lambda: ops.int8_gemm_dequant(xq, xs, *q[nxt()], None, torch.bfloat16),
             "int8 library (_int_mm+dequant) GEMM only": lambda: ops.int8_dequant(torch._int_mm(xq, q[nxt()][0].t()), xs,
                                                                                  q[i[0]][1], None, torch.bfloat16),
         }

@@ -80,7 +80,8 @@ __device__ __forceinline__ void store_sys(rsrc_t r, int64_t vec, u32x4 v) {
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // All threads call.  `flag` is this call's value for barrier `k`.  Returns false on timeout.
-__device__ __forceinline__ bool exchange(const Peers& P, int k, int rank, int world, uint32_t flag, uint64_t timeout_ticks) {
+__device__ __forceinline__ bool exchange(const Peers& P, int k, int rank, int world, uint32_t flag, uint64_t timeout_ticks,
+                                         uint32_t* host_status) {
   wait_vm();            // this wave's payload stores have left
   __syncthreads();      // ... and every other wave's of the workgroup
   bool ok = true;
@@ -97,7 +98,12 @@ __device__ __forceinline__ bool exchange(const Peers& P, int k, int rank, int wo
       }
     }
     __scoped_atomic_thread_fence(__ATOMIC_ACQUIRE, __MEMORY_SCOPE_SYSTEM);
-    if (!ok) __scoped_atomic_store_n(&P.sig[rank]->status, 1u + (uint32_t)k, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
+    if (!ok) {
+      __scoped_atomic_store_n(&P.sig[rank]->status, 1u + (uint32_t)k, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
+      // the same word in host-mapped pinned memory: the host reads it at a synchronisation point it already has
+      // (mi_allreduce_poll) instead of paying a device->host copy per step
+      __scoped_atomic_store_n(host_status, 1u + (uint32_t)k, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
+    }
   }
   return __syncthreads_and(ok);
 }
@@ -123,7 +129,7 @@ template <typename Tag>
 __global__ __launch_bounds__(kThreads) void two_shot_kernel(Peers P, void* __restrict__ out, const void* __restrict__ in,
                                                             const void* __restrict__ bias, int split, int64_t cols,
                                                             int64_t nvec, int64_t part, int64_t buf_bytes, int rank,
-                                                            int world, uint64_t timeout_ticks) {
+                                                            int world, uint64_t timeout_ticks, uint32_t* host_status) {
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   const uint32_t base = P.sig[rank]->counter[blockIdx.x];   // plain: only this workgroup ever writes it
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void two_shot_kernel(Peers P, void* __res
       store_sys(stage, v, x);
     }
   }
-  bool ok = exchange(P, 0, rank, world, base + 1, timeout_ticks);
+  bool ok = exchange(P, 0, rank, world, base + 1, timeout_ticks, host_status);
   // ---- phase 1: reduce my slice over all ranks, rank order ----
   if (ok) {
     const rsrc_t tmp = make_rsrc(P.tmp[rank], buf_bytes);
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void two_shot_kernel(Peers P, void* __res
         if (r < world) acc8<Tag>(a, x[r]);
       store_sys(tmp, idx, pack8<Tag>(a));
     }
-    ok = exchange(P, 1, rank, world, base + 1, timeout_ticks);
+    ok = exchange(P, 1, rank, world, base + 1, timeout_ticks, host_status);
   }
   // ---- phase 2: gather every rank's reduced slice ----
   if (ok) {
@@ -201,6 +207,8 @@ struct mi_allreduce {
   bool opened[MI_ALLREDUCE_MAX_RANKS] = {};
   mi::Peers peers = {};
   bool connected = false;
+  uint32_t* host_status = nullptr;        // host-mapped pinned word, written by the kernel when a spin times out
+  uint32_t* host_status_dev = nullptr;    // its device address
 };
 
 static int64_t region_bytes(int64_t max_bytes) { return (int64_t)sizeof(mi::Signal) + 2 * max_bytes; }
@@ -224,9 +232,22 @@ extern "C" int mi_allreduce_init(mi_allreduce** out, int32_t rank, int32_t world
     return MI_ERR_EXHAUSTED;
   }
   ar->region = static_cast<uint8_t*>(p);
+  void* hs = nullptr;
+  void* hs_dev = nullptr;
+  if (hipHostMalloc(&hs, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(&hs_dev, hs, 0) != hipSuccess) {
+    if (hs) (void)hipHostFree(hs);
+    (void)hipFree(p);
+    delete ar;
+    return MI_ERR_EXHAUSTED;
+  }
+  ar->host_status = static_cast<uint32_t*>(hs);
+  ar->host_status_dev = static_cast<uint32_t*>(hs_dev);
+  *ar->host_status = 0;
   if (hipMemset(p, 0, sizeof(mi::Signal)) != hipSuccess ||
       hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(ipc_handle_out), p) != hipSuccess) {
     (void)hipFree(p);
+    (void)hipHostFree(hs);
     delete ar;
     return MI_ERR_STATE;
   }
@@ -260,6 +281,9 @@ extern "C" int mi_allreduce_run(mi_allreduce* ar, void* out, const void* in, int
   using namespace mi;
   if (!ar || !out || !in || count < 0 || split < 0) return MI_ERR_INVALID_ARG;
   if (!ar->connected) return MI_ERR_STATE;
+  // a spin has timed out before: this rank's call counters are out of step with its peers' for good — the
+  // communicator is dead, further launches would return garbage
+  if (__atomic_load_n(ar->host_status, __ATOMIC_RELAXED) != 0) return MI_ERR_STATE;
   if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
   if (count == 0) return MI_OK;
   if (count % 8 || ((uintptr_t)out & 15) || ((uintptr_t)in & 15)) return MI_ERR_INVALID_ARG;
@@ -275,10 +299,10 @@ extern "C" int mi_allreduce_run(mi_allreduce* ar, void* out, const void* in, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == MI_DTYPE_BF16)
     two_shot_kernel<bf16_tag><<<blocks, kThreads, 0, s>>>(ar->peers, out, in, bias, split, cols, nvec, part, ar->max_bytes,
-                                                          ar->rank, ar->world, ticks);
+                                                          ar->rank, ar->world, ticks, ar->host_status_dev);
   else
     two_shot_kernel<f16_tag><<<blocks, kThreads, 0, s>>>(ar->peers, out, in, bias, split, cols, nvec, part, ar->max_bytes,
-                                                         ar->rank, ar->world, ticks);
+                                                         ar->rank, ar->world, ticks, ar->host_status_dev);
   return launch_status();
 }
 
@@ -290,11 +314,17 @@ extern "C" int mi_allreduce_status(mi_allreduce* ar) {
   return st == 0 ? MI_OK : MI_ERR_STATE;
 }
 
+extern "C" int mi_allreduce_poll(mi_allreduce* ar) {
+  if (!ar || !ar->host_status) return MI_ERR_INVALID_ARG;
+  return __atomic_load_n(ar->host_status, __ATOMIC_ACQUIRE) == 0 ? MI_OK : MI_ERR_STATE;
+}
+
 extern "C" int mi_allreduce_destroy(mi_allreduce* ar) {
   if (!ar) return MI_OK;
   for (int r = 0; r < ar->world; ++r)
     if (ar->opened[r]) (void)hipIpcCloseMemHandle(ar->peer_base[r]);
   if (ar->region) (void)hipFree(ar->region);
+  if (ar->host_status) (void)hipHostFree(ar->host_status);
   delete ar;
   return MI_OK;
 }

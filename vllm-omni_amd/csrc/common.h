@@ -105,7 +105,7 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
 // non-volatile form was, and read lanes that had already exited — run-to-run differences in the tests).
 // Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) treats the two results of
 // the builtin as one value (it dropped the v_max / emitted `v_add v1, v1, v1` after the swap — wrong
-// results on hardware, tools/scratch/plt.hip).  `s_nop 1`: the wait states hipcc itself puts
+// results on hardware).  `s_nop 1`: the wait states hipcc itself puts
 // between a VALU write of an operand and the swap.
 __device__ __forceinline__ void permlane32_swap(float& a, float& b) {  // a[32..63] <-> b[0..31]
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));

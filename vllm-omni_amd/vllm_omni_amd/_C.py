@@ -95,6 +95,7 @@ SIGNATURES = {
     "mi_allreduce_register_buffer": (c_int, [_P, _P]),
     "mi_allreduce_run": (c_int, [_P, _P, _P, c_int64, c_int32, _P, c_int64, c_int, _P]),
     "mi_allreduce_status": (c_int, [_P]),
+    "mi_allreduce_poll": (c_int, [_P]),
     "mi_allreduce_destroy": (c_int, [_P]),
     "mi_blockpool_create": (_P, [c_int32]),
     "mi_blockpool_destroy": (None, [_P]),

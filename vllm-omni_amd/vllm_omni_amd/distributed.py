@@ -97,6 +97,7 @@ class CustomAllReduce:
 
         self._C, self.lib = _C, _C.lib
         self.rank, self.world, self.device, self.max_bytes = tp_rank, tp_size, device, int(max_bytes)
+        self.dead = False
         self._h = ctypes.c_void_p()
         mine = (ctypes.c_ubyte * _C.MI_ALLREDUCE_HANDLE_BYTES)()
         with torch.cuda.device(device):
@@ -134,6 +135,17 @@ class CustomAllReduce:
         """Synchronising health check: raises once any spin has timed out (a peer never arrived)."""
         self._C.check("mi_allreduce_status", self.lib.mi_allreduce_status(self._h))
 
+    def poll(self) -> None:
+        """Health check without a device round trip (``mi_allreduce_poll``: the kernel mirrors its sticky status word
+        into host-mapped pinned memory).  Covers every launch that had completed at the caller's last synchronisation
+        point — the runner calls it right after the event wait of a step's device->host output copy, so a timed-out
+        all-reduce (whose output was never written) raises BEFORE that step's tokens reach the scheduler.  After a
+        timeout the communicator is dead: the peers' call counters no longer match, ``mi_allreduce_run`` refuses."""
+        if self.lib.mi_allreduce_poll(self._h) != self._C.MI_OK:
+            self.dead = True
+            raise RuntimeError("in-tree all-reduce: a peer did not arrive within the timeout; this step's hidden states "
+                               "are invalid and the communicator is dead (restart the TP group)")
+
     def close(self) -> None:
         if self._h:
             self.lib.mi_allreduce_destroy(self._h)
@@ -168,6 +180,12 @@ def simulate_tensor_parallel_rank(tp_size: int, tp_rank: int = 0) -> ParallelSta
 def destroy_distributed_environment() -> None:
     global _STATE
     if _STATE.custom_ar is not None:
+        # no rank may free its shared region while a peer can still be reading it in phase 2 of a launch: drain this
+        # rank's queue, then meet the others, THEN unmap / free
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist.is_initialized() and not getattr(_STATE.custom_ar, "dead", False):
+            dist.barrier(group=_STATE.tp_group)
         _STATE.custom_ar.close()
     _STATE = ParallelState()
     if dist.is_initialized():

@@ -299,7 +299,7 @@ def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
     weights only; under TP a rank's weight is [gate shard; up shard], the layout the kernel expects."""
     if isinstance(x, ops.QuantizedActs):
         n2, k = layer.qweight.shape
-        if layer.bias is None and n2 % 32 == 0 and ops.int8_linear_supported(x.xq.shape[0], n2 // 2, k):
+        if layer.bias is None and n2 % 32 == 0 and ops.int8_linear_supported(min(x.xq.shape[0], ops.INT8_TILE_ROWS), n2 // 2, k):
             return ops.int8_linear_silu_mul(x, layer.qweight, layer.weight_scale)
         return None
     if layer.bias is not None or getattr(layer, "gather_output", False) or not x.is_cuda:
@@ -307,7 +307,8 @@ def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
     if getattr(layer, "qweight", None) is not None:   # W8A8: the gated form of the tiled int8 kernel
         m = x.numel() // x.shape[-1]
         n2, k = layer.qweight.shape
-        if n2 % 32 == 0 and ops.int8_linear_supported(m, n2 // 2, k) and os.environ.get("VLLM_OMNI_AMD_INT8", "kernel") == "kernel":
+        if (n2 % 32 == 0 and ops.int8_linear_supported(min(m, ops.INT8_TILE_ROWS), n2 // 2, k)
+                and os.environ.get("VLLM_OMNI_AMD_INT8", "kernel") == "kernel"):
             return ops.int8_linear_silu_mul(x, layer.qweight, layer.weight_scale)
         return None
     if _LINEAR_MODE == "library":

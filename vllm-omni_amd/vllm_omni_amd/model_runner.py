@@ -1045,6 +1045,11 @@ class GPUARModelRunner:
         n = st.num_reqs
         if self._out_done is not None:
             self._out_done[slot].synchronize()
+        # the step's kernels have completed: an in-tree all-reduce whose peer never arrived left its output unwritten
+        # and said so in a host-mapped status word — raise before these tokens / hidden states reach the scheduler
+        ar = getattr(self.parallel, "custom_ar", None)
+        if ar is not None:
+            ar.poll()
         ids_np = self._out_ids_cpu[slot][:n].numpy().copy()
         ib = self.input_batch
         # bookkeeping: last token per row feeds the next step's embedding lookup.  Rows are addressed by request

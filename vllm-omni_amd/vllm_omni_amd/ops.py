@@ -527,9 +527,12 @@ def linear_silu_mul(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
 
 
 
+INT8_TILE_ROWS = 512   # rows one launch of the tiled W8A8 kernel takes
+
+
 def int8_linear_supported(m: int, n: int, k: int) -> bool:
-    """Shape envelope of the tiled W8A8 kernel (csrc/skinny_gemm.hip on int8 rows)."""
-    return 0 < m <= 512 and k % 128 == 0 and n % 16 == 0 and k > 0
+    """Shape envelope of ONE launch of the tiled W8A8 kernel (csrc/skinny_gemm.hip on int8 rows)."""
+    return 0 < m <= INT8_TILE_ROWS and k % 128 == 0 and n % 16 == 0 and k > 0
 
 
 def int8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -548,24 +551,40 @@ def int8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: 
     m, k = xq.shape
     n = wq.shape[0]
     mode = os.environ.get("VLLM_OMNI_AMD_INT8", "kernel")
-    if mode == "library" and m > 16 and k % 8 == 0 and n % 8 == 0:
+    lib_ok = m > 16 and k % 8 == 0 and n % 8 == 0
+    if mode == "library" and lib_ok:
         y = int8_dequant(torch._int_mm(xq, wq.t()), xs, w_scale, bias, dtype)
-    elif mode != "simple" and int8_linear_supported(m, n, k):
-        y = int8_linear_q(xq, xs, wq, w_scale, bias, dtype)
+    elif mode != "simple" and int8_linear_supported(min(m, INT8_TILE_ROWS), n, k):
+        if m <= INT8_TILE_ROWS:
+            y = int8_linear_q(xq, xs, wq, w_scale, bias, dtype)
+        else:
+            # more rows than the tiled kernel takes (every prefill chunk): the same kernel over blocks of 512 rows —
+            # the rows of a GEMM are independent, so the result is bit-identical to one launch
+            y = torch.empty(m, n, dtype=dtype, device=xq.device)
+            for r0 in range(0, m, INT8_TILE_ROWS):
+                r1 = min(r0 + INT8_TILE_ROWS, m)
+                int8_linear_q(xq[r0:r1], xs[r0:r1], wq, w_scale, bias, dtype, out=y[r0:r1])
+    elif mode != "simple" and lib_ok:
+        # outside the tiled kernel's envelope (k not a multiple of 128, n not of 16): the library contraction with the
+        # in-tree dequantisation epilogue; the simple MFMA kernel (3-5x slower at 512 rows) is the last resort only
+        y = int8_dequant(torch._int_mm(xq, wq.t()), xs, w_scale, bias, dtype)
     else:
         y = int8_gemm_dequant(xq, xs, wq, w_scale, bias, dtype)
     return y.view(*lead, n)
 
 
 def int8_linear_q(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor,
-                  bias: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+                  bias: Optional[torch.Tensor], out_dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The tiled W8A8 kernel on already-quantised activations (xq int8 [m, k], xs fp32 [m])."""
-    _gpu(xq, xs, wq, w_scale, bias)
+    _gpu(xq, xs, wq, w_scale, bias, out)
     m, k = xq.shape
     n = wq.shape[0]
     if wq.shape[1] != k or not wq.is_contiguous() or xq.stride(1) != 1:
         raise ValueError("wq must be a contiguous int8 [n, k] tensor; xq rows must be contiguous")
-    out = torch.empty(m, n, dtype=out_dtype, device=xq.device)
+    if out is None:
+        out = torch.empty(m, n, dtype=out_dtype, device=xq.device)
+    elif out.shape != (m, n) or out.dtype != out_dtype or out.stride(1) != 1:
+        raise ValueError("out must be an [m, n] tensor of out_dtype with contiguous rows")
     need = lib.mi_int8_linear_workspace_bytes(m, n, k)
     ws = _linear_workspace(xq.device, need) if need else None
     check("mi_int8_linear", lib.mi_int8_linear(_p(out), _p(xq), _p(xs), _p(wq), _p(w_scale), _p(bias), m, n, k,
@@ -655,8 +674,11 @@ def int8_linear_silu_mul(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tenso
     m, k = xq.shape
     inter = wq.shape[0] // 2
     out = torch.empty(m, inter, dtype=dtype, device=xq.device)
-    check("mi_int8_linear_silu_mul", lib.mi_int8_linear_silu_mul(_p(out), _p(xq), _p(xs), _p(wq), _p(w_scale), m, inter, k,
-                                                                 xq.stride(0), out.stride(0), _dt(dtype), _stream()))
+    for r0 in range(0, m, INT8_TILE_ROWS):   # one launch per 512 rows (prefill chunks): rows are independent
+        r1 = min(r0 + INT8_TILE_ROWS, m)
+        check("mi_int8_linear_silu_mul", lib.mi_int8_linear_silu_mul(
+            _p(out[r0:r1]), _p(xq[r0:r1]), _p(xs[r0:r1]), _p(wq), _p(w_scale), r1 - r0, inter, k, xq.stride(0),
+            out.stride(0), _dt(dtype), _stream()))
     return out.view(*lead, inter)
 
 

@@ -380,6 +380,13 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
         ("talker.", ""),
     )
     skip_prefixes = ("thinker.", "token2wav.", "code2wav.", "code_predictor.", "talker.code_predictor.")
+    # Qwen3-Omni talker checkpoints also hold the two resize MLPs that turn THINKER outputs into talker inputs
+    # (``text_projection`` / ``hidden_projection``, qwen3_omni_moe_talker.py:93-95,119-120): the reference's talker
+    # class owns them, but they run when the talker's prompt embeddings are built (thinker -> talker hand-over), before
+    # the decode path this package implements, whose inputs arrive as ``prompt_embeds`` / ``thinker_reply_part``
+    # already in the talker's hidden size.  They are skipped BY NAME and recorded in ``skipped_weights``.
+    stage_input_prefixes = ("talker.text_projection.", "talker.hidden_projection.", "text_projection.",
+                            "hidden_projection.")
     # (fused parameter, checkpoint shard, shard id): ``stacked_params_mapping`` of qwen2_old.py:328-336
     stacked_params_mapping = (
         ("qkv_proj", "q_proj", "q"), ("qkv_proj", "k_proj", "k"), ("qkv_proj", "v_proj", "v"),
@@ -388,6 +395,11 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
 
     def _map_checkpoint_name(self, name: str) -> Optional[str]:
         if name.startswith(self.skip_prefixes) or "rotary_emb.inv_freq" in name:
+            return None
+        if name.startswith(self.stage_input_prefixes):
+            if not hasattr(self, "skipped_weights"):
+                self.skipped_weights = []
+            self.skipped_weights.append(name)
             return None
         for old, new in self.hf_to_vllm_prefix:
             if name.startswith(old):
