@@ -155,10 +155,11 @@ def test_tiled_int8_gated_equals_unfused_pair(dev, m, inter, k):
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 1280, 1024), (1300, 3584, 3584), (513, 64, 128)])
-def test_int8_prefill_rows_run_the_tiled_kernel_in_row_blocks(dev, M, N, K, monkeypatch):
-    """More rows than one launch of the tiled kernel takes (every prefill chunk): ops.int8_linear runs it over blocks of
-    512 rows, the gated form likewise — bit-identical to the simple kernel / the unfused pair, and never the simple
-    kernel itself."""
+def test_int8_prefill_rows_never_fall_to_the_simple_kernel(dev, M, N, K, monkeypatch):
+    """More rows than one launch of the tiled kernel takes (every prefill chunk): ops.int8_linear takes the library
+    contraction + in-tree dequantisation (the measured policy), or — forced with VLLM_OMNI_AMD_INT8=tiled — the tiled
+    kernel over blocks of 512 rows; the gated form runs in row blocks.  Bit-identical to the simple kernel / the
+    unfused pair, and never the simple kernel itself."""
     from vllm_omni_amd import ops
 
     g = torch.Generator().manual_seed(M + N)
@@ -172,6 +173,9 @@ def test_int8_prefill_rows_run_the_tiled_kernel_in_row_blocks(dev, M, N, K, monk
     real = ops.int8_linear_q
     monkeypatch.setattr(ops, "int8_linear_q", lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1])
     monkeypatch.setattr(ops, "int8_gemm_dequant", lambda *a, **k: pytest.fail("simple kernel used for a prefill chunk"))
+    got = ops.int8_linear(x, wq, ws, b)
+    assert torch.equal(got, simple) and not calls              # library contraction + mi_int8_dequant
+    monkeypatch.setenv("VLLM_OMNI_AMD_INT8", "tiled")
     got = ops.int8_linear(x, wq, ws, b)
     assert torch.equal(got, simple) and sum(calls) == M and max(calls) <= 512
     if N % 32 == 0:

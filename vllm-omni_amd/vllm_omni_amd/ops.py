@@ -539,10 +539,11 @@ def int8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: 
     """W8A8 linear of the reference's scheme (vllm_omni/quantization/int8_config.py:323-342: dynamic symmetric
     per-token activation scale, per-output-channel weight scale): hand-written per-token quantisation kernel, then
     ONE launch of the tiled int8 kernel — LDS-DMA ring, `v_mfma_i32_16x16x64_i8`, dequantisation + bias in the
-    epilogue (``mi_int8_linear``; split-K shapes add its small reduce launch).  Shapes outside its envelope run the
-    simple MFMA kernel ``mi_int8_gemm_dequant``.  ``VLLM_OMNI_AMD_INT8=library`` routes the contraction to the
-    library instead (``torch._int_mm`` + ``mi_int8_dequant``: cross-check / A-B runs only).  Integer sums are exact
-    on every path, so all three agree bit for bit."""
+    epilogue (``mi_int8_linear``; split-K shapes add its small reduce launch).  Prefill chunks (more than 512 rows)
+    take the library contraction with the in-tree dequantisation epilogue (``torch._int_mm`` + ``mi_int8_dequant``),
+    tiny weights the simple MFMA kernel ``mi_int8_gemm_dequant`` — the measured policy is spelled out below;
+    ``VLLM_OMNI_AMD_INT8`` = ``library`` / ``simple`` / ``tiled`` forces one path (cross-checks, A/B runs).  Integer
+    sums are exact on every path, so all three agree bit for bit."""
     if isinstance(x, QuantizedActs):
         xq, xs, lead, dtype = x.xq, x.xs, x.lead, x.dtype
     else:
@@ -552,22 +553,27 @@ def int8_linear(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias: 
     n = wq.shape[0]
     mode = os.environ.get("VLLM_OMNI_AMD_INT8", "kernel")
     lib_ok = m > 16 and k % 8 == 0 and n % 8 == 0
+    tiled_ok = int8_linear_supported(min(m, INT8_TILE_ROWS), n, k)
+    # Policy from profiles/r03_int8_linear_bench.log (all paths give the same bits, so this is speed only):
+    #   <= 512 rows: the tiled kernel (24-48 us against 27-86 library, 33-263 simple at the S-A shapes, 256 rows) —
+    #      except weights of <= 2 M elements at >= 256 rows (the S-B attention / expert shapes), where the simple MFMA
+    #      kernel has less fixed cost (12.7 against 16.6 us);
+    #   more rows (prefill chunks): the library contraction + the in-tree dequantisation epilogue (60 / 163 us against
+    #      150 / 307 us for the tiled kernel run in 512-row blocks and 252 / 931 us for the simple kernel at 2048 rows);
+    #      the tiled kernel in row blocks where the library cannot take the shape; the simple kernel last.
     if mode == "library" and lib_ok:
         y = int8_dequant(torch._int_mm(xq, wq.t()), xs, w_scale, bias, dtype)
-    elif mode != "simple" and int8_linear_supported(min(m, INT8_TILE_ROWS), n, k):
-        if m <= INT8_TILE_ROWS:
-            y = int8_linear_q(xq, xs, wq, w_scale, bias, dtype)
-        else:
-            # more rows than the tiled kernel takes (every prefill chunk): the same kernel over blocks of 512 rows —
-            # the rows of a GEMM are independent, so the result is bit-identical to one launch
-            y = torch.empty(m, n, dtype=dtype, device=xq.device)
-            for r0 in range(0, m, INT8_TILE_ROWS):
-                r1 = min(r0 + INT8_TILE_ROWS, m)
-                int8_linear_q(xq[r0:r1], xs[r0:r1], wq, w_scale, bias, dtype, out=y[r0:r1])
-    elif mode != "simple" and lib_ok:
-        # outside the tiled kernel's envelope (k not a multiple of 128, n not of 16): the library contraction with the
-        # in-tree dequantisation epilogue; the simple MFMA kernel (3-5x slower at 512 rows) is the last resort only
+    elif mode == "simple":
+        y = int8_gemm_dequant(xq, xs, wq, w_scale, bias, dtype)
+    elif m <= INT8_TILE_ROWS and tiled_ok and not (m >= 256 and n * k <= (1 << 21) and mode != "tiled"):
+        y = int8_linear_q(xq, xs, wq, w_scale, bias, dtype)
+    elif m > INT8_TILE_ROWS and lib_ok and mode != "tiled":
         y = int8_dequant(torch._int_mm(xq, wq.t()), xs, w_scale, bias, dtype)
+    elif m > INT8_TILE_ROWS and tiled_ok:
+        y = torch.empty(m, n, dtype=dtype, device=xq.device)   # rows of a GEMM are independent: same bits as one launch
+        for r0 in range(0, m, INT8_TILE_ROWS):
+            r1 = min(r0 + INT8_TILE_ROWS, m)
+            int8_linear_q(xq[r0:r1], xs[r0:r1], wq, w_scale, bias, dtype, out=y[r0:r1])
     else:
         y = int8_gemm_dequant(xq, xs, wq, w_scale, bias, dtype)
     return y.view(*lead, n)
