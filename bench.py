@@ -67,8 +67,65 @@ def parse_args():
                     help="W8A8 decoder linears (BASELINE config #5 family; NOT the headline: the default line is bf16)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps for per-launch timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", default=os.environ.get("MI_BENCH_TRAFFIC", "pmc"), choices=["pmc", "recorded", "none"],
+                    help="roofline.traffic: 'pmc' = measure in THIS run (two child passes of this script under "
+                         "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, before the parent touches the GPU; N=1, "
+                         "headline workload only), 'recorded' = the figure kept in profiles/, 'none' = null")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled pass itself
     ap.add_argument("--cpu-baseline-batch", type=int, default=4)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.pmc_child:   # a few steps of the same workload, nothing else: the parent reads the counters of the decode launches
+        a.steps, a.warmup, a.no_cpu_baseline, a.roofline_steps, a.traffic = 2, 1, True, 0, "none"
+    return a
+
+
+def measure_decode_traffic_pmc(argv_tail: list, timeout_s: float = 170.0):
+    """HBM bytes per launch of the decode kernel from PMC counters, collected as MI355X_MICROARCH.md's HBM section
+    prescribes: two SEPARATE `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), no trace domains;
+    FETCH_SIZE / WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE reports exactly half the bytes of wide (16 B per lane)
+    coalesced streaming reads, so it is doubled; WRITE_SIZE is exact.  Each pass is a CHILD process running this script
+    (`--pmc-child`: 1 warm-up + 2 steps of the same workload); the parent has not touched the GPU yet.
+    Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    t0 = time.monotonic()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"mi_pmc_{counter.lower()}_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "-d", d, "-o", "run", "--output-format", "csv", "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child"] + argv_tail
+        try:
+            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                               timeout=timeout_s, cwd="/tmp")
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s:.0f} s"
+        if r.returncode != 0:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} pass exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
+        per_dispatch: dict = {}
+        for root, _, files in os.walk(d):
+            for f in files:
+                if f.endswith("counter_collection.csv"):
+                    with open(os.path.join(root, f)) as fh:
+                        for row in csv.DictReader(fh):
+                            if "decode_mfma_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                                k = row["Dispatch_Id"]
+                                per_dispatch[k] = per_dispatch.get(k, 0.0) + float(row["Counter_Value"])
+        shutil.rmtree(d, ignore_errors=True)
+        if not per_dispatch:
+            return None, f"no {counter} rows for the decode kernel"
+        got[counter] = (sum(per_dispatch.values()) / len(per_dispatch), len(per_dispatch))
+    hbm = int(2 * got["FETCH_SIZE"][0] * 1024 + got["WRITE_SIZE"][0] * 1024)
+    return hbm, (f"measured in this run: two child passes under rocprofv3 --pmc (FETCH_SIZE mean {got['FETCH_SIZE'][0]:.0f} KiB "
+                 f"over {got['FETCH_SIZE'][1]} decode launches, doubled per the guide's gfx950 correction; WRITE_SIZE mean "
+                 f"{got['WRITE_SIZE'][0]:.1f} KiB over {got['WRITE_SIZE'][1]}), {time.monotonic() - t0:.0f} s")
 
 
 def parallel_plan(n_gpus: int, cfg) -> tuple[int, int, str]:
@@ -391,6 +448,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # roofline.traffic, measured in this run: the profiled child passes go FIRST, while this process has not touched
+    # the GPU (they are ordinary child processes; nothing is exec'ed from a process that has initialised HIP)
+    pmc_traffic = (None, None)
+    if world == 1 and a.traffic == "pmc" and not a.pmc_child and not a.simulate_shard and a.roofline_steps > 0:
+        pmc_traffic = measure_decode_traffic_pmc([x for x in sys.argv[1:] if x != "--pmc-child"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # rehearsal mode for a 1-GPU box: every rank on cuda:0, collectives over gloo (functional check of
@@ -477,18 +539,25 @@ def main():
         attn = runner.model.language_model.model.layers[0].self_attn
         # unique KV bytes one launch must read: K+V, local kv heads, head_dim, 2 B, ctx tokens, local batch
         algo_bytes = 2 * attn.num_kv_heads * attn.head_dim * 2 * a.ctx * local_batch
+        if a.roofline_steps <= 0:
+            return {"bound": "hbm", "kernel": "mi::decode_mfma_kernel (paged-attention decode)", "achieved": None,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "algorithmic_bytes_per_launch": algo_bytes}
         kern_ms, launches = time_decode_launches(runner, a.roofline_steps)
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_decode_bytes_per_launch.json")
-        if os.path.exists(prof):
+        if pmc_traffic[0] is not None and tp == 1 and local_batch == a.batch:
+            traffic, traffic_src = pmc_traffic
+        elif a.traffic != "none" and os.path.exists(prof):
             try:
                 with open(prof) as f:
                     pj = json.load(f)
                 if pj.get("batch") == local_batch and pj.get("ctx") == a.ctx and pj.get("tp") == tp:
                     traffic = pj.get("hbm_bytes_per_launch")
                     traffic_src = ("NOT measured in this run: rocprofv3 --pmc pass of the same command, "
-                                   "profiles/pmc_decode_bytes_per_launch.json (" + str(pj.get("source", "")) + ")")
+                                   "profiles/pmc_decode_bytes_per_launch.json (" + str(pj.get("source", "")) + ")"
+                                   + ("" if pmc_traffic[1] is None else "; in-run measurement failed: " + str(pmc_traffic[1])))
             except Exception:
                 traffic = None
         return {"bound": "hbm", "kernel": "mi::decode_mfma_kernel (paged-attention decode)", "achieved": round(achieved, 1),
