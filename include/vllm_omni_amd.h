@@ -138,6 +138,13 @@ int mi_rope_neox_and_cache_splitk(void* q_out, const void* partials, int32_t spl
 #define MI_DECODE_FORCE_VALU 2
 #define MI_DECODE_NONTEMPORAL 4 /* nt cache policy on the K/V stream (matrix-core kernel) */
 #define MI_DECODE_ROUNDED_P 8
+/* MI_DECODE_FUSED_MERGE: the matrix-core kernel merges the context partitions inside its own launch (the wave of a
+ * (sequence, head group) that arrives last does it) instead of a second kernel — same bits.  The arrival counters
+ * are the FIRST MI_DECODE_COUNTER_BYTES of `workspace` (mi_paged_attn_decode_workspace_bytes includes them; the
+ * partial sums follow): with the flag the caller vouches that this region was zero before the first launch on the
+ * workspace; every launch leaves it at zero (hipGraph replays need nothing in between). */
+#define MI_DECODE_FUSED_MERGE 16
+#define MI_DECODE_COUNTER_BYTES (1 << 20)
 int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
                                              int32_t head_dim, int32_t max_seq_len,
                                              int32_t partition_size);

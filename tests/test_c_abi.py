@@ -69,7 +69,8 @@ def test_argument_validation_without_gpu():
                                     _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, 0, None) == _C.MI_ERR_INVALID_ARG
     assert lib.mi_paged_attn_decode(p, p, p, p, p, p, 2, 8, 2, 128, 12, 4, 64, 1.0, 1024, 1024, 8, 8, 8, 0, None, 0,
                                     _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, 0, None) == _C.MI_ERR_UNSUPPORTED
-    assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 512) == 256 * 28 * 8 * 130 * 4
+    # arrival counters of the fused merge (fixed region at the front) + fp32 (O, m, l) partials
+    assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 512) == _C.MI_DECODE_COUNTER_BYTES + 256 * 28 * 8 * 130 * 4
     assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 4096) == 0
     # longest partition <= 1024 leaving >= 512 waves, floor 256, never beyond the (rounded) context
     auto = lib.mi_paged_attn_decode_auto_partition

@@ -242,3 +242,61 @@ def test_decode_rejects_bad_arguments(dev):
                                         nq * d + 1, nq * d, kvg.stride(0), kvg.stride(2), kvg.stride(3), 16, None, 0,
                                         _C.MI_DTYPE_BF16, _C.MI_DTYPE_BF16, 0, None)
     assert code == _C.MI_ERR_INVALID_ARG
+
+
+def test_fused_merge_equals_the_two_kernel_merge_bit_for_bit(dev):
+    """The partitions merged inside the attention launch (last-arriving wave of each (sequence, head group), arrival
+    counters at the front of the workspace) against decode_reduce_kernel: identical bits — on ONE workspace reused by
+    launches of different batch sizes, partition sizes and context bounds (the counters must come back to zero every
+    time), with empty sequences in the batch, and replayed from a hipGraph while the sequences grow."""
+    from vllm_omni_amd import ops
+
+    nq, nkv, d, bs = 28, 4, 128, 16
+    lens_all = [1, 0, 130, 517, 64, 1000, 33, 0, 999, 256]
+    kv, kb, vb, table, q, seq_lens = _mk_case(len(lens_all), nq, nkv, d, bs, [max(n, 1) for n in lens_all],
+                                              torch.bfloat16, seed=21)
+    seq_lens = torch.tensor(lens_all, dtype=torch.int32)
+    kvg = kv.to(dev)
+    kbg, vbg = kvg[:, 0], kvg[:, 1]
+    ws = ops.new_decode_workspace(ops.decode_workspace_bytes(len(lens_all), nq, d, 2048, 32), dev)
+
+    def run(S, part, msl, out_dtype, fused, workspace):
+        out = torch.full((S, nq * d), float("nan"), dtype=out_dtype, device=dev)
+        ops.paged_attn_decode(out, q[:S].reshape(S, nq * d).to(dev), kbg, vbg, table[:S].to(dev), seq_lens[:S].to(dev),
+                              msl, d ** -0.5, partition_size=part, workspace=workspace, fused_merge=fused)
+        return out
+
+    for rep in range(3):
+        for S, part, msl in ((10, 256, 1024), (3, 32, 2048), (10, 64, 1000), (7, 1024, 2048), (10, 128, 1040)):
+            for out_dtype in (torch.float32, torch.bfloat16):
+                two = run(S, part, msl, out_dtype, False, None)
+                one = run(S, part, msl, out_dtype, True, ws)
+                torch.cuda.synchronize()
+                assert torch.equal(one, two), (rep, S, part, msl, out_dtype)
+                assert not torch.isnan(one.float()).any()
+                assert torch.equal(one[1], torch.zeros_like(one[1]))          # seq_len 0: zeros
+        counters = ws[:1 << 20].view(torch.int32)
+        assert int(counters.abs().sum()) == 0                                  # every launch left them at zero
+    with pytest.raises(ValueError, match="new_decode_workspace"):
+        run(3, 32, 2048, torch.float32, True, torch.empty(ws.numel(), dtype=torch.uint8, device=dev))
+    # hipGraph replay with growing sequences: same launch, new seq_lens
+    S, part, msl = 10, 256, 1024
+    sl = seq_lens.to(dev)
+    tb, qq = table.to(dev), q.reshape(len(lens_all), nq * d).to(dev)
+    out = torch.zeros(S, nq * d, dtype=torch.bfloat16, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.paged_attn_decode(out, qq, kbg, vbg, tb, sl, msl, d ** -0.5, partition_size=part, workspace=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.paged_attn_decode(out, qq, kbg, vbg, tb, sl, msl, d ** -0.5, partition_size=part, workspace=ws)
+    for step in range(4):
+        sl.copy_(torch.tensor([min(n + 7 * step, 1000) if n else 0 for n in lens_all], dtype=torch.int32))
+        g.replay()
+        torch.cuda.synchronize()
+        want = torch.zeros_like(out)
+        ops.paged_attn_decode(want, qq, kbg, vbg, tb, sl, msl, d ** -0.5, partition_size=part, fused_merge=False)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), step

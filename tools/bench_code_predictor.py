@@ -33,7 +33,13 @@ def timeit(fn, iters=10, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--no-tuned", action="store_true", help="library-default GEMM selections (the runner loads the tuned CSV)")
+    ap.add_argument("--skip-reprefill", action="store_true")
     a = ap.parse_args()
+    if not a.no_tuned:   # what GPUARModelRunner.load_model does before it builds the predictor
+        from vllm_omni_amd.tuned import enable_tuned_gemms
+
+        print("tuned GEMM selections loaded:", enable_tuned_gemms())
     dev = torch.device("cuda:0")
     cfg = CodePredictorConfig()
     b, g, h = a.batch, cfg.num_code_groups, cfg.hidden_size
@@ -57,7 +63,7 @@ def main():
             x = cp.proj_buf[:b].reshape(b * t, h).clone()
             full = cp._stack(x, pos, md).view(b, t, h)
             torch.nn.functional.linear(full[:, step], cp.lm_head[step - 1])
-    t_re = timeit(reprefill, iters=3, warm=1)
+    t_re = float("nan") if a.skip_reprefill else timeit(reprefill, iters=3, warm=1)
     print(f"code predictor, batch {b}, G = {g}: incremental eager {t_eager:.2f} ms | one hipGraph {t_graph:.2f} ms | "
           f"re-prefill schedule (transformer passes only) {t_re:.2f} ms")
 

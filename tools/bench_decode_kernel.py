@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--parts", default="0,256,512,1024,2048,4096")
     ap.add_argument("--modes", default="0,1,2", help="0 = exact fp32-P VALU, 1 = packed dot2 VALU, 2 = MFMA, 3 = MFMA + nt (production), "
                     "4 = MFMA + nt with the single-rounding P of round 2 (A/B)")
+    ap.add_argument("--two-kernels", action="store_true", help="merge the partitions with decode_reduce_kernel (A/B)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -52,8 +53,10 @@ def main():
         packed, force_valu, nt, rp = mode != 0, mode == 1, mode >= 3, mode == 4
         for ps in [int(x) for x in a.parts.split(",")]:
             eff = ops.decode_auto_partition(a.batch, a.nkv, a.ctx, a.bs, ps)
-            ws = torch.empty(max(1, ops.decode_workspace_bytes(a.batch, a.nq, a.d, a.ctx, eff)), dtype=torch.uint8,
-                             device=dev)
+            nbytes = max(1, ops.decode_workspace_bytes(a.batch, a.nq, a.d, a.ctx, eff))
+            # a prepared workspace = partitions merged inside the attention launch; --two-kernels: the separate merge
+            ws = (torch.empty(nbytes, dtype=torch.uint8, device=dev) if a.two_kernels
+                  else ops.new_decode_workspace(nbytes, dev))
             for _ in range(10):
                 ops.paged_attn_decode(out, q, kb, vb, table, seq_lens, a.ctx, a.d ** -0.5, partition_size=eff,
                                       workspace=ws, packed_pv=packed, force_valu=force_valu, nontemporal=nt, rounded_p=rp)

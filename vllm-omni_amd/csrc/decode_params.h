@@ -14,6 +14,9 @@ struct DecodeParams {
   const int32_t* seq_lens;
   float* part_o;   // [num_seqs, n_q, num_parts, HD]
   float* part_ml;  // [num_seqs, n_q, num_parts, 2]
+  // Fused merge (matrix-core kernel): arrival counters [num_seqs, n_q / heads_per_wave], zero before the FIRST launch
+  // and left at zero by every launch; nullptr = the partitions are merged by decode_reduce_kernel instead.
+  int32_t* part_count;
   int32_t num_seqs, num_q_heads, kv_group;  // kv_group = n_q / n_kv
   int32_t bs_log2, block_table_stride;
   int32_t num_parts, part_tiles;  // tiles (16 tokens) per partition

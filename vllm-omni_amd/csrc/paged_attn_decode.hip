@@ -456,7 +456,10 @@ extern "C" int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_
     return 0;
   const int64_t parts = (max_seq_len + partition_size - 1) / partition_size;
   if (parts <= 1) return 0;
-  return (int64_t)num_seqs * num_q_heads * parts * (head_dim + 2) * (int64_t)sizeof(float);
+  // the arrival counters of the fused merge (a region of FIXED size at the front, so that calls of different batch
+  // sizes and context bounds on one workspace never put partial sums where another call keeps its counters), then
+  // the partial (O, m, l) triples
+  return MI_DECODE_COUNTER_BYTES + (int64_t)num_seqs * num_q_heads * parts * (head_dim + 2) * (int64_t)sizeof(float);
 }
 
 extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cache,
@@ -511,8 +514,14 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   p.v_cache = v_cache;
   p.block_table = block_table;
   p.seq_lens = seq_lens;
-  p.part_o = reinterpret_cast<float*>(workspace);
+  p.part_o = need > 0 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + MI_DECODE_COUNTER_BYTES) : nullptr;
   p.part_ml = p.part_o ? p.part_o + (int64_t)num_seqs * num_q_heads * num_parts * head_dim : nullptr;
+  // only the matrix-core kernel merges in its own launch, and only when the caller vouches that the counter region
+  // was zero before the first launch on this workspace (MI_DECODE_FUSED_MERGE)
+  p.part_count = (p.part_ml && use_mfma && (flags & MI_DECODE_FUSED_MERGE) &&
+                  (int64_t)num_seqs * num_q_heads * (int64_t)sizeof(int32_t) <= MI_DECODE_COUNTER_BYTES)
+                     ? reinterpret_cast<int32_t*>(workspace)
+                     : nullptr;
   p.num_seqs = num_seqs;
   p.num_q_heads = num_q_heads;
   p.kv_group = kv_group;
@@ -548,6 +557,7 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
                          : dispatch_group<f16_tag, 64>(p, G, packed, s);
   }
   if (rc != MI_OK) return rc;
+  if (p.part_count) return MI_OK;   // merged inside the launch
   if (dtype == MI_DTYPE_BF16)
     return head_dim == 128 ? launch_reduce<bf16_tag, 128>(p, s) : launch_reduce<bf16_tag, 64>(p, s);
   return head_dim == 128 ? launch_reduce<f16_tag, 128>(p, s) : launch_reduce<f16_tag, 64>(p, s);

@@ -20,6 +20,12 @@
 //     (a k-slot permutation shared by both operands); V^T fragments come from the row-major V
 //     image through `ds_read_b64_tr_b16`.
 //   * O^T accumulates over all tokens of the wave inside the MFMA, so no end-of-wave merge.
+//   * Context partitions merge INSIDE this launch (MI_DECODE_FUSED_MERGE): every wave publishes its (m, l, O^T)
+//     partial, bumps an arrival counter of its (sequence, head group), and the wave that arrives LAST merges the
+//     group's partitions — the arithmetic of decode_reduce_kernel, lane for lane, so the result has the same bits —
+//     while the other workgroups are still streaming.  One launch less per layer, but measured SLOWER than the
+//     two-kernel form at every shape tried (391 against 363 us at B 256 / ctx 4096: each wave's tail gains a store
+//     acknowledge + an atomic round trip while it holds its LDS slot), so it is opt-in.
 // Numerics: fp32 scores/statistics/accumulators.  The MFMA's B operand is 16-bit, so P (fp32, in [0, 1])
 // is carried as TWO cache-dtype values, p = hi + lo with hi = rnd16(p), lo = rnd16(p - hi): 16 (bf16) /
 // 22 (f16) significant bits instead of 8 / 11, which is what brings this kernel inside north_star's
@@ -39,6 +45,14 @@ namespace mi {
 namespace {
 
 // AUX = cache-policy bits of the DMA loads (0 = default, 2 = nt: K/V bytes are read exactly once).
+// 16- / 8-byte stores with device (agent) coherence: sc1 = write through to the point the other XCDs' loads see
+__device__ __forceinline__ void store_agent_b128(float* p, f32x4_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_agent_b64(float* p, f32x2_t v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 template <typename Tag, int HD, int AUX, bool SPLIT>
 __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p, const int gh) {
   scalar_cache_acquire();
@@ -83,7 +97,9 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   float* const out32 = reinterpret_cast<float*>(p.out);
 
   if (t_begin >= t_end) {
-    if (direct && head_ok) {  // seq_len == 0: zeros
+    // Empty partition.  seq_len == 0 has no partition at all: the direct launch and, with the fused merge, the wave of
+    // partition 0 write the zeros (without the fused merge decode_reduce_kernel does).
+    if ((direct || (p.part_count && part == 0 && seq_len == 0)) && head_ok) {
       const int64_t o = (int64_t)seq * p.out_stride + (int64_t)(qh0 + h) * HD;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
@@ -312,8 +328,8 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 
   // ---- epilogue ---------------------------------------------------------------------------------
   l = rows_allreduce_sum(l);
-  if (!head_ok) return;
   if (direct) {
+    if (!head_ok) return;
     const float inv = 1.f / l;
     const int64_t o = (int64_t)seq * p.out_stride + (int64_t)(qh0 + h) * HD + 4 * g;
 #pragma unroll
@@ -328,13 +344,70 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
         *reinterpret_cast<uint2*>(out16 + o + 16 * n) = r;
       }
     }
-  } else {
+    return;
+  }
+  const bool fused = p.part_count != nullptr;
+  if (head_ok) {
     const int64_t slot = ((int64_t)seq * p.num_q_heads + (qh0 + h)) * p.num_parts + part;
     float* po = p.part_o + slot * HD + 4 * g;
+    if (fused) {
+      // device-coherent (sc1) stores: they go past this XCD's L2 to the coherence point themselves, so publishing
+      // them needs no L2 write-back — an agent-scope release FENCE here (buffer_wbl2 from every one of thousands of
+      // waves) cost 50 % of the kernel's time
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-      *reinterpret_cast<float4*>(po + 16 * n) = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
-    if (g == 0) *reinterpret_cast<float2*>(p.part_ml + slot * 2) = make_float2(m, l);
+      for (int n = 0; n < NT; ++n) store_agent_b128(po + 16 * n, acc[n]);
+      if (g == 0) store_agent_b64(p.part_ml + slot * 2, f32x2_t{m, l});
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        *reinterpret_cast<float4*>(po + 16 * n) = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+      if (g == 0) *reinterpret_cast<float2*>(p.part_ml + slot * 2) = make_float2(m, l);
+    }
+  }
+  if (!fused) return;   // merged by decode_reduce_kernel
+
+  // ---- fused merge: the wave of this (sequence, head group) that arrives last merges its partitions ------------
+  // Release: the partial stores above are device-coherent and COMPLETE (vmcnt(0): one wave = one instruction stream,
+  // the wait covers every lane's stores) before the counter moves.
+  wait_vmcnt<0>();
+  int32_t* const cnt = p.part_count + ((int64_t)seq * (p.num_q_heads / gh) + hw);
+  int arrived = 0;
+  if (lane == 0) arrived = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  arrived = __builtin_amdgcn_readfirstlane(arrived);
+  const int np = min(p.num_parts, (steps_total + part_steps - 1) / part_steps);   // partitions that hold tokens
+  if (arrived != np - 1) return;
+  // Acquire: every load below is a device-coherent (sc1) load issued after the counter's value came back, so no
+  // cache of this CU / XCD can serve a line older than the publishers' stores.
+  if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  constexpr int DPL = HD / 64;   // dims per lane, as in decode_reduce_kernel
+  for (int hh = 0; hh < gh; ++hh) {
+    const int qh = qh0 + hh;
+    const int64_t slot0 = ((int64_t)seq * p.num_q_heads + qh) * p.num_parts;
+    const float* ml = p.part_ml + slot0 * 2;
+    // (atomic loads: never scalar loads, never hoisted above the acquire)
+    float mm = -3.0e38f;
+    for (int i = 0; i < np; ++i)
+      mm = fmaxf(mm, __hip_atomic_load(ml + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float L = 0.f, a[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) a[d] = 0.f;
+    for (int i = 0; i < np; ++i) {
+      const float mi_ = __hip_atomic_load(ml + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float li_ = __hip_atomic_load(ml + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float w = fast_exp2(mi_ - mm);
+      L += w * li_;
+      const float* po = p.part_o + (slot0 + i) * HD + lane * DPL;
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) a[d] += w * __hip_atomic_load(po + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float inv = 1.f / L;
+    const int64_t o = (int64_t)seq * p.out_stride + (int64_t)qh * HD + lane * DPL;
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) {
+      const float r = a[d] * inv;
+      if (p.out_f32) out32[o + d] = r;
+      else out16[o + d] = E::to_bits(r);
+    }
   }
 }
 

@@ -22,6 +22,8 @@ MI_DECODE_PACKED_PV = 1
 MI_DECODE_FORCE_VALU = 2
 MI_DECODE_NONTEMPORAL = 4
 MI_DECODE_ROUNDED_P = 8
+MI_DECODE_FUSED_MERGE = 16
+MI_DECODE_COUNTER_BYTES = 1 << 20
 MI_ALLREDUCE_MAX_RANKS, MI_ALLREDUCE_HANDLE_BYTES = 8, 64
 
 # name -> (restype, argtypes); mirrors include/vllm_omni_amd.h declaration by declaration

@@ -509,7 +509,10 @@ class GPUARModelRunner:
                                                        self.block_size)
         nbytes = ops.decode_workspace_bytes(self.max_num_reqs, a.num_heads, a.head_dim, self.max_model_len,
                                             self._decode_part)
-        self._decode_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        if torch.device(self.device).type == "cuda":
+            self._decode_ws = ops.new_decode_workspace(nbytes, self.device)   # zeroed counters: fused partition merge
+        else:
+            self._decode_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         if self.enable_prefix_caching and self.engine_output_type != "text":
             from .prefix_cache import OmniTensorPrefixCache
 

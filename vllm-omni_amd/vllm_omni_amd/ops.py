@@ -138,11 +138,42 @@ def decode_workspace_bytes(num_seqs: int, num_q_heads: int, head_dim: int, max_s
                                                         partition_size))
 
 
+# Workspaces whose counter region (the first MI_DECODE_COUNTER_BYTES) this module has zeroed: only on those does a
+# decode call ask for the fused merge (the kernel leaves the counters at zero, so once is enough).  Keyed by the
+# tensor OBJECT (a weak reference): a recycled address of a freed tensor can never pass for a prepared one.
+_DECODE_WS_READY: dict = {}   # id(tensor) -> weakref(tensor)   (tensors compare element-wise: no WeakSet)
+
+
+def _decode_ws_ready(ws: Optional[torch.Tensor]) -> bool:
+    r = _DECODE_WS_READY.get(id(ws)) if ws is not None else None
+    return r is not None and r() is ws
+
+
+def new_decode_workspace(nbytes: int, device) -> torch.Tensor:
+    """A decode workspace (``decode_workspace_bytes``) with its arrival-counter region zeroed: what
+    ``paged_attn_decode`` needs to merge the context partitions inside the attention launch itself."""
+    import weakref
+
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    ws[:min(ws.numel(), _C.MI_DECODE_COUNTER_BYTES)].zero_()
+    key = id(ws)
+    _DECODE_WS_READY[key] = weakref.ref(ws, lambda _r, k=key: _DECODE_WS_READY.pop(k, None))
+    return ws
+
+
+# OFF by default: measured SLOWER than the separate merge kernel on every shape tried (profiles/r03c_decode_fused_ab.log:
+# 391 against 363 us at B 256 / ctx 4096, 56 against 46 us at the 1/8-size shard shapes) — every wave now ends with a
+# store-acknowledge wait and an atomic round trip while it still holds its LDS slot (5 waves per CU), which costs more
+# streaming time than the 5-7 us merge launch it saves.  Kept (bit-identical, tested) for shapes with few, long waves.
+DECODE_FUSED_MERGE = os.environ.get("VLLM_OMNI_AMD_DECODE_FUSED_MERGE", "0") == "1"
+
+
 def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                       block_table: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, scale: float,
                       partition_size: int = 0, workspace: Optional[torch.Tensor] = None,
                       packed_pv: Optional[bool] = None, force_valu: bool = False,
-                      nontemporal: Optional[bool] = None, rounded_p: bool = False) -> torch.Tensor:
+                      nontemporal: Optional[bool] = None, rounded_p: bool = False,
+                      fused_merge: Optional[bool] = None) -> torch.Tensor:
     """out[s, h] = softmax(q[s,h] . K^T * scale) . V over the paged cache (one query per sequence).
 
     q, out: [S, nq*d] (or [S, nq, d]); block_table int32 [S, max_blocks]; seq_lens int32 [S].
@@ -151,7 +182,9 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
     ``DECODE_PACKED_PV``): P.V on 16-bit operands — the MFMA kernel (P carried as a hi + lo pair of
     cache-dtype values, inside the fp32-P tolerance) where it is built, the dot2 VALU form elsewhere;
     ``force_valu`` keeps the VALU kernel; ``rounded_p`` asks the MFMA kernel for the single-rounding
-    P of flash kernels (A/B measurements only).  Returns ``out``.
+    P of flash kernels (A/B measurements only).  ``fused_merge`` (None = on for workspaces made by
+    ``new_decode_workspace``): the context partitions are merged inside the attention launch by the last-arriving
+    wave of each (sequence, head group) instead of a second kernel — same bits.  Returns ``out``.
     """
     _gpu(out, q, k_cache, v_cache, block_table, seq_lens, workspace)
     nb, bs, hkv, d = k_cache.shape
@@ -167,7 +200,12 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
     partition_size = decode_auto_partition(s, hkv, max_seq_len, bs, partition_size)
     need = decode_workspace_bytes(s, nq, d, max_seq_len, partition_size)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
-        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+        workspace = new_decode_workspace(need, q.device)
+    ready = _decode_ws_ready(workspace)
+    if fused_merge is None:
+        fused_merge = DECODE_FUSED_MERGE and ready
+    elif fused_merge and not ready:
+        raise ValueError("fused_merge needs a workspace from ops.new_decode_workspace (zeroed arrival counters)")
     check("mi_paged_attn_decode", lib.mi_paged_attn_decode(
         _p(out), _p(q), _p(k_cache), _p(v_cache), _p(block_table), _p(seq_lens), s, nq, hkv, d, bs,
         block_table.stride(0), int(max_seq_len), float(scale), q.stride(0), out.stride(0), cb, ct, ch,
@@ -177,6 +215,7 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
         (_C.MI_DECODE_PACKED_PV if (DECODE_PACKED_PV if packed_pv is None else packed_pv) else 0)
         | (_C.MI_DECODE_FORCE_VALU if force_valu else 0)
         | (_C.MI_DECODE_ROUNDED_P if rounded_p else 0)
+        | (_C.MI_DECODE_FUSED_MERGE if fused_merge else 0)
         | (_C.MI_DECODE_NONTEMPORAL if (DECODE_NONTEMPORAL if nontemporal is None else nontemporal) else 0),
         _stream()))
     return out
