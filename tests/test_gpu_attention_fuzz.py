@@ -94,6 +94,7 @@ def test_prefill_random_geometry(dev, seed):
         torch.cuda.synchronize()
         got = out.cpu().float().view(T, nq, d)
         assert torch.isfinite(got).all()
-        torch.testing.assert_close(got, ref, rtol=4e-3 if dtype == torch.bfloat16 else 1e-3, atol=atol,
+        rtol, atol = (1e-3 + (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11), 1e-4)   # fp32 bar + the output rounding
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=atol,
                                    msg=lambda m: f"d={d} nq={nq} nkv={nkv} bs={bs} ctxs={ctxs} chunks={chunks} hm={head_major} "
                                                  f"segments={segments}: {m}")

@@ -46,11 +46,12 @@ def _record(name: str, **kv) -> None:
     print(f"[parity] {name}: " + ", ".join(f"{k}={v}" for k, v in kv.items()))
 
 
-def _errs(got: torch.Tensor, ref: torch.Tensor) -> dict:
+def _errs(got: torch.Tensor, ref: torch.Tensor, out_ulp: float = 0.0) -> dict:
     """max abs error, max error relative to max|ref| of the row (head), and the worst violation of
-    |got - ref| <= atol + 1e-3 |ref| expressed as the atol it would need."""
+    |got - ref| <= atol + 1e-3 |ref| expressed as the atol it would need.  ``out_ulp``: half an ulp of the 16-bit grid
+    the op rounded its output to (unit roundoff 2^-8 bf16, 2^-11 f16), added to the 1e-3 — for ops that have no fp32 output."""
     diff = (got.double() - ref.double()).abs()
-    need_atol = (diff - 1e-3 * ref.double().abs()).clamp(min=0).max().item()
+    need_atol = (diff - (1e-3 + out_ulp) * ref.double().abs()).clamp(min=0).max().item()
     scale = ref.double().abs().amax(-1, keepdim=True).clamp(min=1e-30)
     return {"max_abs": float(diff.max()), "max_rel_to_rowmax": float((diff / scale).max()),
             "atol_needed_at_rtol_1e-3": float(need_atol), "ref_absmax": float(ref.abs().max())}
@@ -276,11 +277,10 @@ def test_prefill_8192_token_prompt_chunked(dev, geom):
                                               t, torch.tensor([total], dtype=torch.int32),
                                               torch.tensor([0, total], dtype=torch.int32), d ** -0.5)
         for c, o in outs.items():
-            e = _errs(o[:, h:h + 1], ref)
+            e = _errs(o[:, h:h + 1], ref, out_ulp=2.0 ** -8)
             _record(f"prefill {nq}/{nkv}/{d} 8192 tokens chunk {c} head {h} vs fp32 oracle (bf16 output)", **e)
-            # the output is rounded to bf16 (2^-9 relative) on top of the packed-P rounding; early rows attend to
-            # few keys and are O(1), late rows average thousands of keys and are O(1e-2)
-            assert e["max_rel_to_rowmax"] <= 8e-3 and e["max_abs"] <= 1.6e-2, (c, h, e)
+            # north_star's bar (rtol 1e-3, atol 1e-4) + the one rounding of the bf16 output
+            assert e["atol_needed_at_rtol_1e-3"] <= 1e-4, (c, h, e)
 
 
 @pytest.mark.parametrize("geom", [S_A, S_B], ids=["S-A", "S-B"])
@@ -313,9 +313,9 @@ def test_prefill_late_chunks_on_a_16k_context(dev, geom):
         a, b = int(qsl[s_]), int(qsl[s_ + 1])
         ref = ref_ops.paged_attention_prefill(q[a:b].cpu(), kc, vc, t, torch.tensor([lens[s_]], dtype=torch.int32),
                                               torch.tensor([0, b - a], dtype=torch.int32), d ** -0.5)
-        e = _errs(got[a:b], ref)
+        e = _errs(got[a:b], ref, out_ulp=2.0 ** -8)
         _record(f"prefill {nq}/{nkv}/{d} chunk {b - a} on ctx {ctxs[s_]} vs fp32 oracle (bf16 output)", **e)
-        assert e["max_rel_to_rowmax"] <= 8e-3 and e["max_abs"] <= 4e-3, (s_, e)
+        assert e["atol_needed_at_rtol_1e-3"] <= 1e-4, (s_, e)
 
 
 # ------------------------------------------------------------------ config #5: int8 decode layer, S-B, batch 512

@@ -91,7 +91,8 @@ namespace {
 
 // waves per workgroup = query heads per KV head handled together; NI = waves that issue DMA;
 // NC = column tiles (of 16 query tokens) per wave.
-template <typename Tag, int HD, int NI, int NC>
+// SPLIT: see prefill_mfma32_kernel — P as a hi + lo pair of cache-dtype values, one extra MFMA per d-tile.
+template <typename Tag, int HD, int NI, int NC, bool SPLIT>
 __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = tprev;   // shader clock vs the 100 MHz counter
 #endif
   f32x4_t sc0[2][NC], sc1[2][NC];
-  uint4 pb[NC];  // P^T operand per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
+  uint4 pb[NC], pl_[NC];  // P^T operand (hi, lo) per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
   auto kread = [&](auto stc, u32x4_t (&k0)[KS], u32x4_t (&k1)[KS]) {
     constexpr int SB = decltype(stc)::value * STAGE;
     if constexpr (MI_PREFILL_ABLATE & 4) {
@@ -346,8 +347,12 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
         const uint4 a = make_uint4(a0[nb][n][0], a0[nb][n][1], a1[nb][n][0], a1[nb][n][1]);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          if constexpr (MI_PREFILL_ABLATE & 2) acc[c][4 * nb + n][0] += __builtin_bit_cast(float, a.x ^ pb[c].x) * 1e-30f;
-          else acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
+          if constexpr (MI_PREFILL_ABLATE & 2) {
+            acc[c][4 * nb + n][0] += __builtin_bit_cast(float, a.x ^ pb[c].x) * 1e-30f;
+          } else {
+            acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
+            if constexpr (SPLIT) acc[c][4 * nb + n] = mfma16<Tag>(a, pl_[c], acc[c][4 * nb + n]);
+          }
         }
       }
     }
@@ -410,6 +415,13 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
         }
         l[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         pb[c] = make_uint4(E::pack(v[0], v[1]), E::pack(v[2], v[3]), E::pack(v[4], v[5]), E::pack(v[6], v[7]));
+        if constexpr (SPLIT) {   // lo = rnd16(p - hi): the subtraction is exact in fp32
+          const uint32_t w[4] = {pb[c].x, pb[c].y, pb[c].z, pb[c].w};
+          uint32_t lo[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lo[i] = E::pack(v[2 * i] - E::lo(w[i]), v[2 * i + 1] - E::hi(w[i]));
+          pl_[c] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
       }
     }
   };
@@ -541,7 +553,11 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
 // SIMD, each with the whole 512-register file (accumulators and Q fragments in the accumulation half) and two column
 // tiles: every K and V fragment read from LDS feeds two MFMAs instead of one, a step is 32 MFMAs between two fragment
 // waits instead of 16, and the barrier joins four waves instead of eight.
-template <typename Tag, int NI, int NC>
+// SPLIT: P enters the PV MFMA as a hi + lo PAIR of cache-dtype values (p = rnd16(p) + rnd16(p - rnd16(p)): 16 / 22
+// significant bits instead of 8 / 11), one extra MFMA per (d-block, key half) against the same V operand — what brings the
+// kernel inside rtol 1e-3 / atol 1e-4 of the fp32 oracle, as the decode kernel's split does.  SPLIT = false is the
+// single-rounding P of flash kernels (`dot(P.to(V.dtype), V)`), kept for A/B (MI_PREFILL_ROUNDED_P=1).
+template <typename Tag, int NI, int NC, bool SPLIT>
 __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(const PrefillParams p) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -704,7 +720,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
       for (int i = 0; i < 16; ++i) acc[c][n][i] = 0.f;
   }
   f32x16_t sc[2][NC];
-  uint4 pb[NC][2];
+  uint4 pb[NC][2], pl_[NC][2];
 
   auto kread = [&](auto stc, u32x4_t (&k)[KS]) { lds_read_b128x8<decltype(stc)::value * STAGE>(k_rd, k); };
   auto qk_mfma = [&](const u32x4_t (&k)[KS], f32x16_t (&s)[NC]) {
@@ -724,7 +740,10 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
       for (int n = 0; n < NB; ++n) {
         const uint4 a = make_uint4(o[4 * n + 2 * m][0], o[4 * n + 2 * m][1], o[4 * n + 2 * m + 1][0], o[4 * n + 2 * m + 1][1]);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c][n] = mfma32<Tag>(a, pb[c][m], acc[c][n]);
+        for (int c = 0; c < NC; ++c) {
+          acc[c][n] = mfma32<Tag>(a, pb[c][m], acc[c][n]);
+          if constexpr (SPLIT) acc[c][n] = mfma32<Tag>(a, pl_[c][m], acc[c][n]);
+        }
       }
   };
   auto row_max = [&](const f32x16_t& s) {
@@ -783,9 +802,18 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[c][i] = fast_exp2(__builtin_fmaf(s[c][i], p.scale_log2e, nms[c]));
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m) {
         pb[c][m] = make_uint4(E::pack(v[c][8 * m], v[c][8 * m + 1]), E::pack(v[c][8 * m + 2], v[c][8 * m + 3]),
                               E::pack(v[c][8 * m + 4], v[c][8 * m + 5]), E::pack(v[c][8 * m + 6], v[c][8 * m + 7]));
+        if constexpr (SPLIT) {   // lo = rnd16(p - hi): the subtraction is exact in fp32
+          const uint32_t w[4] = {pb[c][m].x, pb[c][m].y, pb[c][m].z, pb[c][m].w};
+          uint32_t lo[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            lo[i] = E::pack(v[c][8 * m + 2 * i] - E::lo(w[i]), v[c][8 * m + 2 * i + 1] - E::hi(w[i]));
+          pl_[c][m] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+      }
     }
   };
   auto row_sum = [&](const float (&v)[NC][16]) {
@@ -841,9 +869,9 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
       for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(sc[(ST + 1) & 1][c]);
       if constexpr (MI_PREFILL_SCHED) {
 #pragma unroll
-        for (int i = 0; i < NC * 2 * NB; ++i) {
+        for (int i = 0; i < NC * 2 * NB * (SPLIT ? 2 : 1); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
+          __builtin_amdgcn_sched_group_barrier(0x002, SPLIT ? 2 : 3, 1);
         }
       }
     }
@@ -1062,27 +1090,45 @@ int launch_prefill(PrefillParams p, const PrefillPlan& pl, int num_kv_heads, int
   const int nz = num_kv_heads * ((p.kv_group + pl.hpw - 1) / pl.hpw);
   const dim3 grid(((max_query_len + pl.qt - 1) / pl.qt) * nz * pl.nseg, p.num_seqs, 1), block(64 * pl.waves);
   p.qt = pl.qt;
+  // MI_PREFILL_ROUNDED_P=1: the single-rounding P of flash kernels instead of the hi + lo pair (A/B measurements only:
+  // 0.546 against 0.781 ms per layer at the 8192-token prompt — the pair is +43 %, and what meets rtol 1e-3 / atol 1e-4)
+  const bool rounded_p = [] {   // read per call (tests and A/B tools flip it inside one process)
+    const char* e = getenv("MI_PREFILL_ROUNDED_P");
+    return e && atoi(e) != 0;
+  }();
+#define MI_LAUNCH32(NI_, NC_)                                                                              \
+  do {                                                                                                     \
+    if (rounded_p) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, NI_, NC_, false>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, NI_, NC_, true>), grid, block, 0, s, p);            \
+  } while (0)
+#define MI_LAUNCH16(NI_, NC_)                                                                                \
+  do {                                                                                                       \
+    if (rounded_p) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, NI_, NC_, false>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, NI_, NC_, true>), grid, block, 0, s, p);            \
+  } while (0)
   bool launched = false;
   if constexpr (HD == 128) {
     if (pl.kernel32) {
-      if (pl.w4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 2>), grid, block, 0, s, p);
-      else if (pl.waves >= 4) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 4, 1>), grid, block, 0, s, p);
-      else if (pl.waves >= 2) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 2, 1>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, 1, 1>), grid, block, 0, s, p);
+      if (pl.w4) MI_LAUNCH32(4, 2);
+      else if (pl.waves >= 4) MI_LAUNCH32(4, 1);
+      else if (pl.waves >= 2) MI_LAUNCH32(2, 1);
+      else MI_LAUNCH32(1, 1);
       launched = true;
     }
   }
   if (!launched) {
     if (pl.nc >= 2) {
-      if (pl.waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4, 2>), grid, block, 0, s, p);
-      else if (pl.waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2, 2>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1, 2>), grid, block, 0, s, p);
+      if (pl.waves >= 4) MI_LAUNCH16(4, 2);
+      else if (pl.waves >= 2) MI_LAUNCH16(2, 2);
+      else MI_LAUNCH16(1, 2);
     } else {
-      if (pl.waves >= 4) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 4, 1>), grid, block, 0, s, p);
-      else if (pl.waves >= 2) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 2, 1>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, 1, 1>), grid, block, 0, s, p);
+      if (pl.waves >= 4) MI_LAUNCH16(4, 1);
+      else if (pl.waves >= 2) MI_LAUNCH16(2, 1);
+      else MI_LAUNCH16(1, 1);
     }
   }
+#undef MI_LAUNCH32
+#undef MI_LAUNCH16
   const int rc = launch_status();
   if (rc != MI_OK) return rc;
   return launch_prefill_merge<Tag, HD>(p, max_query_len, s);
