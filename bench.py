@@ -451,8 +451,13 @@ def main():
     # roofline.traffic, measured in this run: the profiled child passes go FIRST, while this process has not touched
     # the GPU (they are ordinary child processes; nothing is exec'ed from a process that has initialised HIP)
     pmc_traffic = (None, None)
+    under_profiler = ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+                      or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ))
     if world == 1 and a.traffic == "pmc" and not a.pmc_child and not a.simulate_shard and a.roofline_steps > 0:
-        pmc_traffic = measure_decode_traffic_pmc([x for x in sys.argv[1:] if x != "--pmc-child"])
+        if under_profiler:   # this process is itself being profiled (kernel trace): no nested profiler passes
+            pmc_traffic = (None, "bench.py is running under rocprofv3 itself")
+        else:
+            pmc_traffic = measure_decode_traffic_pmc([x for x in sys.argv[1:] if x != "--pmc-child"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # rehearsal mode for a 1-GPU box: every rank on cuda:0, collectives over gloo (functional check of

@@ -46,6 +46,19 @@ def test_reference_style_bringup_then_one_decode_step(dev):
     fused = ref_talker.random_weights(cfg, seed=3)
     w.load_model(weights=((n, t.to(dev)) for n, t in checkpoint_names(cfg, fused)))
     assert w.determine_available_memory() == 64 << 20
+    # KV budget without the explicit override (base.py:77-156): utilisation x total minus what THIS process holds —
+    # from the driver's per-process accounting (amdsmi, the counterpart of the reference's NVML per-PID query) when the
+    # box lets us see it, else from the allocator
+    w.config.kv_cache_memory_bytes = None
+    free, total = torch.cuda.mem_get_info(dev)
+    avail = w.determine_available_memory()
+    acct = w.memory_accounting
+    used = acct["amdsmi_process_bytes"] if acct["amdsmi_process_bytes"] else acct["profiled_bytes"]
+    assert avail == max(0, int(total * w.config.gpu_memory_utilization) - used) and 0 < avail < total
+    if acct["amdsmi_process_bytes"]:   # the two views of this (only) process agree to within the runtime's own pools
+        assert abs(acct["amdsmi_process_bytes"] - acct["profiled_bytes"]) < (4 << 30), acct
+    print("memory accounting:", acct)
+    w.config.kv_cache_memory_bytes = 64 << 20
     nb = min(w.determine_num_available_blocks(), 64)
     assert nb >= 16
     w.initialize_cache(nb)

@@ -490,6 +490,53 @@ def determine_available_memory(total_bytes: int, gpu_memory_utilization: float, 
     return max(0, requested - int(used_by_process))
 
 
+def get_process_gpu_memory(local_rank: int) -> Optional[int]:
+    """Device memory held by THIS process on its GPU, from the driver's per-process accounting — the role NVML's
+    ``nvmlDeviceGetComputeRunningProcesses`` plays in the reference (vllm_omni/worker/gpu_memory_utils.py:69-124;
+    ``usedGpuMemory`` of the entry whose pid is ours), here through ``amdsmi``.  With several workers sharing one card
+    (``gpu_memory_utilization`` split between stages) the allocator's own ``memory_reserved`` cannot see the neighbours;
+    the driver's figure per pid can.  ``local_rank`` indexes the VISIBLE devices (``HIP_VISIBLE_DEVICES`` /
+    ``CUDA_VISIBLE_DEVICES`` integer lists are honoured).  Returns None when amdsmi is missing, not permitted or
+    reports nothing for this pid — the caller then takes the profiling branch (base.py:134-154)."""
+    import os
+
+    try:
+        import amdsmi
+    except Exception:  # noqa: BLE001 - not installed
+        return None
+    try:
+        amdsmi.amdsmi_init()
+    except Exception:  # noqa: BLE001 - no driver access in this container
+        return None
+    try:
+        handles = amdsmi.amdsmi_get_processor_handles()
+        index = local_rank
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        if vis:
+            ids = [v.strip() for v in vis.split(",") if v.strip()]
+            if local_rank < len(ids) and ids[local_rank].lstrip("-").isdigit():
+                index = int(ids[local_rank])
+        if not 0 <= index < len(handles):
+            raise RuntimeError(f"Invalid GPU device {index}. Only {len(handles)} GPU(s) available. "
+                               "Check HIP_VISIBLE_DEVICES or stage config 'devices' setting.")
+        me = os.getpid()
+        for proc in amdsmi.amdsmi_get_gpu_process_list(handles[index]):
+            if int(proc.get("pid", -1)) == me:
+                usage = proc.get("memory_usage") or {}
+                vram = usage.get("vram_mem")
+                return int(vram if vram else proc.get("mem", 0))
+        return None     # the driver lists no entry for this pid (not permitted to see it): profiling branch
+    except RuntimeError:
+        raise
+    except Exception:  # noqa: BLE001 - any amdsmi failure: profiling branch
+        return None
+    finally:
+        try:
+            amdsmi.amdsmi_shut_down()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 KV_LAYOUTS = ("NB2", "2NB", "NB2_HEAD_MAJOR")
 
 

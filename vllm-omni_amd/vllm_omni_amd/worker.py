@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from .distributed import init_distributed_environment
-from .kv_cache import determine_available_memory, num_blocks_for_budget
+from .kv_cache import determine_available_memory, get_process_gpu_memory, num_blocks_for_budget
 from .model_runner import GPUARModelRunner
 from .talker import TalkerConfig
 
@@ -137,11 +137,17 @@ class GPUARWorker:
     def determine_available_memory(self) -> int:
         """Bytes available for the KV cache on this rank (base.py:77-156): requested =
         total * gpu_memory_utilization; available = requested - what this process already holds
-        (weights + persistent buffers, read from the allocator; NVML per-PID accounting does not
-        exist on AMD, so this is the profiling branch base.py:134-154)."""
+        (weights + persistent buffers): the driver's per-process figure through amdsmi — the counterpart of
+        the reference's NVML per-PID query — or, when that is unavailable, the allocator's own numbers (the
+        profiling branch, base.py:134-154)."""
         torch.cuda.synchronize()
         free_now, total = torch.cuda.mem_get_info(self.device)
-        used_by_process = max(torch.cuda.memory_reserved(self.device), self.init_free_bytes - free_now)
+        # per-process accounting from the driver first (what the reference asks NVML for, base.py:107-133): correct
+        # when other workers share the card; else what this process reserved / what left the free pool since init
+        profiled = max(torch.cuda.memory_reserved(self.device), self.init_free_bytes - free_now)
+        by_pid = get_process_gpu_memory(self.local_rank)
+        self.memory_accounting = {"amdsmi_process_bytes": by_pid, "profiled_bytes": int(profiled)}
+        used_by_process = by_pid if by_pid is not None and by_pid > 0 else profiled
         return determine_available_memory(total, self.config.gpu_memory_utilization, used_by_process,
                                           self.config.kv_cache_memory_bytes)
 
