@@ -8,7 +8,8 @@ previous one stopped, a one-token step that is still inside its prompt taking it
 sampled token), the bookkeeping rule that an unfinished prompt generates nothing (``sampled_token_ids[i] == []``,
 upstream's discarded samples), and preemption: a request that lost its blocks comes back as a RESUMED request with a new
 block list and recomputes its prompt and the tokens it had generated (prefill rows, nothing generated) before it decodes
-again.
+again — with the thinker's reply rows added to the recomputed generated tokens exactly as they were when those tokens were
+decoded, and the request's reply cursor continuing behind them.
 
 Tolerances as in test_gpu_talker_step.py (hidden states rtol / atol 3e-2 after 2 bf16 layers, a lone element to 5e-2), greedy ids wherever the
 oracle's top-2 logit margin exceeds 0.05; the oracle is teacher-forced with the tokens the device drew."""
@@ -25,7 +26,9 @@ pytestmark = pytest.mark.gpu
 _EXTRA = int(os.environ.get("MI_FUZZ_EXTRA", "0"))
 
 
-@pytest.mark.parametrize("seed", list(range(4)) + list(range(100, 100 + _EXTRA)))
+# seeds 50-52: schedules biased towards the talker's real flow under memory pressure — every prompt is embeddings with
+# reply rows, preemption four times as likely — so that recomputed generated tokens WITH reply rows occur for sure
+@pytest.mark.parametrize("seed", list(range(4)) + [50, 51, 52] + list(range(100, 100 + _EXTRA)))
 def test_random_schedule_matches_oracle(dev, seed):
     from vllm_omni_amd.kv_cache import KVCacheManager
     from vllm_omni_amd.model_runner import GPUARModelRunner
@@ -34,6 +37,7 @@ def test_random_schedule_matches_oracle(dev, seed):
 
     rng = np.random.default_rng(9000 + seed)
     g = torch.Generator().manual_seed(seed)
+    biased = 50 <= seed < 100
     cfg = TalkerConfig.from_json("mini_talker")
     d, nq, nkv = [(128, 4, 2), (64, 4, 2), (128, 2, 1), (64, 8, 4)][int(rng.integers(0, 4))]
     cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.mrope_section = d, nq, nkv, None
@@ -56,27 +60,27 @@ def test_random_schedule_matches_oracle(dev, seed):
     class Live:
         def __init__(self, rid):
             n = int(rng.choice([1, 2, 3, 15, 16, 17, 33, 60])) if rng.random() < 0.6 else int(rng.integers(1, 70))
-            self.use_embeds = bool(rng.random() < 0.7)             # the talker's prompts are embeddings; token ids too
+            self.use_embeds = bool(rng.random() < 0.7) or biased   # the talker's prompts are embeddings; token ids too
             emb = (torch.randn(n, cfg.embedding_size, generator=g) * 0.5).to(torch.bfloat16) if self.use_embeds else None
             toks = torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist()
             self.r = Request(rid, toks, SamplingParams(temperature=0.0), prompt_embeds=emb)
             # the thinker's reply rows, one added to the input of each decode step until they run out (a request that
             # sits a step out keeps its cursor); with prompts of embeddings only — the reference's talker flow
             self.reply = None
-            if self.use_embeds and rng.random() < 0.6:
+            if self.use_embeds and (rng.random() < 0.6 or biased):
                 self.reply = (torch.randn(int(rng.integers(1, 5)), cfg.embedding_size, generator=g) * 0.5).to(torch.bfloat16)
                 self.r.additional_information = {"thinker_reply_part": self.reply}
             self.n_decoded = 0
             self.recompute_until = 0      # preempted and resumed: the tokens it recomputes before it decodes again
             self.resume = False           # the next time it is scheduled it comes back as a RESUMED request
             self.plen = n
-            self.max_new = int(rng.integers(1, 7))
+            self.max_new = int(rng.integers(3, 9)) if biased else int(rng.integers(1, 7))
             self.out = []                 # tokens the device generated
             self.computed = 0
             self.known = False            # the runner has seen it
 
     live, finished_last, next_id, steps_with_graph = [], set(), 0, 0
-    n_partial = n_one_token_prompt_rows = n_mixed = n_recomputed = 0
+    n_partial = n_one_token_prompt_rows = n_mixed = n_recomputed = n_recomputed_with_reply = 0
     for step in range(int(rng.integers(14, 22))):
         # ---- a random schedule for this step ----
         while len(live) < max_reqs and rng.random() < (0.6 if len(live) < 2 else 0.3):
@@ -87,7 +91,7 @@ def test_random_schedule_matches_oracle(dev, seed):
         # preemption (recompute): a running request loses its blocks and starts over at token 0 when it is scheduled
         # again, as a resumed request with a new block list; it recomputes prompt + generated tokens before it decodes
         for q in live:
-            if q.known and q.reply is None and q.computed > 0 and not q.resume and rng.random() < 0.06:
+            if q.known and q.computed > 0 and not q.resume and rng.random() < (0.25 if biased else 0.06):
                 mgr.free(q.r)
                 q.r.num_computed_tokens = q.computed = 0
                 q.recompute_until = q.plen + len(q.out)
@@ -166,9 +170,16 @@ def test_random_schedule_matches_oracle(dev, seed):
                     else:
                         emb_rows.append(ref_talker.decode_embeds(w, torch.tensor(q.r.prompt_token_ids[c:c + a]), None, torch.bfloat16))
                 if a < n:
-                    toks = q.out[c + a - q.plen:c + n - q.plen]
+                    # generated token j went into the model as embed(token j) + reply[j] when it was decoded
+                    # (qwen2_5_omni.py:766-806): the recomputation must feed the same rows to rebuild the same KV
+                    j0, j1 = c + a - q.plen, c + n - q.plen
+                    toks = q.out[j0:j1]
                     assert len(toks) == n - a
-                    emb_rows.append(ref_talker.decode_embeds(w, torch.tensor(toks), None, torch.bfloat16))
+                    for j, tok in zip(range(j0, j1), toks):
+                        vec = q.reply[j:j + 1] if (q.reply is not None and j < q.reply.shape[0]) else None
+                        emb_rows.append(ref_talker.decode_embeds(w, torch.tensor([tok]), vec, torch.bfloat16))
+                        n_recomputed_with_reply += int(vec is not None)
+                    q.n_decoded = max(q.n_decoded, j1)               # the last recomputed row IS the next decode step
                     n_recomputed += n - a
             pos_rows.append(torch.arange(c, c + n))
             ns.append(n)
@@ -212,7 +223,8 @@ def test_random_schedule_matches_oracle(dev, seed):
                 mgr.free(q.r)
     # the schedule exercised what the test is about (deterministic per seed; checked over the default seeds together below)
     test_random_schedule_matches_oracle.stats = getattr(test_random_schedule_matches_oracle, "stats", [])
-    test_random_schedule_matches_oracle.stats.append((n_partial, n_one_token_prompt_rows, n_mixed, steps_with_graph, n_recomputed))
+    test_random_schedule_matches_oracle.stats.append((n_partial, n_one_token_prompt_rows, n_mixed, steps_with_graph, n_recomputed,
+                                                      n_recomputed_with_reply))
 
 
 def test_schedules_covered_the_cases():
@@ -221,5 +233,6 @@ def test_schedules_covered_the_cases():
         pytest.skip("runs after test_random_schedule_matches_oracle")
     tot = np.asarray(stats).sum(0)
     assert tot[0] > 0 and tot[1] > 0 and tot[2] > 0, f"partial chunks / one-token prompt rows / mixed steps: {tot}"
-    if len(stats) >= 20:
+    if len(stats) >= 7:   # the biased seeds ran
         assert tot[4] > 0, "no schedule recomputed generated tokens after a preemption"
+        assert tot[5] > 0, "no recomputed generated token carried a reply row"

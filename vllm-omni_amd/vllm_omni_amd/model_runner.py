@@ -745,17 +745,31 @@ class GPUARModelRunner:
             st = self.requests[ib.req_ids[i]]
             k = int(num_sched[i])
             c = int(ib.num_computed_tokens_cpu[i])
-            if st.prompt_embeds is not None:
-                pl = int(st.prompt_embeds.shape[0])
-                a = min(k, max(0, pl - c))
-                if a:
+            pl = int(ib.num_prompt_tokens[i])
+            a = min(k, max(0, pl - c))          # rows of this chunk that are still inside the prompt
+            if a:
+                if st.prompt_embeds is not None:
                     self.inputs_embeds[t0:t0 + a].copy_(st.prompt_embeds[c:c + a].to(self.dtype), non_blocking=True)
-                if a < k:   # recomputation after a preemption runs over tokens the request generated: their embeddings
-                    ids = torch.as_tensor(st.output_token_ids[c + a - pl:c + k - pl], dtype=torch.int64)
-                    self.inputs_embeds[t0 + a:t0 + k] = self.model.embed_input_ids(ids.to(self.device))
-            else:
-                ids = torch.as_tensor((st.prompt_token_ids + st.output_token_ids)[c:c + k], dtype=torch.int64)
-                self.inputs_embeds[t0:t0 + k] = self.model.embed_input_ids(ids.to(self.device))
+                else:
+                    ids = torch.as_tensor(st.prompt_token_ids[c:c + a], dtype=torch.int64)
+                    self.inputs_embeds[t0:t0 + a] = self.model.embed_input_ids(ids.to(self.device))
+            if a < k:
+                # Recomputation after a preemption runs over tokens the request GENERATED.  Generated token j entered
+                # the model as embed(token j) + thinker_reply_part[j] when it was decoded (one reply row per decode
+                # step while rows last: qwen2_5_omni.py:766-806), so that is what rebuilds the same KV rows; the rows
+                # are still in the request's segment of the device pool.  The chunk's last generated row is the input
+                # of the NEXT decode step, so the request's reply cursor ends behind it.
+                j0, j1 = c + a - pl, c + k - pl
+                ids = torch.as_tensor(st.output_token_ids[j0:j1], dtype=torch.int64).to(self.device)
+                emb = self.model.embed_input_ids(ids)
+                if st.reply_base >= 0 and j0 < st.reply_rows:
+                    r1 = min(j1, st.reply_rows)
+                    rows = self._reply_pool[st.reply_base + j0:st.reply_base + r1]
+                    emb = emb.clone()
+                    emb[:r1 - j0] = (emb[:r1 - j0].float() + rows.float()).to(emb.dtype)
+                self.inputs_embeds[t0 + a:t0 + k] = emb
+                if st.reply_base >= 0:
+                    ib.reply_offset[i] = st.reply_base + min(j1, st.reply_rows)
             t0 += k
 
     def _commit_predictor_inputs(self, n: int, padded: int = 0) -> None:
