@@ -300,3 +300,49 @@ def test_fused_merge_equals_the_two_kernel_merge_bit_for_bit(dev):
         ops.paged_attn_decode(want, qq, kbg, vbg, tb, sl, msl, d ** -0.5, partition_size=part, fused_merge=False)
         torch.cuda.synchronize()
         assert torch.equal(out, want), step
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_long_partitions_walk_the_block_id_windows(dev, dtype):
+    """Partitions of more than 64 blocks (the matrix-core kernel reloads its block-id window every 64 blocks), up to ONE
+    partition for the whole context (direct output, no merge launch — what the auto choice takes once sequences x KV
+    heads >= 512): the oracle's bar, and one-hot targets on both sides of every window boundary gather the right row
+    bit-exactly."""
+    from vllm_omni_amd import ops
+
+    nq, nkv, d, bs = 8, 2, 128, 16
+    lens = [4096, 1023, 1025, 2048 + 31, 3000, 64 * 16 * 3 + 1]
+    kv, kb, vb, table, q, seq_lens = _mk_case(len(lens), nq, nkv, d, bs, lens, dtype, seed=31)
+    ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
+    kvg = kv.to(dev)
+    S = len(lens)
+
+    def run(part, out_dtype=torch.float32, kbv=None, qq=None):
+        out = torch.full((S, nq * d), float("nan"), dtype=out_dtype, device=dev)
+        k_, v_ = kbv if kbv is not None else (kvg[:, 0], kvg[:, 1])
+        ops.paged_attn_decode(out, (q if qq is None else qq).view(S, nq * d).to(dev), k_, v_, table.to(dev),
+                              seq_lens.to(dev), 4096 + 16, d ** -0.5, partition_size=part)
+        torch.cuda.synchronize()
+        return out.cpu().view(S, nq, d)
+
+    for part in (2048, 4096 + 32, 1024 + 512, 8192):
+        got = run(part)
+        torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4, msg=lambda m: f"partition {part}: {m}")
+        assert torch.equal(run(part, dtype), got.to(dtype))
+    # one-hot attention over integer-valued V: tokens 1023 / 1024 (window 0 | 1), 2047 / 2048, 3071 / 3072, 4095
+    targets = [4095, 1022, 1024, 2048, 2047, 3072]
+    kd = torch.zeros_like(kv[:, 0]).float()
+    vd = torch.zeros_like(kv[:, 1]).float()
+    expect = []
+    for s, (n, tgt) in enumerate(zip(lens, targets)):
+        assert tgt < n
+        for t in range(n):
+            blk, off = int(table[s, t // bs]), t % bs
+            kd[blk, off, :, 0] = 200.0 if t == tgt else -200.0
+            vd[blk, off] = float((t * 7) % 251 - 125)
+        expect.append(float((tgt * 7) % 251 - 125))
+    qq = torch.zeros(S, nq, d)
+    qq[:, :, 0] = 1.0
+    got = run(8192, dtype, kbv=(kd.to(dtype).to(dev), vd.to(dtype).to(dev)), qq=qq.to(dtype)).float()
+    for s, e in enumerate(expect):
+        assert torch.equal(got[s], torch.full((nq, d), e)), (s, targets[s])

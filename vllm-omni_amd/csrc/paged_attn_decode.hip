@@ -419,32 +419,36 @@ int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
                                                        int32_t max_seq_len) {
-  // Measured on MI355X (tools/bench_decode_kernel.py, shapes B x ctx = 256x4096, 64x2048, 32x1024,
-  // 8x32768, 1x8192; KV heads 4/2/1): the kernel's per-partition prologue (Q fragments, block-id
-  // window, pipeline fill) and the fp32 partial write + merge cost more than idle CUs do, so take the
-  // LONGEST partition (<= 1024 tokens) that still leaves >= 2 waves per CU, and never go below 256.
+  // Measured on MI355X (tools/bench_decode_kernel.py; profiles/r03e_decode_long_parts*.log: B x ctx from 32 x 4096 to
+  // 256 x 8192 and 64 x 16384, 4 / 2 / 1 KV heads): every partition costs a prologue (Q fragments, block-id window,
+  // pipeline fill), an fp32 partial write and its share of the merge launch, so take the FEWEST partitions that still
+  // leave >= 512 waves (two per CU) — ONE when (sequences x KV heads) >= 512: direct output, no partials, no merge
+  // (B 256 / ctx 4096: 315 us against 340 with four partitions of 1024; fewer than 512 waves loses: 256 waves run at
+  // 55 % of that rate).  Never below 256 tokens, never above 8192 (a bound on the tail when ONE sequence of a batch is
+  // far longer than the rest: one wave streams its whole partition).
   if (num_seqs <= 0 || num_kv_heads <= 0 || max_seq_len <= 0) return 256;
-  const int64_t target_waves = 512;
   const int64_t pairs = (int64_t)num_seqs * num_kv_heads;
-  int32_t best = 256;
-  for (int32_t ps = 1024; ps >= 256; ps /= 2) {
-    const int64_t parts = (max_seq_len + ps - 1) / ps;
-    if (pairs * parts >= target_waves) { best = ps; break; }
-  }
-  if (best > mi::round_up(max_seq_len, 32)) best = mi::round_up(max_seq_len, 32);
-  return best;  // the caller additionally caps it at 64 blocks (mi_paged_attn_decode)
+  const int64_t parts = (512 + pairs - 1) / pairs;
+  int64_t ps = mi::round_up((int32_t)((max_seq_len + parts - 1) / parts), 32);
+  if (ps < 256) ps = 256;
+  if (ps > 8192) ps = 8192;
+  if (ps > mi::round_up(max_seq_len, 32)) ps = mi::round_up(max_seq_len, 32);
+  return (int32_t)ps;  // kernels that keep a partition's block ids in ONE register cap it at 64 blocks (below)
 }
 
-// The partition size a call will really use: `requested` (0 = auto), capped at 64 KV blocks
-// (the kernel keeps a partition's block ids in one 64-lane register) and kept a multiple of 16.
+// The partition size a call will really use: `requested` (0 = auto).  The matrix-core kernel (flags: PACKED_PV without
+// FORCE_VALU, block_size >= 16, a multiple of 32 tokens) walks its block ids window by window and takes any length;
+// the VALU kernel keeps a partition's block ids in one 64-lane register: capped at 64 KV blocks.
 extern "C" int32_t mi_paged_attn_decode_effective_partition(int32_t num_seqs, int32_t num_kv_heads,
                                                             int32_t max_seq_len, int32_t block_size,
-                                                            int32_t requested) {
+                                                            int32_t requested, int32_t flags) {
   if (block_size <= 0) return 0;
   int32_t ps = requested > 0 ? requested
                              : mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len);
+  const bool any_length = (flags & MI_DECODE_PACKED_PV) && !(flags & MI_DECODE_FORCE_VALU) && block_size >= 16 &&
+                          ps % 32 == 0;
   const int32_t cap = 64 * block_size;
-  if (ps > cap) ps = cap;
+  if (!any_length && ps > cap) ps = cap;
   return ps;
 }
 
@@ -493,7 +497,7 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
     return MI_ERR_INVALID_ARG;
 
   partition_size = mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len,
-                                                            block_size, partition_size);
+                                                            block_size, partition_size, flags);
   if (partition_size <= 0 || partition_size % kTile) return MI_ERR_INVALID_ARG;
   const int num_parts = (max_seq_len + partition_size - 1) / partition_size;
   const int64_t need = mi_paged_attn_decode_workspace_bytes(num_seqs, num_q_heads, head_dim,

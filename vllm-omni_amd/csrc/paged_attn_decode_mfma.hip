@@ -85,7 +85,11 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   const int t_begin = part * part_steps;
   const int first_blk = (t_begin * kStep) >> p.bs_log2;
   const int32_t* const bt_row = p.block_table + (int64_t)seq * p.block_table_stride;
-  const int win_ids = bt_row[min(first_blk + lane, p.block_table_stride - 1)];
+  // win_a: ids of the 64-block window the loop is in, win_b: of the window behind it (the DMA runs two steps ahead and
+  // crosses into it near the end of a window).  A partition of <= 64 blocks never leaves win_a.
+  int win_a = bt_row[min(first_blk + lane, p.block_table_stride - 1)];
+  int win_b = win_a;
+  int win_first = first_blk;   // logical block of win_a's lane 0 (wave-uniform)
 
   const int seq_len = p.seq_lens[seq];
   const int steps_total = (seq_len + kStep - 1) / kStep;
@@ -161,10 +165,17 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   const uint64_t blk_bytes = (uint64_t)p.blk_stride * 2;
   const uint32_t tok_bytes = (uint32_t)p.tok_stride * 2;
   const uint32_t grp_bytes = RPI * tok_bytes;
+  // Physical id of logical block `blk` (wave-uniform): a lane of win_a, or of win_b once the prefetch has crossed into
+  // the next window.  Two readlanes and a select — no load, so no wait, anywhere near the DMA issue.
+  auto phys_of = [&](int blk) -> uint32_t {
+    const int rel = blk - win_first;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(win_a, rel & 63);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane(win_b, rel & 63);
+    return rel < 64 ? a : b;
+  };
   auto subtile_base = [&](int tok0) -> uint64_t {  // byte offset of token row tok0 (wave-uniform)
     const int blk = min(tok0 >> p.bs_log2, last_blk);
-    const uint32_t phys = (uint32_t)__builtin_amdgcn_readlane(win_ids, blk - first_blk);
-    return (uint64_t)phys * blk_bytes + (uint32_t)(tok0 & bs_mask) * tok_bytes;
+    return (uint64_t)phys_of(blk) * blk_bytes + (uint32_t)(tok0 & bs_mask) * tok_bytes;
   };
   auto issue_k = [&](int t, int st) {
 #pragma unroll
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
           const int row0 = t * kStep + 16 * j + RPI * ii;
           const int tok = min(row0 + lane / LPR, limit - 1);              // per lane
           const int blk_u = min(row0, limit - 1) >> p.bs_log2;              // wave-uniform
-          const uint32_t phys = (uint32_t)__builtin_amdgcn_readlane(win_ids, blk_u - first_blk);
+          const uint32_t phys = phys_of(blk_u);
           const int c = (lane % LPR) ^ swz_v<HD>(RPI * ii + lane / LPR);
           const uint64_t off = (uint64_t)phys * blk_bytes + (uint64_t)((uint32_t)(tok & bs_mask) * tok_bytes) +
                                (uint64_t)((int64_t)kvh * p.head_stride * 2) + (uint32_t)(c * 16);
@@ -314,15 +325,36 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   // ---- pipeline: stage t+1 streams in while stage t is consumed ------------------------------
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  const int steps_per_win = (64 << p.bs_log2) / kStep;
+  if (t_end - t_begin > steps_per_win) {   // wave-uniform; before any DMA is in flight
+    win_b = bt_row[min(first_blk + 64 + lane, p.block_table_stride - 1)];
+    asm volatile("" : "+v"(win_b));
+  }
   issue_k(t_begin, 0);
   issue_v(t_begin, 0);
   if (t_begin + 1 < t_end) {
     issue_k(t_begin + 1, 1);
     issue_v(t_begin + 1, 1);
   }
-  for (int t = t_begin; t < t_end; t += 2) {
-    compute(t, S0{});
-    if (t + 1 < t_end) compute(t + 1, S1{});
+  // A partition longer than 64 blocks (MI_DECODE_LONG_PARTITIONS) is walked window by window: steps_per_win is even for
+  // every block size >= 16, so a window starts on stage 0 and a 32-token step never straddles two windows.  At a window
+  // change win_b becomes win_a and the ids behind it are loaded with ONE blocking vector load — its wait is forced right
+  // here (the empty asm is a use), outside the pipelined loop: placed by the compiler at the first readlane instead it
+  // becomes a vmcnt(0) in front of every block-id lookup and drains the LDS-DMA ring on every sub-tile (measured: 2190
+  // instead of 345 us per launch).  Cost: the ring of ONE wave runs dry for ~1 us per 1024 tokens (85 us of streaming);
+  // the CU's other waves keep the HBM stream going.
+  for (int t = t_begin; t < t_end;) {
+    const int seg_end = min(t_end, t + steps_per_win);
+    for (; t < seg_end; t += 2) {
+      compute(t, S0{});
+      if (t + 1 < t_end) compute(t + 1, S1{});
+    }
+    if (t < t_end) {   // next window (only ever taken with multi_win)
+      win_a = win_b;
+      win_first += 64;
+      win_b = bt_row[min(win_first + 64 + lane, p.block_table_stride - 1)];
+      asm volatile("" : "+v"(win_b));
+    }
   }
   // the last step waited with vmcnt(0): no DMA can land in this workgroup's LDS after it exits
 
@@ -414,7 +446,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 }  // namespace
 
 // Launch the MFMA decode kernel.  Caller guarantees: head_dim in {64, 128}, block_size >= 16,
-// partition a multiple of 32 tokens and <= 64 blocks.
+// partition a multiple of 32 tokens (any number of blocks: the block-id window is reloaded every 64 blocks).
 int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, bool nt, bool split_p,
                        hipStream_t stream) {
   const int64_t waves = (int64_t)p.num_seqs * (p.num_q_heads / gh) * p.num_parts;

@@ -505,10 +505,15 @@ class GPUARModelRunner:
         for layer, kv in zip(self.model.language_model.model.layers, self.kv_caches):
             layer.self_attn.attn.bind_kv_cache(kv)
         a = self.model.language_model.model.layers[0].self_attn
+        # The partition of a decode launch is chosen per call from the step's batch size and context bound (the fewest
+        # partitions that leave >= 512 waves: ops.decode_auto_partition); the workspace is sized once for the largest
+        # need any batch size of this runner can have.  `_decode_part` (reporting only) = the full batch's choice.
         self._decode_part = ops.decode_auto_partition(self.max_num_reqs, a.num_kv_heads, self.max_model_len,
                                                        self.block_size)
-        nbytes = ops.decode_workspace_bytes(self.max_num_reqs, a.num_heads, a.head_dim, self.max_model_len,
-                                            self._decode_part)
+        nbytes = max(ops.decode_workspace_bytes(b, a.num_heads, a.head_dim, self.max_model_len,
+                                                ops.decode_auto_partition(b, a.num_kv_heads, self.max_model_len,
+                                                                          self.block_size))
+                     for b in range(1, self.max_num_reqs + 1))
         if torch.device(self.device).type == "cuda":
             self._decode_ws = ops.new_decode_workspace(nbytes, self.device)   # zeroed counters: fused partition merge
         else:
@@ -719,7 +724,7 @@ class GPUARModelRunner:
             num_actual_tokens=total, max_query_len=max_query_len, query_start_loc=self.query_start_loc.gpu[:n + 1],
             seq_lens=self.seq_lens.gpu[:n], max_seq_len=max_seq_len_bound, block_table=bt.block_table.gpu[:n],
             slot_mapping=bt.slot_mapping.gpu[:total], num_reqs=n, num_decodes=num_decodes,
-            decode_partition_size=self._decode_part, decode_workspace=self._decode_ws)
+            decode_partition_size=0, decode_workspace=self._decode_ws)   # 0 = auto, per call
 
     def _preprocess_embeds(self, n: int, total: int, num_sched: np.ndarray, num_decodes: int) -> None:
         """Fill ``self.inputs_embeds[:total]`` (the model's ``preprocess`` hook, batched)."""

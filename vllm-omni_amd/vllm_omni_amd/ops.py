@@ -125,11 +125,18 @@ DECODE_PACKED_PV = True
 DECODE_NONTEMPORAL = True   # nt cache policy on the K/V stream: +8 % measured (profiles/)
 
 
+def _decode_flags(packed_pv: Optional[bool], force_valu: bool) -> int:
+    return ((_C.MI_DECODE_PACKED_PV if (DECODE_PACKED_PV if packed_pv is None else packed_pv) else 0)
+            | (_C.MI_DECODE_FORCE_VALU if force_valu else 0))
+
+
 def decode_auto_partition(num_seqs: int, num_kv_heads: int, max_seq_len: int, block_size: int = 16,
-                          requested: int = 0) -> int:
-    """Partition size a decode call will really use (``requested`` or auto, capped at 64 blocks)."""
+                          requested: int = 0, packed_pv: Optional[bool] = None, force_valu: bool = False) -> int:
+    """Partition size a decode call will really use: ``requested``, or the auto choice — the fewest partitions that
+    leave >= 512 waves, ONE (direct output, no merge launch) once sequences x KV heads >= 512; any multiple of 32 tokens
+    for the matrix-core kernel, capped at 64 blocks for the VALU kernel (``packed_pv`` False / ``force_valu``)."""
     return int(lib.mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len, block_size,
-                                                            requested))
+                                                            requested, _decode_flags(packed_pv, force_valu)))
 
 
 def decode_workspace_bytes(num_seqs: int, num_q_heads: int, head_dim: int, max_seq_len: int,
@@ -197,7 +204,7 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
     cb, ct, ch = _cache_strides(k_cache, v_cache)
     if s == 0:
         return out
-    partition_size = decode_auto_partition(s, hkv, max_seq_len, bs, partition_size)
+    partition_size = decode_auto_partition(s, hkv, max_seq_len, bs, partition_size, packed_pv, force_valu)
     need = decode_workspace_bytes(s, nq, d, max_seq_len, partition_size)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = new_decode_workspace(need, q.device)
