@@ -53,7 +53,12 @@ __device__ __forceinline__ void store_agent_b64(float* p, f32x2_t v) {
   asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <typename Tag, int HD, int AUX, bool SPLIT>
+// NS = stages of the wave's K/V ring (steps in flight).  2 (the product): 32 KiB of LDS per wave, five waves per CU.
+// 4 (64 KiB, two waves per CU, ~56 KiB in flight per wave) was built for launches with at most two waves per CU (TP / DP
+// shard shapes, small batches on long contexts) on the theory that a wave's own stream rate limits them — measured, it
+// is never ahead: 47.6 against 46.7 us at B 32 / ctx 4096 (512 waves), 94 against 88 at 256 x 7/1 heads, 338 against
+// 316 at the headline (profiles/r03g_decode_stages.log).  Only NS = 2 is instantiated.
+template <typename Tag, int HD, int AUX, bool SPLIT, int NS>
 __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p, const int gh) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   constexpr int IPS = 16 / RPI;       // DMA instructions per 16-row sub-tile: 4 / 2
   constexpr int IMG = kStep * ROWB;   // one K or V image of a stage (8 KiB)
   constexpr int STAGE = 2 * IMG;      // K image + V image
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
 
   const int lane = threadIdx.x;
   const int wave = blockIdx.x;
@@ -226,7 +231,14 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   // vmcnt bookkeeping.  The only vector-memory operations in flight are DMA groups, retired in
   // issue order:  K0 V0 K1 V1 | K2 (after QK 0)  V2 (after PV 0) | K3 V3 | ...
   // so "image X has landed" == vmcnt(number of instructions issued after X's group).
-  auto wait_groups = [&](int groups) {  // wave-uniform
+  static_assert((2 * NS - 1) * kGrp <= 63, "the groups in flight must fit the 6-bit vmcnt");
+  auto wait_groups = [&](int groups) {  // wave-uniform; `groups` DMA groups were issued after the one waited for
+    if constexpr (NS > 2) {
+      if (groups >= 7) { wait_vmcnt<7 * kGrp>(); return; }
+      if (groups == 6) { wait_vmcnt<6 * kGrp>(); return; }
+      if (groups == 5) { wait_vmcnt<5 * kGrp>(); return; }
+      if (groups == 4) { wait_vmcnt<4 * kGrp>(); return; }
+    }
     if (groups >= 3) wait_vmcnt<3 * kGrp>();
     else if (groups == 2) wait_vmcnt<2 * kGrp>();
     else if (groups == 1) wait_vmcnt<kGrp>();
@@ -241,14 +253,17 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   auto compute = [&](int t, auto stc) {
     constexpr int ST = decltype(stc)::value;
     constexpr int SB = ST * STAGE;
-    const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
-    // K(t) landed?  issued after it: V(t), and K(t+1) V(t+1) when step t+1 exists
-    wait_groups(1 + (has1 ? 2 : 0));
+    // steps behind t that are already in the ring (their K and V groups were issued after K(t) / V(t)), and whether
+    // step t + NS exists (its K group is issued between this step's two waits)
+    const int ahead = min(NS - 1, t_end - 1 - t);
+    const bool refill = t + NS < t_end;
+    // K(t) landed?  issued after it: V(t), and K, V of the `ahead` steps behind it
+    wait_groups(1 + 2 * ahead);
     // ---- S^T = K . Q^T for the two 16-token sub-tiles -------------------------------------
     u32x4_t k0[KS], k1[KS];
     if constexpr (KS == 4) lds_read_rows8<SB, SB + 16 * ROWB>(k_rd, k0, k1);
     else lds_read_rows4<SB, SB + 16 * ROWB>(k_rd, k0, k1);
-    if (has2) issue_k(t + 2, ST);  // K image of this stage is free again: refill it now
+    if (refill) issue_k(t + NS, ST);  // K image of this stage is free again: refill it now
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -300,8 +315,8 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
       for (int i = 0; i < 4; ++i) lo[i] = E::pack(v[i][0] - E::lo(w[i]), v[i][1] - E::hi(w[i]));
       p_lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
-    // V(t) landed?  issued after it: K(t+1) V(t+1) when step t+1 exists, K(t+2) when step t+2 does
-    wait_groups((has1 ? 2 : 0) + (has2 ? 1 : 0));
+    // V(t) landed?  issued after it: K, V of the `ahead` steps behind it, and K(t + NS) when that step exists
+    wait_groups(2 * ahead + (refill ? 1 : 0));
     // ---- O^T[n] += V^T[n] . P^T, four d-tiles (8 transposed reads) per wait -------------------
 #pragma unroll
     for (int nb = 0; nb < NT; nb += 4) {
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
         }
       }
     }
-    if (has2) issue_v(t + 2, ST);  // every read of this stage's V image has retired
+    if (refill) issue_v(t + NS, ST);  // every read of this stage's V image has retired
   };
 
   // ---- pipeline: stage t+1 streams in while stage t is consumed ------------------------------
@@ -330,11 +345,12 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
     win_b = bt_row[min(first_blk + 64 + lane, p.block_table_stride - 1)];
     asm volatile("" : "+v"(win_b));
   }
-  issue_k(t_begin, 0);
-  issue_v(t_begin, 0);
-  if (t_begin + 1 < t_end) {
-    issue_k(t_begin + 1, 1);
-    issue_v(t_begin + 1, 1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    if (t_begin + i < t_end) {
+      issue_k(t_begin + i, i);
+      issue_v(t_begin + i, i);
+    }
   }
   // A partition longer than 64 blocks (MI_DECODE_LONG_PARTITIONS) is walked window by window: steps_per_win is even for
   // every block size >= 16, so a window starts on stage 0 and a 32-token step never straddles two windows.  At a window
@@ -345,9 +361,13 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   // the CU's other waves keep the HBM stream going.
   for (int t = t_begin; t < t_end;) {
     const int seg_end = min(t_end, t + steps_per_win);
-    for (; t < seg_end; t += 2) {
+    for (; t < seg_end; t += NS) {   // steps_per_win is a multiple of NS: a window starts on stage 0
       compute(t, S0{});
       if (t + 1 < t_end) compute(t + 1, S1{});
+      if constexpr (NS == 4) {
+        if (t + 2 < t_end) compute(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < t_end) compute(t + 3, std::integral_constant<int, 3>{});
+      }
     }
     if (t < t_end) {   // next window (only ever taken with multi_win)
       win_a = win_b;
@@ -452,22 +472,24 @@ int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, b
   const int64_t waves = (int64_t)p.num_seqs * (p.num_q_heads / gh) * p.num_parts;
   if (waves > INT32_MAX) return MI_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)waves), block(64);
-#define MI_LAUNCH(TAG, HDIM)                                                                            \
-  do {                                                                                                  \
-    if (split_p) {                                                                                      \
-      if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2, true>), grid, block, 0, stream, p, gh);  \
-      else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0, true>), grid, block, 0, stream, p, gh);     \
-    } else {                                                                                            \
-      if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2, false>), grid, block, 0, stream, p, gh); \
-      else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0, false>), grid, block, 0, stream, p, gh);    \
-    }                                                                                                   \
+#define MI_LAUNCH_NS(TAG, HDIM, NS_)                                                                        \
+  do {                                                                                                      \
+    if (split_p) {                                                                                          \
+      if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2, true, NS_>), grid, block, 0, stream, p, gh);  \
+      else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0, true, NS_>), grid, block, 0, stream, p, gh);     \
+    } else {                                                                                                \
+      if (nt) hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 2, false, NS_>), grid, block, 0, stream, p, gh); \
+      else hipLaunchKernelGGL((decode_mfma_kernel<TAG, HDIM, 0, false, NS_>), grid, block, 0, stream, p, gh);    \
+    }                                                                                                       \
   } while (0)
+#define MI_LAUNCH(TAG, HDIM) MI_LAUNCH_NS(TAG, HDIM, 2)
   if (dtype == MI_DTYPE_BF16) {
     if (head_dim == 128) MI_LAUNCH(bf16_tag, 128); else MI_LAUNCH(bf16_tag, 64);
   } else {
     if (head_dim == 128) MI_LAUNCH(f16_tag, 128); else MI_LAUNCH(f16_tag, 64);
   }
 #undef MI_LAUNCH
+#undef MI_LAUNCH_NS
   return launch_status();
 }
 
