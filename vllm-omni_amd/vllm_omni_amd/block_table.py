@@ -47,16 +47,78 @@ class CpuGpuBuffer:
         return self.gpu[:n]
 
 
+class StepArena:
+    """One pinned host block and its device twin holding the step's SMALL index arrays side by side (positions, sequence
+    lengths, query offsets, slot mapping, reply / sampler / predictor rows): ``buffer()`` hands out ``CpuGpuBuffer``-shaped
+    views, their ``copy_to_gpu(n)`` only marks bytes dirty, and ``flush()`` sends the dirty extent with ONE host->device
+    copy where each array used to be its own (seven launches of ~5.5 us + ~6.5 us of gap each per decode step on the
+    captured path: profiles/r03_shard_tp4dp2_timeline.md).  Bytes between two dirty arrays are copied along — host and
+    device twins of an arena array are only ever written through the host side, so that rewrites equal data.  ``flush()``
+    must run before the first kernel that reads any of the arrays is enqueued (the runner does, at the end of its input
+    commit); arrays the DEVICE also writes (the last sampled token ids) do not belong in an arena."""
+
+    ALIGN = 256
+
+    def __init__(self, nbytes: int, device: Optional[torch.device], pin: bool = True):
+        on_gpu = device is not None and torch.device(device).type == "cuda"
+        self.cpu = torch.zeros(nbytes, dtype=torch.uint8, pin_memory=bool(pin and on_gpu and torch.cuda.is_available()))
+        self.gpu = torch.zeros(nbytes, dtype=torch.uint8, device=device) if on_gpu else self.cpu
+        self._used = 0
+        self._lo: Optional[int] = None
+        self._hi = 0
+
+    def buffer(self, *shape: int, dtype: torch.dtype) -> "ArenaBuffer":
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        off = -(-self._used // self.ALIGN) * self.ALIGN
+        if off + nbytes > self.cpu.numel():
+            raise MemoryError("StepArena is too small for its buffers")
+        self._used = off + nbytes
+        return ArenaBuffer(self, off, shape, dtype, nbytes)
+
+    def mark(self, lo: int, hi: int) -> None:
+        self._lo = lo if self._lo is None else min(self._lo, lo)
+        self._hi = max(self._hi, hi)
+
+    def flush(self) -> None:
+        if self._lo is None:
+            return
+        if self.gpu is not self.cpu:
+            self.gpu[self._lo:self._hi].copy_(self.cpu[self._lo:self._hi], non_blocking=True)
+        self._lo, self._hi = None, 0
+
+
+class ArenaBuffer:
+    """``CpuGpuBuffer`` interface over a slice of a ``StepArena``."""
+
+    def __init__(self, arena: StepArena, off: int, shape, dtype: torch.dtype, nbytes: int):
+        self._arena, self._off = arena, off
+        self.cpu = arena.cpu[off:off + nbytes].view(dtype).view(*shape)
+        self.np = self.cpu.numpy()
+        self.gpu = arena.gpu[off:off + nbytes].view(dtype).view(*shape)
+        self._row_bytes = nbytes // shape[0] if shape and shape[0] else 0
+        self._nbytes = nbytes
+
+    def copy_to_gpu(self, n: Optional[int] = None) -> torch.Tensor:
+        nb = self._nbytes if n is None else n * self._row_bytes
+        if nb:
+            self._arena.mark(self._off, self._off + nb)
+        return self.gpu if n is None else self.gpu[:n]
+
+
 class BlockTable:
     def __init__(self, block_size: int, max_num_reqs: int, max_num_blocks_per_req: int, max_num_batched_tokens: int,
-                 device: Optional[torch.device] = None, pin_memory: bool = True):
+                 device: Optional[torch.device] = None, pin_memory: bool = True, arena: Optional[StepArena] = None):
         self.block_size = block_size
         self.max_num_reqs = max_num_reqs
         self.max_num_blocks_per_req = max_num_blocks_per_req
         self.max_num_batched_tokens = max_num_batched_tokens
         self.block_table = CpuGpuBuffer(max_num_reqs, max_num_blocks_per_req, dtype=torch.int32, device=device,
                                         pin=pin_memory)
-        self.slot_mapping = CpuGpuBuffer(max_num_batched_tokens, dtype=torch.int64, device=device, pin=pin_memory)
+        self.slot_mapping = (arena.buffer(max_num_batched_tokens, dtype=torch.int64) if arena is not None else
+                             CpuGpuBuffer(max_num_batched_tokens, dtype=torch.int64, device=device, pin=pin_memory))
         self.num_blocks_per_row = np.zeros(max_num_reqs, dtype=np.int32)
 
     # ---- rows -----------------------------------------------------------------
@@ -128,9 +190,9 @@ class MultiGroupBlockTable:
     """One ``BlockTable`` per KV-cache group (the talker has exactly one)."""
 
     def __init__(self, max_num_reqs: int, max_model_len: int, max_num_batched_tokens: int, block_sizes: Sequence[int],
-                 device: Optional[torch.device] = None, pin_memory: bool = True):
+                 device: Optional[torch.device] = None, pin_memory: bool = True, arena: Optional[StepArena] = None):
         self.block_tables = [
-            BlockTable(bs, max_num_reqs, -(-max_model_len // bs), max_num_batched_tokens, device, pin_memory)
+            BlockTable(bs, max_num_reqs, -(-max_model_len // bs), max_num_batched_tokens, device, pin_memory, arena)
             for bs in block_sizes
         ]
 

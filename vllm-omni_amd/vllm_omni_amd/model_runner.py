@@ -67,15 +67,17 @@ class SamplingState:
     upstream keeps in `SamplingMetadata` (`prompt_token_ids`, `output_token_ids`, per-request generators) for
     the sampler call at vllm_omni/worker/gpu_ar_model_runner.py:626-657."""
 
-    def __init__(self, max_num_reqs: int, vocab: int, device, base_seed: int):
+    def __init__(self, max_num_reqs: int, vocab: int, device, base_seed: int, arena=None):
         from .block_table import CpuGpuBuffer
 
+        self.arena = arena
         self.vocab, self.words = vocab, (vocab + 31) // 32
         self.base_seed = int(base_seed or 0)
         self.free_slots = list(range(max_num_reqs - 1, -1, -1))
         self.scratch_slot = max_num_reqs                      # rows without a penalty record their draws here
         self.bitmap = torch.zeros(max_num_reqs + 1, self.words, dtype=torch.int32, device=device)
-        mk = lambda dt: CpuGpuBuffer(max_num_reqs, dtype=dt, device=device)  # noqa: E731
+        mk = lambda dt: (arena.buffer(max_num_reqs, dtype=dt) if arena is not None   # noqa: E731
+                         else CpuGpuBuffer(max_num_reqs, dtype=dt, device=device))
         self.temperature, self.top_p, self.rep = mk(torch.float32), mk(torch.float32), mk(torch.float32)
         self.top_k, self.seen_row = mk(torch.int32), mk(torch.int32)
         self.seed, self.offset = mk(torch.int64), mk(torch.int64)
@@ -124,11 +126,13 @@ class SamplingState:
                 self.rep.np[i] = 1.0
             self.seed.np[i] = st.sample_seed
             self.offset.np[i] = len(st.output_token_ids) + drawn_ahead
-        return ops.sample_tokens(logits[:n], self.temperature.copy_to_gpu(n), self.seed.copy_to_gpu(n),
-                                 self.offset.copy_to_gpu(n), top_k=self.top_k.copy_to_gpu(n),
-                                 top_p=self.top_p.copy_to_gpu(n), rep_penalty=self.rep.copy_to_gpu(n),
-                                 seen_bitmap=self.bitmap, seen_row=self.seen_row.copy_to_gpu(n), update_seen=True,
-                                 ids=ids[:n])
+        dev_args = [b.copy_to_gpu(n) for b in (self.temperature, self.seed, self.offset, self.top_k, self.top_p, self.rep,
+                                                self.seen_row)]
+        if self.arena is not None:
+            self.arena.flush()      # ONE host->device copy for the seven per-row arrays, before the launch reads them
+        temperature, seed, offset, top_k, top_p, rep, seen_row = dev_args
+        return ops.sample_tokens(logits[:n], temperature, seed, offset, top_k=top_k, top_p=top_p, rep_penalty=rep,
+                                 seen_bitmap=self.bitmap, seen_row=seen_row, update_seen=True, ids=ids[:n])
 
 
 class ReplyRowAllocator:
@@ -174,7 +178,8 @@ class ReplyRowAllocator:
 class InputBatch:
     """Persistent batch: dense rows [0, num_reqs), condensed on removal."""
 
-    def __init__(self, max_num_reqs: int, max_model_len: int, max_num_batched_tokens: int, block_size: int, device):
+    def __init__(self, max_num_reqs: int, max_model_len: int, max_num_batched_tokens: int, block_size: int, device,
+                 arena=None):
         self.max_num_reqs = max_num_reqs
         self.req_ids: list[str] = []
         self.req_id_to_index: dict[str, int] = {}
@@ -188,7 +193,7 @@ class InputBatch:
         self.reply_offset = np.full(max_num_reqs, -1, dtype=np.int64)   # row of the next reply vector, -1 = none
         self.reply_end = np.zeros(max_num_reqs, dtype=np.int64)
         self.block_table = MultiGroupBlockTable(max_num_reqs, max_model_len, max_num_batched_tokens, [block_size],
-                                                device)
+                                                device, arena=arena)
 
     @property
     def num_reqs(self) -> int:
@@ -402,7 +407,13 @@ class GPUARModelRunner:
         self.model: Optional[Qwen2_5OmniTalkerForConditionalGeneration] = None
         self.kv_caches: list = []
         self.requests: dict[str, CachedRequestState] = {}
-        self.input_batch = InputBatch(max_num_reqs, max_model_len, self.max_num_batched_tokens, block_size, device)
+        from .block_table import StepArena
+
+        # the step's small index arrays live in ONE pinned block / device block: one host->device copy per step
+        # instead of one per array (block_table.StepArena); generous: 16 int64 arrays of the larger of tokens / requests
+        self._arena = StepArena(16 * 8 * (max(self.max_num_batched_tokens, max_num_reqs) + 64) + 64 * StepArena.ALIGN, device)
+        self.input_batch = InputBatch(max_num_reqs, max_model_len, self.max_num_batched_tokens, block_size, device,
+                                      arena=self._arena)
         self.execute_model_state: Optional[ExecuteModelState] = None
         self.kv_extracted: dict[str, Any] = {}
         self.kv_payloads: dict[str, torch.Tensor] = {}     # packed wire payloads (1-D uint8, device)
@@ -420,12 +431,13 @@ class GPUARModelRunner:
         from .block_table import CpuGpuBuffer
 
         dev, n, t = self.device, self.max_num_reqs, self.max_num_batched_tokens
-        self.positions = CpuGpuBuffer(t, dtype=torch.int64, device=dev)
-        self.seq_lens = CpuGpuBuffer(n, dtype=torch.int32, device=dev)
-        self.query_start_loc = CpuGpuBuffer(n + 1, dtype=torch.int32, device=dev)
-        self.last_token_ids = CpuGpuBuffer(n, dtype=torch.int64, device=dev)
-        self.reply_idx = CpuGpuBuffer(n, dtype=torch.int64, device=dev)
-        self.logits_indices = CpuGpuBuffer(n, dtype=torch.int64, device=dev)
+        ar = self._arena
+        self.positions = ar.buffer(t, dtype=torch.int64)
+        self.seq_lens = ar.buffer(n, dtype=torch.int32)
+        self.query_start_loc = ar.buffer(n + 1, dtype=torch.int32)
+        self.last_token_ids = CpuGpuBuffer(n, dtype=torch.int64, device=dev)   # also written on the DEVICE: not in the arena
+        self.reply_idx = ar.buffer(n, dtype=torch.int64)
+        self.logits_indices = ar.buffer(n, dtype=torch.int64)
         on_gpu = torch.device(dev).type == "cuda"
         e = self.config.embedding_size
         self.inputs_embeds = torch.zeros(t, e, dtype=self.dtype, device=dev)
@@ -477,16 +489,17 @@ class GPUARModelRunner:
             self._state_free = list(range(n - 1, -1, -1))
             # + one scratch row: where the padded rows of a bucketed graph replay park their state
             self._last_hidden = torch.zeros(n + 1, self.config.hidden_size, dtype=self.dtype, device=self.device)
-            self._state_rows = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
-            self._cp_seed = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
-            self._cp_offset = CpuGpuBuffer(n, dtype=torch.int64, device=self.device)
+            self._state_rows = self._arena.buffer(n, dtype=torch.int64)
+            self._cp_seed = self._arena.buffer(n, dtype=torch.int64)
+            self._cp_offset = self._arena.buffer(n, dtype=torch.int64)
             self._cp_codes = torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, device=self.device)
             k = self.OUT_SLOTS
             on_gpu = torch.device(self.device).type == "cuda"
             self._out_codes_cpu = [torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, pin_memory=on_gpu) for _ in range(k)]
             self._out_codes_stage = [torch.zeros(n, cpc.num_code_groups, dtype=torch.int64, device=self.device) for _ in range(k)]
         if torch.device(self.device).type == "cuda" and self.config.vocab_size <= 15744:
-            self.sampling_state = SamplingState(self.max_num_reqs, self.config.vocab_size, self.device, self.seed or 0)
+            self.sampling_state = SamplingState(self.max_num_reqs, self.config.vocab_size, self.device, self.seed or 0,
+                                                arena=self._arena)
         if self.max_reply_rows:
             self._reply_pool = torch.zeros(self.max_reply_rows, self.config.embedding_size, dtype=self.dtype,
                                            device=self.device)
@@ -742,6 +755,7 @@ class GPUARModelRunner:
         # every step — a pure-prefill step too — ends by storing hidden[-1] of each request in its state row
         # (`last_talker_hidden`, qwen3_omni.py:634-640): the rows must belong to THIS step's batch
         self._commit_predictor_inputs(n)
+        self._arena.flush()   # positions, lengths, offsets, slots, reply and predictor rows: one copy, before any reader
         if num_decodes:
             self._decode_embeds(num_decodes)
         # prefill rows: per-request prompt embeddings (thinker hidden states) or token embeddings
@@ -998,6 +1012,7 @@ class GPUARModelRunner:
             self.last_token_ids.copy_to_gpu(n)
         self.reply_idx.copy_to_gpu(max(n, padded))
         self._commit_predictor_inputs(n, padded)
+        self._arena.flush()   # one host->device copy for everything the replay reads
 
     @torch.inference_mode()
     def sample_tokens(self, grammar_output=None, async_output: bool = False):
