@@ -114,6 +114,31 @@ def decoder_stack(cfg, weights: dict, h: torch.Tensor, positions: torch.Tensor, 
     return hidden
 
 
+def thinker_to_talker_prefill(cfg, weights: dict, spk_row: torch.Tensor, thinker_prompt_embeds: torch.Tensor,
+                              thinker_result: torch.Tensor, round_to=None):
+    """The talker's prompt as the reference's preprocess hook builds it on a prefill span
+    (``thinker_to_talker_process`` / ``_thinker_to_talker_prefill``, qwen2_5_omni.py:681-764):
+
+        rows = cat(thinker_prompt_embeds,                                     :735-741
+                   emb_thinker(speaker) + emb_codec(tts_codec_pad),
+                   thinker_result[0] + emb_codec(tts_codec_start))
+        ids  = [tts_codec_mask] * (n - 2) + [tts_codec_pad, tts_codec_start]   :744-756  (n = rows)
+        thinker_reply_part = thinker_result[1:]                                :716-717
+
+    ``spk_row`` = the speaker token's row of the THINKER's embedding table (``_get_embed_text_spk_token``, :639-642).
+    The sums are the reference's tensor adds in the model dtype: exact fp32 sum, one rounding (``round_to``).
+    Returns (ids list, rows [P + 2, E] fp32 on the ``round_to`` grid, reply rows [K - 1, E])."""
+    emb = weights["language_model.model.embed_tokens.weight"].to(F32)
+    pad, bos = emb[cfg.tts_codec_pad_token_id], emb[cfg.tts_codec_start_token_id]
+    row_spk = R._rt(spk_row.to(F32).reshape(-1) + pad, round_to)
+    row_bos = R._rt(thinker_result[0].to(F32) + bos, round_to)
+    e = emb.shape[1]
+    rows = torch.cat([thinker_prompt_embeds.to(F32).reshape(-1, e), row_spk.view(1, e), row_bos.view(1, e)])
+    n = rows.shape[0]
+    ids = ([cfg.tts_codec_mask_token_id] * (n - 2) + [cfg.tts_codec_pad_token_id, cfg.tts_codec_start_token_id])[-n:]
+    return ids, rows, thinker_result[1:]
+
+
 def logits_and_greedy(cfg, weights: dict, hidden: torch.Tensor, suppress_start_id: Optional[int], round_to=None):
     logits = _lin(hidden, weights["language_model.lm_head.weight"], None, round_to)
     logits = R.bad_word_processor(logits, suppress_start_id, cfg.tts_codec_end_token_id, cfg.tts_codec_start_token_id)

@@ -285,3 +285,40 @@ def test_upstream_scheduler_output_is_normalised():
     so.scheduled_cached_reqs.req_ids, so.num_scheduled_tokens = [], {"n0": 3}
     r._update_states(so)
     assert r.input_batch.req_ids == ["n0"] and r.requests["n0"].reply_rows == 2
+
+
+def test_talker_prompt_is_built_from_the_thinker_hand_over():
+    """The reference hands a talker request over as ``additional_information{prompt_embeds, thinker_result, ...}`` and the
+    model's preprocess hook builds the prompt on the prefill span (qwen2_5_omni.py:653-764): P thinker rows, one
+    speaker + codec-pad row, one first-reply + codec-bos row; the rest of the reply is the per-step queue.  The product's
+    ``thinker_to_talker_process`` against the oracle's restatement, bit for bit (the sums are single bf16 roundings),
+    the speaker rows coming out of a checkpoint's ``thinker_embedding.weight``."""
+    from vllm_omni_amd.talker import Qwen2_5OmniTalkerForConditionalGeneration as Talker, TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_talker")
+    w = ref_talker.random_weights(cfg, seed=4)
+    m = Talker(cfg, torch.bfloat16, torch.device("cpu"), seed=0)
+    g = torch.Generator().manual_seed(1)
+    table = torch.zeros(151873, cfg.embedding_size, dtype=torch.bfloat16)     # a thinker embedding table (ids to 151872)
+    for tok in (151860, 151870, 151872):
+        table[tok] = torch.randn(cfg.embedding_size, generator=g).to(torch.bfloat16)
+    loaded = m.load_weights(list(w.items()) + [("thinker_embedding.weight", table)])
+    assert loaded == set(w.keys())                                            # the table is not a talker parameter
+    assert set(m.thinker_special_embeddings) == {151860, 151870, 151872}
+    P, K = 11, 5
+    info = {"prompt_embeds": torch.randn(P, cfg.embedding_size, generator=g),                 # fp32, as the thinker stage sends them
+            "thinker_result": torch.randn(K, cfg.embedding_size, generator=g),
+            "prompt_token_ids": list(range(P)), "thinker_output_token_ids": [7, 8, 9, 10, 11]}
+    for voice, tok in (("Chelsie", 151872), ("Ethan", 151870), ("nobody", 151860)):
+        ids, rows, upd = m.thinker_to_talker_process(info, voice)
+        r_ids, r_rows, r_reply = ref_talker.thinker_to_talker_prefill(
+            cfg, w, table[tok], info["prompt_embeds"].to(torch.bfloat16), info["thinker_result"].to(torch.bfloat16),
+            torch.bfloat16)
+        assert ids == r_ids == [cfg.tts_codec_mask_token_id] * P + [cfg.tts_codec_pad_token_id, cfg.tts_codec_start_token_id]
+        assert rows.shape == (P + 2, cfg.embedding_size) and torch.equal(rows.float(), r_rows)
+        assert torch.equal(upd["thinker_reply_part"].float(), r_reply.float()) and upd["thinker_reply_part"].shape[0] == K - 1
+    with pytest.raises(ValueError):
+        m.thinker_to_talker_process({"prompt_embeds": info["prompt_embeds"], "thinker_result": torch.zeros(0, cfg.embedding_size)})
+    m2 = Talker(cfg, torch.bfloat16, torch.device("cpu"), seed=0)
+    with pytest.raises(RuntimeError, match="thinker's embedding table"):
+        m2.thinker_to_talker_process(info)

@@ -131,3 +131,93 @@ def test_shared_prefix_reuses_blocks_and_matches_the_oracle(dev, budget):
     out = runner.execute_model(so) or runner.sample_tokens()
     sched.update_from_output(so, out)
     assert out.pooler_output[0]["hidden"].shape[0] == min(40, budget)
+
+
+def test_reference_shaped_talker_request_through_scheduler_and_runner(dev):
+    """A talker request as the reference's stage input processor hands it over — placeholder prompt ids
+    ``[8293] + [8292] * P + [8294]`` and ``additional_information{prompt_embeds, thinker_result, prompt_token_ids,
+    thinker_output_token_ids}``, no request-level prompt embeddings (stage_input_processors/qwen2_5_omni.py:6-61) —
+    goes scheduler -> runner unchanged: the runner builds the P + 2 prompt rows the model's preprocess hook builds
+    (qwen2_5_omni.py:681-764), prefills them, then decodes with one reply row per step.  Hidden states of the prefill
+    and of every decode step against the oracle; a second request with the SAME thinker prompt and a different reply
+    re-uses the prompt's full blocks (the hash covers the hand-over's rows)."""
+    from vllm_omni_amd.model_runner import GPUARModelRunner
+    from vllm_omni_amd.scheduler import MI355XARScheduler
+    from vllm_omni_amd.sched_output import Request, SamplingParams
+    from vllm_omni_amd.talker import TalkerConfig
+
+    cfg = TalkerConfig.from_json("mini_talker")
+    cfg.mrope_section = None
+    runner = GPUARModelRunner(cfg, dev, torch.bfloat16, max_num_reqs=4, max_model_len=128, max_num_batched_tokens=64,
+                              block_size=BS, enforce_eager=True, max_reply_rows=64, seed=0, enable_prefix_caching=True)
+    runner.load_model()
+    w = ref_talker.random_weights(cfg, seed=3)
+    g = torch.Generator().manual_seed(21)
+    spk = torch.randn(cfg.embedding_size, generator=g).to(torch.bfloat16)
+    table = torch.zeros(151873, cfg.embedding_size, dtype=torch.bfloat16)
+    table[151872] = spk
+    table[151860] = torch.randn(cfg.embedding_size, generator=g).to(torch.bfloat16)
+    runner.model.load_weights([(k, v.to(dev)) for k, v in w.items()] + [("thinker_embedding.weight", table)])
+    runner.model.set_suppress_start_id(cfg.tts_codec_mask_token_id)
+    runner.initialize_kv_cache(NB)
+    vc = NS(scheduler_config=NS(max_num_seqs=4, max_num_batched_tokens=64, enable_chunked_prefill=True),
+            cache_config=NS(block_size=BS, enable_prefix_caching=True), model_config=NS(max_model_len=128, omni_kv_config=None))
+    sched = MI355XARScheduler(vc, NS(num_blocks=NB), None, BS)
+    csc = ref_ops.build_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
+
+    P, K, steps = 34, 4, 5
+    tp = torch.randn(P, cfg.embedding_size, generator=g)                       # fp32 hidden states from the thinker stage
+    ids = [8293] + [8292] * P + [8294]
+
+    def request(rid, reply):
+        info = {"prompt_embeds": tp, "thinker_result": reply, "prompt_token_ids": list(range(P)),
+                "thinker_output_token_ids": list(range(K))}
+        return Request(rid, ids, SamplingParams(temperature=0.0, max_tokens=steps), additional_information=info)
+
+    def oracle(reply, tokens):
+        """Prefill of the built prompt, then `len(tokens)` decode steps teacher-forced with the device's tokens."""
+        _, rows, rp = ref_talker.thinker_to_talker_prefill(cfg, w, spk, tp.to(torch.bfloat16), reply.to(torch.bfloat16),
+                                                          torch.bfloat16)
+        nblk = (P + 2 + steps + BS) // BS
+        caches = [(torch.zeros(nblk + 1, BS, cfg.num_key_value_heads, cfg.head_dim),
+                   torch.zeros(nblk + 1, BS, cfg.num_key_value_heads, cfg.head_dim)) for _ in range(cfg.num_hidden_layers)]
+        tbl = torch.arange(1, nblk + 1, dtype=torch.int32).view(1, -1)
+        n = rows.shape[0]
+        pos = torch.arange(n, dtype=torch.int64)
+        hid = [ref_talker.talker_step(cfg, w, rows, pos, caches, tbl, torch.tensor([n], dtype=torch.int32),
+                                      torch.tensor([0, n], dtype=torch.int32),
+                                      ref_ops.slot_mapping(tbl, torch.zeros(n, dtype=torch.int64), pos, BS), csc, torch.bfloat16)]
+        for j, tok in enumerate(tokens):
+            vec = rp[j:j + 1].to(torch.bfloat16) if j < rp.shape[0] else None
+            emb = ref_talker.decode_embeds(w, torch.tensor([tok]), vec, torch.bfloat16)
+            p1 = torch.tensor([n + j], dtype=torch.int64)
+            hid.append(ref_talker.talker_step(cfg, w, emb, p1, caches, tbl, torch.tensor([n + j + 1], dtype=torch.int32),
+                                              torch.tensor([0, 1], dtype=torch.int32),
+                                              ref_ops.slot_mapping(tbl, torch.zeros(1, dtype=torch.int64), p1, BS), csc,
+                                              torch.bfloat16))
+        return hid
+
+    reply_a = torch.randn(K, cfg.embedding_size, generator=g)
+    ra = request("a", reply_a)
+    sched.add_request(ra)
+    trace = _drive(sched, runner)
+    assert ra.is_finished() and len(ra.output_token_ids) == steps
+    got = [o.pooler_output[o.req_id_to_index["a"]]["hidden"].float() for _, o in trace if "a" in o.req_id_to_index]
+    want = oracle(reply_a, ra.output_token_ids[:-1])
+    assert got[0].shape == (P + 2, cfg.hidden_size) and len(got) == len(want) == steps
+    for i, (x, y) in enumerate(zip(got, want)):
+        torch.testing.assert_close(x, y, rtol=3e-2, atol=3e-2, msg=lambda m: f"step {i}: {m}")
+
+    # same thinker prompt, different reply: blocks 0, 1 (rows 0..31 of the 34 thinker rows) are a hit, the rest is not
+    reply_b = torch.randn(K, cfg.embedding_size, generator=g)
+    rb = request("b", reply_b)
+    sched.add_request(rb)
+    so = sched.schedule()
+    nr = so.scheduled_new_reqs[0]
+    assert nr.num_computed_tokens == 2 * BS and so.num_scheduled_tokens == {"b": P + 2 - 2 * BS}
+    out = runner.execute_model(so) or runner.sample_tokens()
+    sched.update_from_output(so, out)
+    hb = out.pooler_output[0]["hidden"].float()
+    assert hb.shape == (P + 2, cfg.hidden_size)                                # cached rows + this step's
+    torch.testing.assert_close(hb, oracle(reply_b, [])[0], rtol=3e-2, atol=3e-2)
+    assert torch.equal(hb[:2 * BS], got[0][:2 * BS])

@@ -150,14 +150,33 @@ def _request_tokens(request) -> Sequence[int]:
     return list(request.prompt_token_ids) + list(getattr(request, "output_token_ids", []) or [])
 
 
-def _prompt_rows(request) -> int:
+def _prompt_embed_source(request):
+    """The rows that ARE the prompt's content when its token ids are placeholders: ``request.prompt_embeds``, or — the
+    reference's thinker -> talker hand-over, where the model's preprocess hook builds the rows from
+    ``additional_information`` (qwen2_5_omni.py:681-764) — the thinker's prompt rows, one row standing for the speaker
+    token (a constant per voice: the voice name is hashed with it) and the first reply row.  Returns (Tensor | None, tag)."""
     pe = getattr(request, "prompt_embeds", None)
-    return int(pe.shape[0]) if isinstance(pe, torch.Tensor) else 0
+    if isinstance(pe, torch.Tensor):
+        return pe, b""
+    info = getattr(request, "additional_information", None)
+    if isinstance(info, dict) and isinstance(info.get("thinker_result"), torch.Tensor):
+        tr = info["thinker_result"]
+        tp = info.get("prompt_embeds")
+        e = tr.shape[-1]
+        tp = tp.reshape(-1, e).to(tr.dtype).cpu() if isinstance(tp, torch.Tensor) else tr.new_zeros(0, e).cpu()
+        rows = torch.cat([tp, tr.new_zeros(1, e).cpu(), tr[:1].reshape(1, e).cpu()], dim=0)
+        return rows, b"voice:" + str(info.get("voice_type", "Chelsie")).encode()
+    return None, b""
+
+
+def _prompt_rows(request) -> int:
+    pe, _ = _prompt_embed_source(request)
+    return int(pe.shape[0]) if pe is not None else 0
 
 
 def _has_reply_rows(request) -> bool:
     info = getattr(request, "additional_information", None)
-    return isinstance(info, dict) and info.get("thinker_reply_part") is not None
+    return isinstance(info, dict) and (info.get("thinker_reply_part") is not None or info.get("thinker_result") is not None)
 
 
 def block_content_hash(parent: bytes, token_ids: Sequence[int], extra: bytes = b"") -> bytes:
@@ -256,8 +275,8 @@ class KVCacheManager:
             return hs[:num_blocks]
         toks = _request_tokens(request)
         b = self.block_size
-        pe = getattr(request, "prompt_embeds", None)
-        rows = _prompt_rows(request)
+        pe, voice = _prompt_embed_source(request)
+        rows = int(pe.shape[0]) if pe is not None else 0
         salted = _has_reply_rows(request)
         plen = max(rows, len(request.prompt_token_ids))
         parent = hs[-1] if hs else b"\0" * 16
@@ -265,7 +284,7 @@ class KVCacheManager:
             lo, hi = i * b, (i + 1) * b
             extra = b""
             if lo < rows:   # the block covers prompt rows given as embeddings: their bytes ARE the content
-                extra = pe[lo:min(hi, rows)].detach().contiguous().cpu().view(torch.uint8).numpy().tobytes()
+                extra = pe[lo:min(hi, rows)].detach().contiguous().cpu().view(torch.uint8).numpy().tobytes() + voice
             if hi > plen and salted:
                 extra += b"|" + rid.encode()
             parent = block_content_hash(parent, toks[lo:hi], extra)

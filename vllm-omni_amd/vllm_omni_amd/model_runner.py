@@ -577,9 +577,21 @@ class GPUARModelRunner:
 
         to_add: list[CachedRequestState] = []
         for nr in so.scheduled_new_reqs:
+            prompt_embeds, info = nr.prompt_embeds, nr.additional_information
+            if prompt_embeds is None and isinstance(info, dict) and isinstance(info.get("thinker_result"), torch.Tensor):
+                # The reference hands a talker request over as additional_information{prompt_embeds, thinker_result,
+                # prompt_token_ids, thinker_output_token_ids} and lets the MODEL's preprocess hook build the prompt rows on
+                # the prefill span (gpu_model_runner.py:1264-1309 -> talker_preprocess -> thinker_to_talker_process,
+                # qwen2_5_omni.py:653-764).  Same construction, once, when the request enters: P + 2 prompt rows, the
+                # remaining thinker rows become the request's reply queue.
+                _, prompt_embeds, upd = self.model.thinker_to_talker_process(info, info.get("voice_type", "Chelsie"))
+                if nr.prompt_token_ids and len(nr.prompt_token_ids) != prompt_embeds.shape[0]:
+                    raise ValueError(f"request {nr.req_id}: {len(nr.prompt_token_ids)} prompt token ids but the thinker "
+                                     f"hand-over builds {prompt_embeds.shape[0]} prompt rows (thinker prompt + 2)")
+                info = dict(info, **upd)
             st = CachedRequestState(nr.req_id, list(nr.prompt_token_ids), nr.sampling_params,
                                     tuple(list(b) for b in nr.block_ids), nr.num_computed_tokens,
-                                    prompt_embeds=nr.prompt_embeds, additional_information=nr.additional_information)
+                                    prompt_embeds=prompt_embeds, additional_information=info)
             self.requests[nr.req_id] = st
             # first scheduling with computed tokens == a hit in the KV prefix cache: the rows of the cached blocks
             # come out of the tensor prefix cache when the step's output is packed (gpu_model_runner.py:315-320)

@@ -52,6 +52,11 @@ class TalkerConfig:
     tts_codec_end_token_id: Optional[int] = 8294
     tts_codec_pad_token_id: Optional[int] = 8292
     tts_codec_mask_token_id: Optional[int] = 8296
+    # ids in the THINKER's vocabulary whose thinker-embedding rows the talker's prompt is built from
+    # (``Qwen2_5OmniTalkerConfig`` defaults; qwen2_5_omni.py:563-637)
+    tts_text_start_token_id: Optional[int] = 151860
+    tts_text_end_token_id: Optional[int] = 151861
+    tts_text_pad_token_id: Optional[int] = 151859
     # sparse-MoE MLP (Qwen3-Omni talker); num_experts == 0: dense SiLU MLP
     num_experts: int = 0
     num_experts_per_tok: int = 0
@@ -311,6 +316,61 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
         ids = ops.mask_logits_argmax(logits, ranges, col, ids)
         return logits, ids
 
+    # ---- prompt construction (the model's ``preprocess`` hook on a prefill span) -------------------------------
+    # speaker -> token id in the thinker's vocabulary (qwen2_5_omni.py:570-579)
+    TTS_TEXT_SPK_TOKEN_IDS = {"m02": 151870, "Ethan": 151870, "f030": 151872, "Chelsie": 151872,
+                              "prefix_caching": 151870}
+
+    def set_thinker_special_embeddings(self, rows) -> None:
+        """Rows of the THINKER's token-embedding table the talker's prompt needs: ``{token id: Tensor[embedding_size]}``
+        for the speaker tokens and ``tts_text_start_token_id`` (``_init_special_tokens_embeddings``,
+        qwen2_5_omni.py:563-637: the reference keeps the whole ``thinker_embedding`` on the talker stage for these few
+        lookups; ``load_weights`` extracts them from ``thinker_embedding.weight``)."""
+        self.thinker_special_embeddings = {int(k): v.detach().to(self.dtype).to(self.device).reshape(-1)
+                                           for k, v in dict(rows).items()}
+
+    def _embed_text_spk_token(self, voice_type: Optional[str]) -> torch.Tensor:
+        rows = getattr(self, "thinker_special_embeddings", None)
+        if not rows:
+            raise RuntimeError("the talker's prompt needs rows of the thinker's embedding table: load a checkpoint with "
+                               "thinker_embedding.weight or call set_thinker_special_embeddings()")
+        tok = self.TTS_TEXT_SPK_TOKEN_IDS.get(voice_type or "")
+        if tok is None or tok not in rows:            # unknown voice: the text BOS row (qwen2_5_omni.py:639-642)
+            tok = self.config.tts_text_start_token_id
+        return rows[int(tok)]
+
+    def thinker_to_talker_process(self, info: dict, voice_type: Optional[str] = "Chelsie"):
+        """What the reference's ``preprocess`` hook builds for a talker request on its prefill span
+        (``thinker_to_talker_process`` / ``_thinker_to_talker_prefill``, qwen2_5_omni.py:681-764) from the request's
+        ``additional_information`` — ``prompt_embeds`` [P, E] (the thinker's hidden states over ITS prompt),
+        ``thinker_result`` [K, E] (over its reply), ``prompt_token_ids``, ``thinker_output_token_ids``:
+
+            prompt rows   = cat(prompt_embeds, emb_thinker(speaker) + emb_codec(pad), thinker_result[0] + emb_codec(bos))
+            prompt ids    = [mask] * P + [pad, bos]                       (the codec-side ids of those rows)
+            reply rows    = thinker_result[1:]                            (one per decode step, update_dict)
+
+        Returns ``(ids list, rows Tensor[P + 2, E], {"thinker_reply_part": rows})``; the runner consumes the rows as
+        the request's prompt embeddings and the reply rows through its device pool."""
+        cfg = self.config
+        e = cfg.embedding_size
+        pe = info.get("prompt_embeds")
+        tr = info.get("thinker_result")
+        zero = torch.zeros(0, e, dtype=self.dtype, device=self.device)
+        pe = pe.to(self.dtype).to(self.device) if isinstance(pe, torch.Tensor) else zero
+        tr = tr.to(self.dtype).to(self.device) if isinstance(tr, torch.Tensor) else zero
+        if tr.shape[0] == 0:
+            raise ValueError("talker request without thinker_result rows: nothing to start the codec stream from")
+        emb = self.language_model.model.embed_tokens
+        codec = lambda tok: emb[int(tok)].to(self.dtype)   # noqa: E731
+        spk = self._embed_text_spk_token(voice_type)
+        # sums in the reference's dtype arithmetic: bf16 + bf16 -> bf16 (one rounding of the exact fp32 sum)
+        row_spk = (spk.float() + codec(cfg.tts_codec_pad_token_id).float()).to(self.dtype)
+        row_bos = (tr[0].float() + codec(cfg.tts_codec_start_token_id).float()).to(self.dtype)
+        rows = torch.cat([pe.reshape(-1, e), row_spk.view(1, e), row_bos.view(1, e)], dim=0)
+        n = rows.shape[0]
+        ids = ([cfg.tts_codec_mask_token_id] * (n - 2) + [cfg.tts_codec_pad_token_id, cfg.tts_codec_start_token_id])[-n:]
+        return ids, rows, {"thinker_reply_part": tr[1:].contiguous()}
+
     def decode_one_step_embeds(self, last_token_ids: torch.Tensor, step_vec: Optional[torch.Tensor]) -> torch.Tensor:
         """Per-step talker input: ``thinker_reply_part[step] + embed(last codec token)``
         (``_thinker_to_talker_decode_one_step``, qwen2_5_omni.py:796-804), for the whole batch."""
@@ -469,6 +529,13 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
             return params[name]
 
         for raw_name, w in items:
+            if raw_name in ("thinker_embedding.weight", "thinker.model.embed_tokens.weight") and w.dim() == 2 \
+                    and w.shape[1] == cfg.embedding_size:
+                # the few rows of the thinker's embedding table the talker's prompt is built from (speaker tokens, text
+                # BOS): qwen2_5_omni.py:563-637 keeps the whole table on the talker stage for them
+                want = set(self.TTS_TEXT_SPK_TOKEN_IDS.values()) | {cfg.tts_text_start_token_id}
+                self.set_thinker_special_embeddings({t: w[t] for t in want if t is not None and t < w.shape[0]})
+                continue
             name = self._map_checkpoint_name(raw_name)
             if name is None:
                 continue
