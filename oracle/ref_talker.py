@@ -126,6 +126,11 @@ def thinker_to_talker_prefill(cfg, weights: dict, spk_row: torch.Tensor, thinker
         thinker_reply_part = thinker_result[1:]                                :716-717
 
     ``spk_row`` = the speaker token's row of the THINKER's embedding table (``_get_embed_text_spk_token``, :639-642).
+    Independent statement of the same construction in the installed HF ``transformers`` (read as text):
+    ``modeling_qwen2_5_omni.py:3859-3890`` (generate: inputs = thinker prompt states | text-BOS(speaker) embed | first
+    reply row), ``:2271-2277`` (talker forward at prefill: ``inputs_embeds[:, -1] += emb(codec_bos)``,
+    ``inputs_embeds[:, -2] += emb(codec_pad)``), ``:2292-2297`` (decode: ``emb(code) + thinker_reply_part[:, :1]``, queue
+    advances by one).
     The sums are the reference's tensor adds in the model dtype: exact fp32 sum, one rounding (``round_to``).
     Returns (ids list, rows [P + 2, E] fp32 on the ``round_to`` grid, reply rows [K - 1, E])."""
     emb = weights["language_model.model.embed_tokens.weight"].to(F32)
