@@ -302,6 +302,24 @@ def test_fused_merge_equals_the_two_kernel_merge_bit_for_bit(dev):
         assert torch.equal(out, want), step
 
 
+@pytest.mark.parametrize("bs,d,lens", [(32, 128, [4500, 2047, 2049, 4096]),      # windows of 2048 tokens
+                                         (64, 64, [8200, 4095, 4097, 4096]),       # windows of 4096 tokens, head_dim 64
+                                         (16, 64, [3000, 1025, 2048, 1024])])
+def test_long_partitions_other_block_sizes(dev, bs, d, lens):
+    """The window walk at block sizes 32 / 64 (a window is 64 BLOCKS: 2048 / 4096 tokens) and head_dim 64, one partition
+    for the whole context and partitions that end inside a window; layouts head-major and token-major."""
+    from vllm_omni_amd import ops
+
+    nq, nkv = 8, 2
+    for layout in ("head_major", "nb2"):
+        kv, kb, vb, table, q, seq_lens = _mk_case(len(lens), nq, nkv, d, bs, lens, torch.bfloat16, seed=41, layout=layout)
+        ref = ref_ops.paged_attention_decode(q, kb, vb, table, seq_lens, d ** -0.5)
+        for part in (0, 64 * bs + 32 * 3, 16384):
+            got = _run(dev, kv, layout, table, q, seq_lens, torch.float32, partition_size=part, max_seq_len=max(lens) + 7,
+                       mode="fast")
+            torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4, msg=lambda m: f"bs {bs} {layout} partition {part}: {m}")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_long_partitions_walk_the_block_id_windows(dev, dtype):
     """Partitions of more than 64 blocks (the matrix-core kernel reloads its block-id window every 64 blocks), up to ONE
