@@ -112,14 +112,16 @@ def test_fused_moe_matches_oracle(dev, dtype, T, E, k, H, I, S):
     torch.testing.assert_close(got[same], ref_free[same], rtol=3 * tol, atol=3 * atol)
 
 
+@pytest.mark.parametrize("T", [77, 8192, 5000, 513])   # one workgroup; 16, 10 and 2 workgroups (4096 pairs each)
 @pytest.mark.parametrize("rpt", [32, 64])
-def test_align_groups_pairs_by_expert(dev, rpt):
+def test_align_groups_pairs_by_expert(dev, rpt, T):
     """Bit-exact integer structure: every pair appears exactly once, in a row range owned by its expert, ranges are
-    padded to 32 rows with -1, tile_expert names the owner of every tile."""
+    padded to 32 rows with -1, tile_expert names the owner of every tile — for a decode batch (one workgroup) and for
+    prefill-sized token counts (several workgroups, each counting the pairs in front of its chunk itself)."""
     from vllm_omni_amd import _C, ops
 
     lib = _C.lib
-    T, k, E = 77, 8, 128
+    k, E = 8, 128
     g = torch.Generator().manual_seed(1)
     ids = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev)
     counts = torch.bincount(ids.reshape(-1).long(), minlength=E).to(torch.int32)
@@ -133,9 +135,10 @@ def test_align_groups_pairs_by_expert(dev, rpt):
     n_tiles = int(nt.item())
     assert n_tiles == int(((counts + rpt - 1) // rpt).sum()) and n_tiles * rpt <= max_rows
     sp_c, rop_c, te_c, flat = sp.cpu()[: n_tiles * rpt], rop.cpu(), te.cpu()[:n_tiles], ids.cpu().reshape(-1)
-    live = sp_c[sp_c >= 0]
-    assert sorted(live.tolist()) == list(range(T * k))
-    for row, pair in enumerate(sp_c.tolist()):
-        if pair >= 0:
-            assert int(te_c[row // rpt]) == int(flat[pair]) and int(rop_c[pair]) == row
+    live_rows = (sp_c >= 0).nonzero().flatten()
+    live = sp_c[live_rows].long()
+    assert torch.equal(live.sort().values, torch.arange(T * k))                      # every pair exactly once
+    assert torch.equal(te_c[live_rows // rpt].long(), flat[live].long())              # in a tile its expert owns
+    assert torch.equal(rop_c[live].long(), live_rows)                                 # and row_of_pair is the inverse
+    assert int((sp_c < 0).sum()) == n_tiles * rpt - T * k                             # everything else is -1 padding
     assert (te_c[1:] >= te_c[:-1]).all()

@@ -124,7 +124,14 @@ __global__ __launch_bounds__(256) void moe_zero_counts_kernel(int32_t* __restric
   for (int e = threadIdx.x; e < E; e += 256) counts[e] = 0;
 }
 
-// ---------------------------------------------------------------- align (one workgroup)
+// ---------------------------------------------------------------- align
+// gridDim.x workgroups, each owning one contiguous chunk of the (token, k) pairs.  The row of a pair is
+// start[expert] + (pairs of that expert in EARLIER chunks) + (its arrival rank inside the chunk): a workgroup gets the
+// middle term by counting the experts of every pair in front of its chunk itself (a few LDS-atomic passes over ids the
+// L2 already holds: the last of 16 workgroups re-reads 240 KB at 8192 tokens x top-8) instead of through a global cursor
+// array (every workgroup makes ONE pass over all ids, which also tells it each expert's true pair count for the padding),
+// so the launch needs no workspace and no second kernel.  One workgroup (the decode batch) is the round-2 kernel;
+// at 8192 tokens that one CU issued all 65 536 scattered stores itself (45-66 us).
 __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restrict__ ids,
                                                          const int32_t* __restrict__ counts, int num_pairs, int E,
                                                          int32_t* __restrict__ sorted_pairs,
@@ -133,8 +140,10 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
                                                          int32_t* __restrict__ num_tiles, int max_rows, int rpt) {
   scalar_cache_acquire();
   __shared__ int32_t start[257];   // padded row offset of every expert
-  __shared__ int32_t cursor[256];
+  __shared__ int32_t cursor[256];  // next free row of every expert, relative to start[]
+  __shared__ int32_t total[256];   // pairs of every expert as the ids really have them (counts[] is the caller's word)
   const int tid = threadIdx.x;
+  const int wg = blockIdx.x, nwg = gridDim.x;
   // padded row offset of every expert: the loads and the roundings in parallel, the short running sum by one thread
   if (tid < E) cursor[tid] = (counts[tid] + rpt - 1) / rpt * rpt;
   __syncthreads();
@@ -145,24 +154,40 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
       acc += cursor[e];
     }
     start[E] = acc;
-    num_tiles[0] = acc / rpt;
+    if (wg == 0) num_tiles[0] = acc / rpt;
   }
   __syncthreads();
-  for (int e = tid; e < E; e += 1024) cursor[e] = 0;
+  for (int e = tid; e < E; e += 1024) cursor[e] = total[e] = 0;
   __syncthreads();
-  const int total = start[E];
-  for (int r = tid; r < total && r < max_rows; r += 1024) sorted_pairs[r] = -1;
-  for (int e = tid; e < E; e += 1024)
-    for (int r = start[e]; r < start[e + 1]; r += rpt) tile_expert[r / rpt] = e;
+  // this workgroup's chunk of pairs (a multiple of 4096, so the four-pairs-per-trip loop below keeps its stride)
+  const int chunk = ((num_pairs + nwg - 1) / nwg + 4095) / 4096 * 4096;
+  const int lo = min(wg * chunk, num_pairs), hi = min(lo + chunk, num_pairs);
+  // one pass over ALL ids: pairs of every expert in front of the chunk (where the chunk's rows start) and in total
+  // (where the expert's padding starts — taken from the ids themselves, so a row is either a pair or -1 whatever the
+  // caller's counts say)
+  for (int i = tid; i < num_pairs; i += 1024) {
+    const int e = ids[i];
+    if (e >= 0 && e < E) {
+      atomicAdd(&total[e], 1);
+      if (i < lo) atomicAdd(&cursor[e], 1);
+    }
+  }
   __syncthreads();
+  // padding rows (-1) and tile owners: experts are dealt round-robin to the workgroups; a padding row is never a live
+  // row of any pair, so nobody else writes it
+  for (int e = wg + nwg * (tid >> 6); e < E; e += nwg * 16) {
+    const int live_end = start[e] + min(total[e], start[e + 1] - start[e]);
+    for (int r = live_end + (tid & 63); r < start[e + 1] && r < max_rows; r += 64) sorted_pairs[r] = -1;
+    for (int r = start[e] + rpt * (tid & 63); r < start[e + 1]; r += rpt * 64) tile_expert[r / rpt] = e;
+  }
   // four pairs per thread and trip: the id loads, the LDS atomics and the scattered stores of the four are independent,
-  // so their latencies overlap (one pair per trip was 64 dependent round trips at 8192 tokens x top-8: 45-66 us)
-  for (int i0 = tid; i0 < num_pairs; i0 += 4096) {
+  // so their latencies overlap (one pair per trip was 64 dependent round trips at 8192 tokens x top-8)
+  for (int i0 = lo + tid; i0 < hi; i0 += 4096) {
     int e[4], r[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + 1024 * u;
-      e[u] = i < num_pairs ? ids[i] : -1;
+      e[u] = i < hi ? ids[i] : -1;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -173,7 +198,7 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + 1024 * u;
-      if (i < num_pairs) {
+      if (i < hi) {
         if (r[u] >= 0) sorted_pairs[r[u]] = i;
         row_of_pair[i] = r[u] >= 0 ? r[u] : 0;
       }
@@ -414,7 +439,10 @@ extern "C" int mi_moe_align(int32_t* sorted_pairs, int32_t* row_of_pair, int32_t
     return MI_ERR_INVALID_ARG;
   if (num_experts <= 0 || num_experts > 256 || max_rows > 0x7fffffff) return MI_ERR_UNSUPPORTED;
   if (rows_per_tile != 32 && rows_per_tile != 64) return MI_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), topk_ids,
+  // one workgroup per 4096 pairs, at most 32 (a decode batch of 512 tokens x top-8 is exactly one)
+  int nwg = (num_pairs + 4095) / 4096;
+  if (nwg > 32) nwg = 32;
+  hipLaunchKernelGGL(moe_align_kernel, dim3(nwg), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), topk_ids,
                      expert_counts, num_pairs, num_experts, sorted_pairs, row_of_pair, tile_expert, num_tiles,
                      (int)max_rows, (int)rows_per_tile);
   return launch_status();
