@@ -157,8 +157,14 @@ def test_decode_steps_match_oracle(dev, enforce_eager, quant, linear_mode, monke
     assert total == 0 or agree == total, f"greedy ids disagree on {total - agree} of {total} confident rows"
     if linear_mode == "kernel":
         assert len(kernel_calls) >= 4 * cfg.num_hidden_layers   # qkv, o, gate_up (+ SiLU, fused), down of every layer
+    elif quant is None:
+        # 4 rows: "auto" hands the kernel exactly the projections of a megaelement or more (layers._streaming_kernel_wins)
+        big = sum(layers._streaming_kernel_wins(B, *lin.weight.shape)
+                  for layer in runner.model.model.layers
+                  for lin in (layer.self_attn.qkv_proj, layer.self_attn.o_proj, layer.mlp.gate_up_proj, layer.mlp.down_proj))
+        assert (len(kernel_calls) > 0) == (big > 0)
     else:
-        assert not kernel_calls                                 # 4 rows: outside the shapes "auto" hands to the kernel
+        assert not kernel_calls                                 # W8A8 layers never take the 16-bit kernel
 
 
 def test_finished_requests_are_removed_and_kv_extracted(dev):

@@ -290,7 +290,13 @@ _DEFER_QKV = os.environ.get("VLLM_OMNI_AMD_DEFER_QKV", "0") == "1"
 def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
     # measured in situ at the headline talker's shapes, whole and TP-sharded, batch 32-256 per rank:
     # ahead of the library at K 18944 and 9472 (TP 1, 2), level at 4736 with 128 rows, behind with 256 (TP 4)
-    return m <= 256 and k >= 8192 and k >= 2 * n
+    if m <= 256 and k >= 8192 and k >= 2 * n:
+        return True
+    # at <= 32 rows the kernel is at or ahead of the library on every projection measured IN A GRAPH — talker qkv 12.7
+    # against 13.4 us, o 11.7 / 12.6 (profiles/r03c_skinny_shard_shapes.log), the code predictor's 1-6 M-element
+    # linears: 9.16 against 9.70 ms per call at batch 32 (profiles/r03j_predictor_linear_modes.log) — not at 64 rows
+    # (o_proj 11.6 against 8.7) and not at 512 (19.5 against 15.9 ms per predictor call)
+    return m <= 32 and n * k >= (1 << 20)
 
 
 def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
