@@ -37,6 +37,12 @@
 #ifndef MI_SKINNY_MH8
 #define MI_SKINNY_MH8 2          // consumer waves per slab at 65-128 rows (8 m-tiles)
 #endif
+#ifndef MI_SKINNY_NST4
+// ring stages at <= 64 rows.  A stage is 28 / 24 KB there, so five / six fit (`(NSLAB) == 5 ? 5 : 6`); measured level
+// with three at 32 and 64 rows on all four talker projections (profiles/r03k_ring_depth_ab.log: gate_up 6.04 against
+// 5.96 TB/s, down 4.94 / 4.97, the two small ones 0.1-0.4 us slower) — the ring depth is not what bounds them
+#define MI_SKINNY_NST4(NSLAB) 3
+#endif
 #ifndef MI_SKINNY_LOADER_PRIO
 #define MI_SKINNY_LOADER_PRIO 3  // s_setprio of the loader waves (their issue slots come before the consumers')
 #endif
@@ -142,12 +148,25 @@ __device__ __forceinline__ void lds_read_w(uint32_t a0, uint32_t a1, u32x4_t (&w
       : "memory");
 }
 
+// vmcnt wait of a loader wave that keeps up to A - 1 later steps (PPL pieces each) in flight behind the one it waits
+// for; `rem` = steps issued after that one (fewer than A - 1 at the tail of the k range)
+template <int PPL, int A>
+__device__ __forceinline__ void wait_steps_behind(int rem) {
+  if constexpr (A <= 1) {
+    wait_vmcnt<0>();
+  } else {
+    if (rem >= A - 1) wait_vmcnt<PPL * (A - 1)>();
+    else wait_steps_behind<PPL, A - 1>(rem);
+  }
+}
+
 // NSLAB: 32-row weight slabs per tile (tile = 32 NSLAB rows); MT: 16-row m-tiles (x rows padded to 16 MT);
 // MH: consumer waves per slab, each with MT / MH m-tiles; NL: loader waves.
 // GATED: gate_up_proj with the SiluAndMul that follows it (qwen2_old.py:65-68: act_fn(gate_up_proj(x))) in the epilogue —
 // a slab is 16 gate rows and the 16 matching up rows, a tile covers 16 NSLAB output columns, and the [M, 2 I]
 // intermediate never goes to memory.
-template <typename Tag, typename OT, int NSLAB, int MT, int MH, int NL, bool GATED, bool GROUPED = false>
+// NST: stages of the LDS ring; NST - 1 steps are in flight ahead of the consumers (three everywhere: MI_SKINNY_NST4).
+template <typename Tag, typename OT, int NSLAB, int MT, int MH, int NL, bool GATED, bool GROUPED = false, int NST = 3>
 __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(const SkinnyParams p) {
   // One pipeline step = one 64-wide k block.  A stage of the LDS ring is one image of 128-byte rows: the 16 MT rows of
   // x, then the tile's 32 NSLAB weight rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7).  The image is
@@ -161,10 +180,10 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   constexpr int MTW = MT / MH;
   constexpr int kXBytes = MT * 2048;
   constexpr int kStage = kXBytes + TR * 128;
-  constexpr int NST = 3;
   constexpr int XI = MT * 2, PIECES = XI + TR / 8;
   constexpr int PPL = PIECES / NL;
-  static_assert(PIECES % NL == 0 && PPL <= 63, "equal shares; one step of pieces must fit vmcnt");
+  constexpr int AHEAD = NST - 1;   // steps in flight
+  static_assert(PIECES % NL == 0 && PPL * (AHEAD - 1) <= 63, "equal shares; the steps in flight must fit vmcnt");
   static_assert(MTW % 4 == 0 && NST * kStage <= 160 * 1024, "m-tiles are read in fours; the ring must fit the LDS");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using E = Elem<OT>;
@@ -236,14 +255,15 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
                                            (lds_void*)(st + (l + NL * i) * 1024), 16, 0, MI_SKINNY_W_AUX);
       }
     };
-    if (n_it > 0 && !(p.dbg & 1)) issue(0, 0);
-    if (n_it > 1 && !(p.dbg & 1)) issue(1, 1);
-    int stage = 2;   // stage of step it + 2
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j)
+      if (j < n_it && !(p.dbg & 1)) issue(j, j);
+    int stage = AHEAD;   // stage of step it + AHEAD (= the stage step it - 1 was read from)
     for (int it = 0; it < n_it; ++it) {
-      if (it + 1 < n_it) wait_vmcnt<PPL>();   // step `it` landed; step it + 1 may still be in flight
-      else wait_vmcnt<0>();
+      // step `it` landed; the (up to AHEAD - 1) steps issued after it may still be in flight
+      wait_steps_behind<PPL, AHEAD>(n_it - 1 - it);
       __builtin_amdgcn_s_barrier();
-      if (it + 2 < n_it && !(p.dbg & 1)) issue(it + 2, stage);
+      if (it + AHEAD < n_it && !(p.dbg & 1)) issue(it + AHEAD, stage);
       stage = stage == NST - 1 ? 0 : stage + 1;
     }
     return;
@@ -751,8 +771,9 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
   }
 #define MI_SKINNY(TAG, OT, NSLAB, MT, MH, NL, GATED)                                                              \
   do {                                                                                                            \
-    auto kern = skinny_gemm_kernel<TAG, OT, NSLAB, MT, MH, NL, GATED>;                                            \
-    constexpr int lds = 3 * (MT * 2048 + NSLAB * 4096);                                                           \
+    constexpr int nst = MT == 4 ? MI_SKINNY_NST4(NSLAB) : 3;                                                      \
+    auto kern = skinny_gemm_kernel<TAG, OT, NSLAB, MT, MH, NL, GATED, false, nst>;                                \
+    constexpr int lds = nst * (MT * 2048 + NSLAB * 4096);                                                         \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
     if (attr != hipSuccess) return MI_ERR_LAUNCH;                                                                 \
