@@ -160,7 +160,7 @@ def test_decode_steps_match_oracle(dev, enforce_eager, quant, linear_mode, monke
     elif quant is None:
         # 4 rows: "auto" hands the kernel exactly the projections of a megaelement or more (layers._streaming_kernel_wins)
         big = sum(layers._streaming_kernel_wins(B, *lin.weight.shape)
-                  for layer in runner.model.model.layers
+                  for layer in runner.model.language_model.model.layers
                   for lin in (layer.self_attn.qkv_proj, layer.self_attn.o_proj, layer.mlp.gate_up_proj, layer.mlp.down_proj))
         assert (len(kernel_calls) > 0) == (big > 0)
     else:

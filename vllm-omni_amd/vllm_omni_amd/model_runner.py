@@ -33,7 +33,7 @@ from .block_table import MultiGroupBlockTable
 from .kv_cache import KVCacheSpec, allocate_kv_cache, extract_request_kv
 from .layers import AttentionMetadata, set_forward_context
 from .sched_output import (EMPTY_MODEL_RUNNER_OUTPUT, CachedRequestData, NewRequestData, OmniModelRunnerOutput,
-                           SamplingParams, SchedulerOutput)
+                           SamplingMetadata, SamplingParams, SchedulerOutput)
 from .talker import Qwen2_5OmniTalkerForConditionalGeneration, TalkerConfig
 
 
@@ -348,8 +348,12 @@ class GPUARModelRunner:
                  kv_layout: str = "NB2_HEAD_MAJOR", enforce_eager: Optional[bool] = None,
                  engine_output_type: Optional[str] = None, max_reply_rows: Optional[int] = None,
                  seed: Optional[int] = 0, quantization: Optional[str] = None, code_predictor=None,
-                 copy_outputs: bool = True, enable_prefix_caching: Optional[bool] = None):
-        """``copy_outputs``: hand every step's ``pooler_output`` tensors back as caller-owned host tensors, as the
+                 copy_outputs: bool = True, enable_prefix_caching: Optional[bool] = None, model_cls=None):
+        """``model_cls``: the model class ``load_model`` builds (same constructor as the talker class, which is the
+        default) — how a stage brings its own ``preprocess`` / ``postprocess`` / ``sample`` hooks, as the reference's
+        model classes do (gpu_model_runner.py:1264-1309,1045-1070; gpu_ar_model_runner.py:633-650).
+
+        ``copy_outputs``: hand every step's ``pooler_output`` tensors back as caller-owned host tensors, as the
         reference does (``hidden_states.to("cpu")``, gpu_ar_model_runner.py:835).  False returns VIEWS of the pinned
         output ring, valid until ``OUT_SLOTS - 1`` further steps have been sampled (what bench.py uses: fresh 1.8 MB
         host allocations every step were measured to stall the device queues)."""
@@ -403,6 +407,8 @@ class GPUARModelRunner:
         # codec token into all residual codebooks, the talker's input is the SUM of their embeddings + the text step
         self.code_predictor_config = code_predictor
         self.code_predictor = None
+        self.model_cls = model_cls or Qwen2_5OmniTalkerForConditionalGeneration
+        self._generic_hooks = False      # set by load_model: drive the model's hooks per request (eager)
         self.parallel = get_parallel_state()
         self.model: Optional[Qwen2_5OmniTalkerForConditionalGeneration] = None
         self.kv_caches: list = []
@@ -472,7 +478,14 @@ class GPUARModelRunner:
             from .tuned import enable_tuned_gemms
 
             self.tuned_gemms = enable_tuned_gemms()
-        self.model = Qwen2_5OmniTalkerForConditionalGeneration(self.config, self.dtype, self.device, self.seed)
+        self.model = self.model_cls(self.config, self.dtype, self.device, self.seed)
+        m = self.model
+        # a model whose hooks are not the ones the vectorised step implements goes through the per-request hook loop
+        self._generic_hooks = bool((getattr(m, "has_preprocess", False) and not getattr(m, "batched_preprocess", False))
+                                   or getattr(m, "has_postprocess", False))
+        if self._generic_hooks and self.code_predictor_config is not None:
+            raise ValueError("the per-request hook loop and the fused code-predictor step are alternatives: a model class "
+                             "with its own preprocess / postprocess runs its predictor inside those hooks")
         if self.quantization == "int8":   # online W8A8 of the decoder linears (int8_config.py:391-418)
             self.model.quantize_int8()
         if self.code_predictor_config is not None:
@@ -578,7 +591,8 @@ class GPUARModelRunner:
         to_add: list[CachedRequestState] = []
         for nr in so.scheduled_new_reqs:
             prompt_embeds, info = nr.prompt_embeds, nr.additional_information
-            if prompt_embeds is None and isinstance(info, dict) and isinstance(info.get("thinker_result"), torch.Tensor):
+            if (prompt_embeds is None and isinstance(info, dict) and isinstance(info.get("thinker_result"), torch.Tensor)
+                    and not self._generic_hooks):
                 # The reference hands a talker request over as additional_information{prompt_embeds, thinker_result,
                 # prompt_token_ids, thinker_output_token_ids} and lets the MODEL's preprocess hook build the prompt rows on
                 # the prefill span (gpu_model_runner.py:1264-1309 -> talker_preprocess -> thinker_to_talker_process,
@@ -651,6 +665,8 @@ class GPUARModelRunner:
         pool ONCE; the batch rows only keep [offset, end) cursors into it.  A request that left the batch for a
         step (unscheduled / preempted) and comes back continues where it stopped (``reply_cursor``); its segment is
         released when it finishes.  A full pool raises — live rows are never overwritten."""
+        if self._generic_hooks:     # the model's preprocess hook consumes the queue from additional_information itself
+            return
         if st.reply_base < 0:
             info = st.additional_information or {}
             rp = info.get("thinker_reply_part")
@@ -803,6 +819,74 @@ class GPUARModelRunner:
                     ib.reply_offset[i] = st.reply_base + min(j1, st.reply_rows)
             t0 += k
 
+    def _update_intermediate_buffer(self, req_id: str, upd) -> None:
+        """Merge a hook's per-request update into the request's ``additional_information`` (the reference's
+        ``model_intermediate_buffer``, gpu_model_runner.py:1388-1412): a key's new value replaces the old one; tensors go
+        to the host unless the model lists the key in ``gpu_resident_buffer_keys``."""
+        st = self.requests.get(req_id)
+        if st is None or not isinstance(upd, dict) or not upd:
+            return
+        gpu_keys = getattr(self.model, "gpu_resident_buffer_keys", ())
+        info = dict(st.additional_information or {})
+        for k, v in upd.items():
+            if isinstance(v, torch.Tensor):
+                info[k] = v.detach().clone() if k in gpu_keys else v.detach().to("cpu").contiguous()
+            elif isinstance(v, list):
+                info[k] = [x.detach().to("cpu").contiguous() if isinstance(x, torch.Tensor) else x for x in v]
+            else:
+                info[k] = v
+        st.additional_information = info
+
+    def _preprocess_embeds_hooks(self, n: int, total: int, num_sched: np.ndarray, num_decodes: int) -> None:
+        """``self.inputs_embeds[:total]`` through the MODEL's ``preprocess`` hook, one call per request on its span of
+        the step — the reference's loop (gpu_model_runner.py:1264-1309): base rows are the token embeddings (or the
+        request's prompt embeddings), the hook returns the rows to overlay and a per-request update."""
+        ib = self.input_batch
+        self._arena.flush()
+        qsl = self.query_start_loc.np
+        ids_np = np.zeros(total, dtype=np.int64)
+        for i in range(n):
+            st = self.requests[ib.req_ids[i]]
+            s, k, c = int(qsl[i]), int(num_sched[i]), int(ib.num_computed_tokens_cpu[i])
+            if i < num_decodes:
+                ids_np[s] = ib.last_token_ids_cpu[i]
+            elif st.prompt_token_ids:
+                toks = (st.prompt_token_ids + st.output_token_ids)[c:c + k]
+                ids_np[s:s + len(toks)] = toks
+        input_ids = torch.from_numpy(ids_np).to(self.device)
+        self.inputs_embeds[:total] = self.model.embed_input_ids(input_ids.clamp(0, self.config.vocab_size - 1))
+        for i in range(n):
+            rid = ib.req_ids[i]
+            st = self.requests[rid]
+            s, k, c = int(qsl[i]), int(num_sched[i]), int(ib.num_computed_tokens_cpu[i])
+            if st.prompt_embeds is not None and c < st.prompt_embeds.shape[0]:
+                a = min(k, st.prompt_embeds.shape[0] - c)
+                self.inputs_embeds[s:s + a].copy_(st.prompt_embeds[c:c + a].to(self.dtype), non_blocking=True)
+            if not getattr(self.model, "has_preprocess", False):
+                continue
+            infos = dict(st.additional_information or {})
+            infos["request_id"] = rid
+            req_ids, req_embeds, upd = self.model.preprocess(input_ids=input_ids[s:s + k],
+                                                             input_embeds=self.inputs_embeds[s:s + k], **infos)
+            self._update_intermediate_buffer(rid, upd)
+            seg = min(k, int(req_embeds.shape[0]))
+            self.inputs_embeds[s:s + seg] = req_embeds[:seg].to(self.dtype)
+
+    def _postprocess_hooks(self, hidden: torch.Tensor, n: int, num_sched: np.ndarray) -> None:
+        """The model's ``postprocess`` hook on every request's rows of the step's hidden states
+        (``_process_additional_information_updates``, gpu_model_runner.py:1032-1070)."""
+        if not getattr(self.model, "has_postprocess", False):
+            return
+        ib = self.input_batch
+        qsl = self.query_start_loc.np
+        for i in range(n):
+            rid = ib.req_ids[i]
+            st = self.requests[rid]
+            s = int(qsl[i])
+            upd = self.model.postprocess(hidden[s:s + int(num_sched[i])], multimodal_outputs=None,
+                                         **(st.additional_information or {}))
+            self._update_intermediate_buffer(rid, upd)
+
     def _commit_predictor_inputs(self, n: int, padded: int = 0) -> None:
         """Per-request state rows, Philox keys and draw bases of the code predictor for this step's batch rows
         (padded graph rows point at the scratch state row ``max_num_reqs``)."""
@@ -860,7 +944,7 @@ class GPUARModelRunner:
         """Pure-decode batches replay a hipGraph.  With TP > 1 the graph contains the all-reduces (RCCL collectives
         are capturable, probed on this stack with tools/probe_rccl_graph.py; the in-tree two-shot all-reduce is a
         plain kernel launch); VLLM_OMNI_AMD_TP_GRAPH=0 keeps TP > 1 eager."""
-        if self.enforce_eager or total != n or torch.device(self.device).type != "cuda":
+        if self.enforce_eager or total != n or torch.device(self.device).type != "cuda" or self._generic_hooks:
             return False
         if num_decodes is not None and num_decodes != n:   # a one-token row still inside its prompt
             return False
@@ -944,7 +1028,8 @@ class GPUARModelRunner:
             scheduler_output = normalize_scheduler_output(scheduler_output)
         # an output whose host part is still pending may stay pending only across a pure steady-state decode step
         # (same requests, same rows, one token each): everything else reads the host-side token state
-        if self._last_output is not None and not self._last_output.done and not self._steady_decode(scheduler_output):
+        if self._last_output is not None and not self._last_output.done and (
+                self._generic_hooks or not self._steady_decode(scheduler_output)):
             self._last_output.get_output()
         kv_done = None
         if scheduler_output.finished_requests_needing_kv_transfer:
@@ -973,12 +1058,17 @@ class GPUARModelRunner:
             hidden, logits, ids = outs["hidden"], outs["logits"], outs["ids"]
         else:
             self._commit_inputs(n, total)
-            self._preprocess_embeds(n, total, num_sched, num_decodes)
+            if self._generic_hooks:
+                self._preprocess_embeds_hooks(n, total, num_sched, num_decodes)
+            else:
+                self._preprocess_embeds(n, total, num_sched, num_decodes)
             if self._h2d_done is not None:
                 self._h2d_done.record()
                 self._h2d_pending = True
             md = self._build_metadata(n, total, int(num_sched.max()), max_seq_len, num_decodes)
             hidden, logits, ids = self._forward(n, total, md)
+            if self._generic_hooks:
+                self._postprocess_hooks(hidden, n, num_sched)
         ib = self.input_batch
         # (a request recomputing after a preemption is partial until it is back at its frontier, prompt + the tokens it
         #  had generated — upstream's `seq_len < req_state.num_tokens`)
@@ -1043,7 +1133,10 @@ class GPUARModelRunner:
         # non-greedy requests (or a repetition penalty): one launch of the device sampler on the masked
         # logits — penalty, temperature, top-k, top-p and the draw; greedy rows of the batch go through it too
         states = [self.requests[r] for r in ib.req_ids[:n]]
-        if SamplingState.needed([s_.sampling_params for s_ in states]):
+        model_ids = self._model_sampler(st.logits, states, n)
+        if model_ids is not None:
+            ids = model_ids
+        elif SamplingState.needed([s_.sampling_params for s_ in states]):
             if self.sampling_state is None:
                 raise RuntimeError("non-greedy sampling needs the device sampler (GPU, vocabulary <= 15744): "
                                    "there is no host fallback")
@@ -1087,6 +1180,30 @@ class GPUARModelRunner:
         self._out_inflight[slot] = out
         self._last_output = out
         return out if async_output else out.get_output()
+
+    def _model_sampler(self, logits: torch.Tensor, states: list, n: int) -> Optional[torch.Tensor]:
+        """``prefer_model_sampler`` (gpu_ar_model_runner.py:633-650): a model with its own ``sample(logits,
+        sampling_metadata)`` draws the step's tokens; None from it (or no such model) leaves the runner's sampler in
+        charge.  Its ids land in the same device buffer the runner's sampler writes."""
+        fn = getattr(self.model, "sample", None)
+        if logits is None or not callable(fn) or not getattr(self.model, "prefer_model_sampler", False):
+            return None
+        sp = [s_.sampling_params for s_ in states]
+        dev = logits.device
+        greedy = [p.temperature <= 0 for p in sp]
+        md = SamplingMetadata(
+            temperature=None if all(greedy) else torch.tensor([max(p.temperature, 0.0) for p in sp], dtype=torch.float32, device=dev),
+            all_greedy=all(greedy), all_random=not any(greedy),
+            top_p=None if all(p.top_p >= 1.0 for p in sp) else torch.tensor([p.top_p for p in sp], dtype=torch.float32, device=dev),
+            top_k=None if all(p.top_k <= 0 for p in sp) else torch.tensor([p.top_k for p in sp], dtype=torch.int32, device=dev),
+            output_token_ids=[list(s_.output_token_ids) for s_ in states])
+        out = fn(logits[:n], md)
+        if out is None:
+            return None
+        toks = getattr(out, "sampled_token_ids", out)
+        ids = self.sampled_ids_gpu[:n]
+        ids.copy_(torch.as_tensor(toks, device=dev).reshape(-1)[:n].to(torch.int64))
+        return ids
 
     def _finish_output(self, out: AsyncOmniModelRunnerOutput) -> OmniModelRunnerOutput:
         """Host half of a step's output: wait for its device->host copy, update the token state."""

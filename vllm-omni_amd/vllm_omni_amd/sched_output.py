@@ -26,6 +26,22 @@ class SamplingParams:
     ignore_eos: bool = False
 
 
+@dataclass
+class SamplingMetadata:
+    """What a model's own ``sample(logits, sampling_metadata)`` receives when it sets ``prefer_model_sampler``
+    (gpu_ar_model_runner.py:626-650) — the fields of upstream's ``vllm.v1.sample.metadata.SamplingMetadata`` a model
+    sampler reads: per-row temperature / top-k / top-p on the logits' device, the two batch flags, and the tokens
+    generated so far per row."""
+
+    temperature: Any = None          # Tensor[n] float32, or None when all rows are greedy
+    all_greedy: bool = True
+    all_random: bool = False
+    top_p: Any = None                # Tensor[n] float32 or None (no row restricts)
+    top_k: Any = None                # Tensor[n] int32 or None
+    output_token_ids: list = field(default_factory=list)
+    generators: dict = field(default_factory=dict)
+
+
 class RequestStatus(enum.IntEnum):
     """Upstream's ``vllm.v1.request.RequestStatus`` as the reference uses it (omni_ar_scheduler.py:143,362-385):
     everything after ``PREEMPTED`` is a finished state."""

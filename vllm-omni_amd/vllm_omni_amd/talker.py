@@ -260,7 +260,16 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
     """Talker = ``thinker_to_talker_proj`` (Linear embedding_size -> hidden) + Qwen2 decoder
     (qwen2_5_omni_talker.py:72-81); ``forward`` consumes ``inputs_embeds`` (:123-148)."""
 
+    # The runner contract of the reference's model classes (gpu_model_runner.py:1264-1309,1045-1070;
+    # gpu_ar_model_runner.py:633-650): `preprocess` builds a request's input rows per step, `postprocess` returns
+    # per-request updates from its hidden rows, `sample` may replace the runner's sampler.  `batched_preprocess` is this
+    # package's addition: the runner's VECTORISED step (device reply pool + one gather-add launch, hipGraph-able)
+    # realises this class's `preprocess` for the whole batch; a subclass that changes `preprocess` sets it False and is
+    # driven through the per-request hook loop instead (eager).
     has_preprocess = True
+    has_postprocess = False
+    prefer_model_sampler = False
+    batched_preprocess = True
 
     def __init__(self, cfg: TalkerConfig, dtype=torch.bfloat16, device=None, seed: Optional[int] = 0):
         self.config = cfg
@@ -370,6 +379,27 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
         n = rows.shape[0]
         ids = ([cfg.tts_codec_mask_token_id] * (n - 2) + [cfg.tts_codec_pad_token_id, cfg.tts_codec_start_token_id])[-n:]
         return ids, rows, {"thinker_reply_part": tr[1:].contiguous()}
+
+    def preprocess(self, input_ids: torch.Tensor, input_embeds: Optional[torch.Tensor], **info_dict):
+        """The per-request hook as the reference's runner calls it (``talker_preprocess``, qwen2_5_omni.py:653-679) on one
+        request's span of the step: a span longer than one token is the prompt — rebuilt from the thinker hand-over in
+        ``info_dict`` when there is one (the update carries the reply queue) — and a one-token span is a decode step:
+        the head of the request's ``thinker_reply_part`` queue is added to the token's embedding and the update carries
+        the rest of the queue (``thinker_to_talker_decode_one_step``, :766-796).
+        Returns ``(input_ids, input_embeds, update_dict)``."""
+        if input_embeds is None and input_ids is not None:
+            input_embeds = self.embed_input_ids(input_ids)
+        if input_ids.shape[0] > 1:
+            if isinstance(info_dict.get("thinker_result"), torch.Tensor):
+                ids, rows, upd = self.thinker_to_talker_process(info_dict, info_dict.get("voice_type", "Chelsie"))
+                return torch.as_tensor(ids, dtype=torch.int64, device=rows.device), rows, upd
+            return input_ids, input_embeds, {}
+        upd = {}
+        q = info_dict.get("thinker_reply_part")
+        if isinstance(q, torch.Tensor) and q.numel() > 0:
+            upd["thinker_reply_part"] = q[1:]
+            input_embeds = self.decode_one_step_embeds(input_ids[0:1], q[0:1].to(input_embeds.device))
+        return input_ids[0:1], input_embeds[0:1], upd
 
     def decode_one_step_embeds(self, last_token_ids: torch.Tensor, step_vec: Optional[torch.Tensor]) -> torch.Tensor:
         """Per-step talker input: ``thinker_reply_part[step] + embed(last codec token)``
