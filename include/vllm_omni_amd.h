@@ -108,6 +108,35 @@ int mi_rope_neox_and_cache_splitk(void* q_out, const void* partials, int32_t spl
                                   int64_t cache_block_stride, int64_t cache_token_stride,
                                   int64_t cache_head_stride, int dtype, void* stream);
 
+/* One decode step of attention for sequences whose WHOLE context lives in ONE
+ * KV block of at most 64 tokens — the private cache of the Qwen3-Omni code
+ * predictor (models/common/qwen3_code_predictor.py:318-626 runs
+ * a 5-layer stack over the <= 33 positions of one talker token):
+ * (q/k-norm ->) neox RoPE -> append K/V at slot `positions[t]` of block
+ * `block_ids[t * block_ids_stride]` -> attention of row t's q heads over tokens
+ * 0..positions[t] of that block, in one launch; the same math as
+ * mi_rope_neox_and_cache followed by mi_paged_attn_decode (q, k rounded to the
+ * cache dtype after the rotation; fp32 softmax and P.V; one output rounding).
+ * q [T, nq*d], k / v [T, nkv*d] (views of one qkv row are fine), out [T, nq*d];
+ * head_dim 128 and rot_dim == head_dim only, nq / nkv in {1, 2, 4, 8};
+ * both norm weights or neither.  MI_ERR_UNSUPPORTED otherwise.
+ * max_position_bound: host-known upper bound of positions[] (< block_size; it
+ * sizes the per-lane registers: a launch early in the sequences runs at a higher
+ * occupancy); positions == NULL: every row sits AT max_position_bound (the code
+ * predictor steps all its sequences in lock-step). */
+int mi_rope_cache_attend_block(void* out, const void* q, const void* k, const void* v,
+                               const int64_t* positions, int32_t max_position_bound,
+                               const float* cos_sin_cache,
+                               int32_t max_position, int32_t rot_dim, const void* q_norm_weight,
+                               const void* k_norm_weight, float norm_eps, void* k_cache,
+                               void* v_cache, const int32_t* block_ids, int64_t block_ids_stride,
+                               int32_t num_tokens, int32_t num_q_heads, int32_t num_kv_heads,
+                               int32_t head_dim, int32_t block_size, int64_t out_token_stride,
+                               int64_t q_token_stride, int64_t k_token_stride,
+                               int64_t v_token_stride, int64_t cache_block_stride,
+                               int64_t cache_token_stride, int64_t cache_head_stride, float scale,
+                               int dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * A5 — paged-attention decode (q_len == 1).
  * Replaces the decode half of upstream `Attention.forward` (TRITON_ATTN on

@@ -213,7 +213,8 @@ class MI355XCodePredictor:
                 p = step + 1
                 md = AttentionMetadata(num_actual_tokens=b, max_query_len=1, query_start_loc=self._qsl1[:b + 1],
                                        seq_lens=self._seq[p][:b], max_seq_len=p + 1, block_table=self.block_table[:b],
-                                       slot_mapping=self._slots[p][:b], num_reqs=b, num_decodes=b)
+                                       slot_mapping=self._slots[p][:b], num_reqs=b, num_decodes=b, single_block=True,
+                                       uniform_position=p)
                 hid = self._stack(buf[:b, p].clone(), self._pos[p][:b], md)   # clone: the stack works in place
         out = (codes[:b].unsqueeze(-1).clone(), buf[:b].clone())
         return out + (all_logits,) if return_logits else out

@@ -46,6 +46,10 @@ class AttentionMetadata:
     num_decodes: int = 0           # leading requests with query_len == 1
     decode_partition_size: int = 0
     decode_workspace: Optional[torch.Tensor] = None
+    # every sequence's whole context lives in block_table[:, 0] (<= 64 tokens) and the step is one token per sequence
+    # at `positions`: RoPE + KV append + attention run as ONE launch (ops.rope_cache_attend_block; the code predictor)
+    single_block: bool = False
+    uniform_position: Optional[int] = None   # with single_block: every sequence's new token sits at this position
 
 
 @dataclass
@@ -190,6 +194,10 @@ class MI355XAttentionBackend:
         return [8, 16, 32]
 
 
+# VLLM_OMNI_AMD_BLOCK_ATTENTION=0: single-block steps take the general pair (RoPE + KV-write launch, paged decode) — A/B
+_BLOCK_ATTENTION = os.environ.get("VLLM_OMNI_AMD_BLOCK_ATTENTION", "1") != "0"
+
+
 class Attention:
     """``Attention(num_heads, head_size, scale, num_kv_heads=...)``; ``forward(q, k, v)`` writes K/V
     into the paged cache at ``slot_mapping`` and attends over ``block_table`` (qwen2_old.py:135-144,154).
@@ -246,6 +254,14 @@ class Attention:
         md = get_forward_context().attn_metadata
         out = torch.empty_like(q) if output is None else output
         sec = rope._section(positions)
+        if (md is not None and md.single_block and sec is None and _BLOCK_ATTENTION
+                and ops.block_attention_supported(self.num_heads, self.num_kv_heads, self.head_size, self._kb.shape[1],
+                                                  rope.cos_sin_cache.shape[1])):
+            pos = positions if md.uniform_position is None else int(md.uniform_position)
+            return ops.rope_cache_attend_block(out, q, k, v, pos, rope.cos_sin_cache, self.head_size, self._kb,
+                                               self._vb, md.block_table[:, 0], self.scale, q_norm_weight=q_norm_weight,
+                                               k_norm_weight=k_norm_weight, norm_eps=norm_eps,
+                                               max_position_bound=md.max_seq_len - 1)
         if md is None:
             ops.rope_neox_and_cache(q, k, None, positions, rope.cos_sin_cache, self.head_size, mrope_section=sec,
                                     q_norm_weight=q_norm_weight, k_norm_weight=k_norm_weight, norm_eps=norm_eps)

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Union
 
 import torch
 
@@ -115,6 +115,45 @@ def rope_neox_and_cache(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tens
         _p(k_cache), _p(v_cache), _p(slot_mapping), t, nq, nkv, head_dim, bs,
         q.stride(0), k.stride(0), v.stride(0) if v is not None else 0, cb, ct, ch,
         _dt(q.dtype), _stream()))
+
+
+def block_attention_supported(num_q_heads: int, num_kv_heads: int, head_dim: int, block_size: int, rot_dim: int) -> bool:
+    return (head_dim == 128 and rot_dim == 128 and block_size <= 64 and num_q_heads % num_kv_heads == 0
+            and num_q_heads // num_kv_heads in (1, 2, 4, 8))
+
+
+def rope_cache_attend_block(out: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                            positions: Union[torch.Tensor, int], cos_sin_cache: torch.Tensor, head_dim: int,
+                            k_cache: torch.Tensor, v_cache: torch.Tensor, block_ids: torch.Tensor, scale: float,
+                            q_norm_weight: Optional[torch.Tensor] = None, k_norm_weight: Optional[torch.Tensor] = None,
+                            norm_eps: float = 1e-6, max_position_bound: Optional[int] = None) -> torch.Tensor:
+    """(q/k-norm ->) RoPE -> K/V append -> attention in ONE launch for sequences that live in one KV block each
+    (``mi_rope_cache_attend_block``): row t's new token sits at ``positions[t]`` of block ``block_ids[t]`` and attends
+    over tokens 0..positions[t] of it.  ``block_ids`` int32 [T] (any stride: a block-table column).
+    ``positions``: int64 [T] on the device with ``max_position_bound`` >= every entry (default block_size - 1), or a
+    host int when every row sits at the same position (the code predictor's lock-step sequences)."""
+    _gpu(out, q, k, v, cos_sin_cache, k_cache, v_cache, block_ids, q_norm_weight, k_norm_weight)
+    if isinstance(positions, int):
+        bound, positions = positions, None
+    else:
+        _gpu(positions)
+        if positions.dtype != torch.int64 or positions.dim() != 1:
+            raise TypeError("positions must be int64 [T] (or a host int)")
+        bound = k_cache.shape[1] - 1 if max_position_bound is None else int(max_position_bound)
+    if cos_sin_cache.dtype != torch.float32:
+        raise TypeError("cos_sin_cache must be float32")
+    if block_ids.dtype != torch.int32 or block_ids.dim() != 1:
+        raise TypeError("block_ids must be int32 [T]")
+    t = q.shape[0]
+    nq, nkv = q.shape[-1] // head_dim, k.shape[-1] // head_dim
+    max_pos, rot_dim = cos_sin_cache.shape
+    cb, ct, ch = _cache_strides(k_cache, v_cache)
+    check("mi_rope_cache_attend_block", lib.mi_rope_cache_attend_block(
+        _p(out), _p(q), _p(k), _p(v), _p(positions), bound, _p(cos_sin_cache), max_pos, rot_dim, _p(q_norm_weight),
+        _p(k_norm_weight), float(norm_eps), _p(k_cache), _p(v_cache), _p(block_ids), block_ids.stride(0), t, nq, nkv,
+        head_dim, k_cache.shape[1], out.stride(0), q.stride(0), k.stride(0), v.stride(0), cb, ct, ch, float(scale),
+        _dt(q.dtype), _stream()))
+    return out
 
 
 # --------------------------------------------------------------------------- A5
