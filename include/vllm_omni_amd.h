@@ -382,6 +382,17 @@ int mi_talker_decode_embeds(void* out, const void* embed_table, const int64_t* t
                             int64_t num_reply_rows, int64_t out_token_stride, int dtype,
                             void* stream);
 
+/* Code-predictor step glue (qwen3_code_predictor.py:560-600: the sampled
+ * code of codebook s is stored, embedded with that codebook's table and appended to
+ * the sequence): out_a[t] = out_b[t] = embed_table[token_ids[t]] (16-bit rows of
+ * embed_dim, out_b may be NULL), ids_out[t * ids_out_stride] = token_ids[t]
+ * (may be NULL) — one launch instead of a gather and three copies.  Ids outside
+ * [0, vocab) yield a zero row. */
+int mi_embed_codes(void* out_a, void* out_b, int64_t* ids_out, const void* embed_table,
+                   const int64_t* token_ids, int32_t num_tokens, int32_t embed_dim, int32_t vocab,
+                   int64_t out_a_token_stride, int64_t out_b_token_stride, int64_t ids_out_stride,
+                   void* stream);
+
 /* ------------------------------------------------------------------------
  * A13 — W8A8 int8 linear (scheme of vllm_omni/quantization/int8_config.py:
  * 180-212,323-342,391-418): dynamic symmetric per-token activation quant

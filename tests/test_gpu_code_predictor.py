@@ -121,3 +121,25 @@ def test_code_predictor_graph_replay_equals_eager(dev):
     for x, y in zip(e1 + e2, g1 + g2):
         assert torch.equal(x, y)
     assert not torch.equal(e1[0], e2[0])
+
+
+def test_embed_codes_is_a_gather_and_two_copies(dev):
+    """``ops.embed_codes``: the predictor's per-step glue (store the code, embed it, append it to the sequence, feed the
+    next step) in one launch — bit-equal to the indexing it replaces, strided destinations, out-of-range ids -> zero row."""
+    from vllm_omni_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    V, E, B, G = 2048, 1024, 37, 8
+    table = torch.randn(V, E, generator=g).to(torch.bfloat16).to(dev)
+    ids = torch.randint(0, V, (B,), generator=g).to(dev)
+    ids[3], ids[7] = -1, V
+    buf = torch.zeros(B, G + 1, E, dtype=torch.bfloat16, device=dev)
+    nxt = torch.full((B, E), 7.0, dtype=torch.bfloat16, device=dev)
+    codes = torch.zeros(B, G, dtype=torch.int64, device=dev)
+    ops.embed_codes(ids, table, buf[:, 4], nxt, codes[:, 3])
+    want = table[ids.clamp(0, V - 1)].clone()
+    want[3], want[7] = 0, 0
+    assert torch.equal(buf[:, 4], want) and torch.equal(nxt, want) and torch.equal(codes[:, 3], ids)
+    assert int(buf[:, :4].abs().sum()) == 0 and int(buf[:, 5:].abs().sum()) == 0 and int(codes[:, :3].abs().sum()) == 0
+    ops.embed_codes(ids, table, nxt)          # single destination, no id copy
+    assert torch.equal(nxt, want)

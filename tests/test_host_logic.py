@@ -220,8 +220,9 @@ def test_linear_routing_policy_matches_the_measurements():
     for tp, down, gate_up in [(1, True, True), (2, True, True), (4, False, False), (8, False, False)]:
         for m in (64, 128, 256):
             assert L._streaming_kernel_wins(m, H, I // tp) is down, (tp, m)
-        for m in (32, 128, 256):
+        for m in (64, 128, 256):
             assert L._fused_gate_up_wins(m, I // tp, H) is gate_up, (tp, m)
+        assert L._fused_gate_up_wins(32, I // tp, H)        # <= 32 rows: one launch instead of GEMM + SiluAndMul
     assert not L._streaming_kernel_wins(512, H, I) and not L._fused_gate_up_wins(512, I, H)
     # qkv_proj / o_proj are not "deep and narrow": the plain policy leaves them on the library ...
     assert not L._streaming_kernel_wins(256, 4608, H) and not L._streaming_kernel_wins(256, H, H)
@@ -231,6 +232,7 @@ def test_linear_routing_policy_matches_the_measurements():
     for n, k in [(4608, H), (H, H), (H, I // 4), (H, I // 8), (2048, 1024), (1024, 2048), (1024, 3072)]:
         assert L._streaming_kernel_wins(32, n, k) and L._streaming_kernel_wins(1, n, k), (n, k)
     assert not L._streaming_kernel_wins(32, 512, 1024)
+    assert L._fused_gate_up_wins(32, 3072, 1024) and not L._fused_gate_up_wins(64, 3072, 1024)   # the code predictor's MLP
     # ... o_proj joins only with the deferred reduce; the code predictor's 1024 x 2048 o_proj never does
     assert L._deferred_kernel_wins(256, H, H) and L._deferred_kernel_wins(32, H, H)
     assert not L._deferred_kernel_wins(256, 1024, 2048) and not L._deferred_kernel_wins(512, H, H)

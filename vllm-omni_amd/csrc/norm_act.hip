@@ -452,6 +452,24 @@ __global__ __launch_bounds__(256) void talker_embeds_kernel(uint16_t* __restrict
   }
 }
 
+// out_a[t] = out_b[t] = table[ids[t]], ids_out[t] = ids[t]: one workgroup per token, 16 B per lane (any 16-bit type).
+__global__ __launch_bounds__(128) void embed_codes_kernel(uint16_t* __restrict__ out_a, uint16_t* __restrict__ out_b,
+                                                         int64_t* __restrict__ ids_out, const uint16_t* __restrict__ table,
+                                                         const int64_t* __restrict__ ids, int dim, int vocab, int64_t a_stride,
+                                                         int64_t b_stride, int64_t ids_stride) {
+  scalar_cache_acquire();
+  const int t = blockIdx.x;
+  const int64_t id = ids[t];
+  const bool ok = id >= 0 && id < vocab;
+  const uint16_t* src = table + (ok ? id : 0) * (int64_t)dim;
+  if (ids_out && threadIdx.x == 0) ids_out[t * ids_stride] = id;
+  for (int ch = threadIdx.x; ch < dim / 8; ch += 128) {
+    const uint4 a = ok ? *reinterpret_cast<const uint4*>(src + ch * 8) : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(out_a + t * a_stride + ch * 8) = a;
+    if (out_b) *reinterpret_cast<uint4*>(out_b + t * b_stride + ch * 8) = a;
+  }
+}
+
 template <typename Tag>
 int launch_rms(void* out, const void* x, void* residual, const void* w, float eps, int T, int H,
                int64_t xs, int64_t os, int64_t rs, hipStream_t s) {
@@ -736,5 +754,20 @@ extern "C" int mi_talker_decode_embeds(void* out, const void* embed_table, const
     hipLaunchKernelGGL((talker_embeds_kernel<f16_tag>), dim3(num_tokens), dim3(256), 0, s, o, tb, token_ids, rp, reply_idx, embed_dim, vocab, num_reply_rows, out_token_stride);
   else
     return MI_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
+extern "C" int mi_embed_codes(void* out_a, void* out_b, int64_t* ids_out, const void* embed_table, const int64_t* token_ids,
+                              int32_t num_tokens, int32_t embed_dim, int32_t vocab, int64_t out_a_token_stride,
+                              int64_t out_b_token_stride, int64_t ids_out_stride, void* stream) {
+  using namespace mi;
+  if (num_tokens == 0) return MI_OK;
+  if (!out_a || !embed_table || !token_ids || num_tokens < 0 || embed_dim <= 0 || vocab <= 0) return MI_ERR_INVALID_ARG;
+  if (embed_dim % 8 || out_a_token_stride % 8 || (out_b && out_b_token_stride % 8)) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)out_a | (uintptr_t)out_b | (uintptr_t)embed_table) & 15) return MI_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(embed_codes_kernel, dim3(num_tokens), dim3(128), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<uint16_t*>(out_a), reinterpret_cast<uint16_t*>(out_b), ids_out,
+                     reinterpret_cast<const uint16_t*>(embed_table), token_ids, embed_dim, vocab, out_a_token_stride,
+                     out_b_token_stride, ids_out_stride);
   return launch_status();
 }

@@ -112,6 +112,8 @@ class MI355XCodePredictor:
         self._in_hidden = torch.zeros(mb, emb_dim, dtype=dtype, device=device)
         self._in_seed = torch.zeros(mb, dtype=torch.int64, device=device)
         self._in_offset = torch.zeros(mb, dtype=torch.int64, device=device)
+        self._step_in = torch.zeros(mb, cfg.hidden_size, dtype=dtype, device=device)   # the stack's input row of a step
+        self._steps = torch.arange(1, g, dtype=torch.int64, device=device).view(g - 1, 1)
         self._graphs: dict = {}
 
     # ---- reference-named surface ------------------------------------------------------------------------
@@ -201,21 +203,30 @@ class MI355XCodePredictor:
                                slot_mapping=self._slots0[:2 * b], num_reqs=b, num_decodes=0)
         hid = self._stack(buf[:b, :2].reshape(2 * b, h), self._pos0[:2 * b], md)[1::2]
         all_logits = []
+        draws = base.view(1, b) + self._steps          # [G - 1, B] Philox counters of the call's draws: one launch, not G - 1
+        fused = self.proj_weight is None and torch.device(dev).type == "cuda"
         for step in range(1, g):
             logits = F.linear(hid, self.lm_head[step - 1])
             if return_logits:
                 all_logits.append(logits.float())
-            code = ops.sample_tokens(logits, temp, seed, base + step, top_k=topk, top_p=topp)
-            codes[:b, step] = code
-            # embed the predicted code -> next buffer position (the last one is only returned, never forwarded)
-            buf[:b, step + 1] = self._project(F.embedding(code, self.codec_embedding[step - 1]))
+            code = ops.sample_tokens(logits, temp, seed, draws[step - 1], top_k=topk, top_p=topp)
+            # store the code, embed it -> next buffer position (the last one is only returned, never forwarded) and the
+            # next step's input row (the stack works in place on its input): one launch (ops.embed_codes)
+            x = self._step_in[:b]
+            if fused:
+                ops.embed_codes(code, self.codec_embedding[step - 1], buf[:b, step + 1], x if step < g - 1 else None,
+                                codes[:b, step])
+            else:
+                codes[:b, step] = code
+                buf[:b, step + 1] = self._project(F.embedding(code, self.codec_embedding[step - 1]))
+                x = buf[:b, step + 1].clone()
             if step < g - 1:
                 p = step + 1
                 md = AttentionMetadata(num_actual_tokens=b, max_query_len=1, query_start_loc=self._qsl1[:b + 1],
                                        seq_lens=self._seq[p][:b], max_seq_len=p + 1, block_table=self.block_table[:b],
                                        slot_mapping=self._slots[p][:b], num_reqs=b, num_decodes=b, single_block=True,
                                        uniform_position=p)
-                hid = self._stack(buf[:b, p].clone(), self._pos[p][:b], md)   # clone: the stack works in place
+                hid = self._stack(x, self._pos[p][:b], md)
         out = (codes[:b].unsqueeze(-1).clone(), buf[:b].clone())
         return out + (all_logits,) if return_logits else out
 

@@ -359,7 +359,11 @@ def _deferred_qkv_wins(m: int, n: int, k: int) -> bool:
 
 def _fused_gate_up_wins(m: int, inter: int, k: int) -> bool:
     # same measurements: ahead at I 18944 and 9472 per rank (>= ~120 tiles in one launch), not at 4736
-    return m <= 256 and inter >= 8192
+    if m <= 256 and inter >= 8192:
+        return True
+    # <= 32 rows: the fused launch replaces a GEMM the kernel already wins (see _streaming_kernel_wins) AND the
+    # SiluAndMul launch behind it (the code predictor's 6144 x 1024 gate_up_proj at batch 32)
+    return m <= 32 and 2 * inter * k >= (1 << 20) and os.environ.get("VLLM_OMNI_AMD_FUSE_SMALL_GATE_UP", "1") == "1"
 
 
 def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_reduce: bool = False):

@@ -117,6 +117,23 @@ def rope_neox_and_cache(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tens
         _dt(q.dtype), _stream()))
 
 
+def embed_codes(ids: torch.Tensor, table: torch.Tensor, out_a: torch.Tensor, out_b: Optional[torch.Tensor] = None,
+                ids_out: Optional[torch.Tensor] = None) -> None:
+    """``out_a[t] = out_b[t] = table[ids[t]]``, ``ids_out[t] = ids[t]`` in one launch (``mi_embed_codes``): the code
+    predictor's per-step glue.  ``out_*`` [T, E] row views (any row stride), ``ids_out`` int64 [T] (any stride)."""
+    _gpu(ids, table, out_a, out_b, ids_out)
+    if ids.dtype != torch.int64 or ids.dim() != 1 or not ids.is_contiguous():
+        raise TypeError("ids must be contiguous int64 [T]")
+    if table.dim() != 2 or not table.is_contiguous() or out_a.dtype != table.dtype or out_a.stride(-1) != 1:
+        raise ValueError("table must be contiguous [V, E]; outputs rows of the same dtype")
+    if ids_out is not None and (ids_out.dtype != torch.int64 or ids_out.dim() != 1):
+        raise TypeError("ids_out must be int64 [T]")
+    check("mi_embed_codes", lib.mi_embed_codes(
+        _p(out_a), _p(out_b), _p(ids_out), _p(table), _p(ids), ids.shape[0], table.shape[1], table.shape[0],
+        out_a.stride(0), out_b.stride(0) if out_b is not None else 0, ids_out.stride(0) if ids_out is not None else 0,
+        _stream()))
+
+
 def block_attention_supported(num_q_heads: int, num_kv_heads: int, head_dim: int, block_size: int, rot_dim: int) -> bool:
     return (head_dim == 128 and rot_dim == 128 and block_size <= 64 and num_q_heads % num_kv_heads == 0
             and num_q_heads // num_kv_heads in (1, 2, 4, 8))
