@@ -43,6 +43,9 @@
 // 5.96 TB/s, down 4.94 / 4.97, the two small ones 0.1-0.4 us slower) — the ring depth is not what bounds them
 #define MI_SKINNY_NST4(NSLAB) 3
 #endif
+#ifndef MI_SKINNY_GROUPED_NST
+#define MI_SKINNY_GROUPED_NST 3  // ring stages of the grouped (sparse-MoE expert) form: 72 KB, two workgroups per CU
+#endif
 #ifndef MI_SKINNY_LOADER_PRIO
 #define MI_SKINNY_LOADER_PRIO 3  // s_setprio of the loader waves (their issue slots come before the consumers')
 #endif
@@ -811,8 +814,8 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
 
 template <typename Tag, bool GATED>
 int launch_grouped_t(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
-  auto kern = skinny_gemm_kernel<Tag, Tag, 4, 4, 1, 4, GATED, true>;
-  constexpr int lds = 3 * (4 * 2048 + 4 * 4096);
+  auto kern = skinny_gemm_kernel<Tag, Tag, 4, 4, 1, 4, GATED, true, MI_SKINNY_GROUPED_NST>;
+  constexpr int lds = MI_SKINNY_GROUPED_NST * (4 * 2048 + 4 * 4096);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return MI_ERR_LAUNCH;
