@@ -322,3 +322,48 @@ def test_talker_prompt_is_built_from_the_thinker_hand_over():
     m2 = Talker(cfg, torch.bfloat16, torch.device("cpu"), seed=0)
     with pytest.raises(RuntimeError, match="thinker's embedding table"):
         m2.thinker_to_talker_process(info)
+
+
+# ------------------------------------------------------------------ per-request hook buffer (runner contract)
+def _cpu_runner_with_request(rid="r1"):
+    from vllm_omni_amd.model_runner import CachedRequestState, GPUARModelRunner
+    from vllm_omni_amd.sched_output import SamplingParams
+    from vllm_omni_amd.talker import TalkerConfig
+
+    runner = GPUARModelRunner(TalkerConfig.from_json("mini_talker"), torch.device("cpu"), torch.bfloat16, max_num_reqs=4,
+                              max_model_len=64, max_num_batched_tokens=32, block_size=16)
+    runner.requests[rid] = CachedRequestState(rid, [1, 2], SamplingParams(), ([],), 0)
+    return runner
+
+
+def test_update_intermediate_buffer_rules_of_the_reference():
+    """The four rules the reference's own tests pin for ``_update_intermediate_buffer``
+    (tests/worker/test_omni_gpu_model_runner.py:171-243): tensors and lists are stored, successive updates accumulate
+    keys, an empty update and an unknown request id are no-ops."""
+    runner = _cpu_runner_with_request()
+    runner._update_intermediate_buffer("r1", {"my_tensor": torch.tensor([1.0, 2.0]), "my_list": [3, 4]})
+    buf = runner.model_intermediate_buffer["r1"]
+    assert torch.allclose(buf["my_tensor"], torch.tensor([1.0, 2.0])) and buf["my_list"] == [3, 4]
+    assert runner.requests["r1"].additional_information is buf
+
+    runner = _cpu_runner_with_request()
+    runner._update_intermediate_buffer("r1", {"a": torch.tensor([1.0])})
+    runner._update_intermediate_buffer("r1", {"b": torch.tensor([2.0])})
+    buf = runner.model_intermediate_buffer["r1"]
+    assert torch.allclose(buf["a"], torch.tensor([1.0])) and torch.allclose(buf["b"], torch.tensor([2.0]))
+    runner._update_intermediate_buffer("r1", {"a": torch.tensor([5.0])})          # a key's new value replaces the old one
+    assert torch.allclose(runner.model_intermediate_buffer["r1"]["a"], torch.tensor([5.0]))
+
+    runner = _cpu_runner_with_request()
+    runner._update_intermediate_buffer("r1", {})
+    assert "r1" not in runner.model_intermediate_buffer
+    runner._update_intermediate_buffer("unknown_req", {"key": torch.tensor([1.0])})
+    assert "unknown_req" not in runner.model_intermediate_buffer and "unknown_req" not in runner.requests
+
+    # tensors are detached (`.detach().to("cpu").contiguous()`, as the reference stores them), list items too
+    runner = _cpu_runner_with_request()
+    src = torch.tensor([1.0, 2.0], requires_grad=True)
+    runner._update_intermediate_buffer("r1", {"t": src, "l": [src, 7]})
+    buf = runner.model_intermediate_buffer["r1"]
+    assert not buf["t"].requires_grad and buf["t"].device.type == "cpu"
+    assert not buf["l"][0].requires_grad and buf["l"][1] == 7

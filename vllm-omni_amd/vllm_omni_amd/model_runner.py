@@ -819,6 +819,12 @@ class GPUARModelRunner:
                     ib.reply_offset[i] = st.reply_base + min(j1, st.reply_rows)
             t0 += k
 
+    @property
+    def model_intermediate_buffer(self) -> dict:
+        """``{req_id: per-request dict}`` — the reference's name for what a request's hooks accumulate
+        (gpu_model_runner.py:1388-1412); here it IS the request's ``additional_information``."""
+        return {rid: st.additional_information for rid, st in self.requests.items() if st.additional_information}
+
     def _update_intermediate_buffer(self, req_id: str, upd) -> None:
         """Merge a hook's per-request update into the request's ``additional_information`` (the reference's
         ``model_intermediate_buffer``, gpu_model_runner.py:1388-1412): a key's new value replaces the old one; tensors go
