@@ -757,7 +757,7 @@ int launch_v2(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
 int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int dtype, hipStream_t s, bool int8 = false) {
   const dim3 grid(pl.tiles * pl.split, (p.M + 16 * pl.mt - 1) / (16 * pl.mt));
   if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
-  if (pl.mt == 16 && linear_v2()) {
+  if (pl.mt == 16 && pl.nslab >= 4 && linear_v2()) {
 #define MI_V2(TAG, OT)                                                                                                   \
     do {                                                                                                                 \
       if (pl.nslab == 5) return gated ? launch_v2<TAG, OT, 10, 6, true>(p, grid, s) : launch_v2<TAG, OT, 10, 5, false>(p, grid, s); \
@@ -794,10 +794,20 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
       else MI_SKINNY(TAG, OT, 4, 4, 1, 4, GATED);                \
     }                                                            \
   } while (0)
-#define MI_SKINNY_G(TAG, OT)                  \
-  do {                                        \
-    if (gated) MI_SKINNY_T(TAG, OT, true);    \
-    else MI_SKINNY_T(TAG, OT, false);         \
+  // gated form, narrow tiles (16 / 32 output columns): a projection whose 64-column tiles would leave most CUs idle
+  // (no split-K here: the activation needs the whole sum) — TP shards of the talker's gate_up_proj, the code predictor's
+#define MI_SKINNY_NARROW(TAG, OT, NSLAB)                         \
+  do {                                                           \
+    if (pl.mt == 16) MI_SKINNY(TAG, OT, NSLAB, 16, 2, 4, true);  \
+    else if (pl.mt == 8) MI_SKINNY(TAG, OT, NSLAB, 8, 2, 4, true);\
+    else MI_SKINNY(TAG, OT, NSLAB, 4, 1, 4, true);               \
+  } while (0)
+#define MI_SKINNY_G(TAG, OT)                                     \
+  do {                                                           \
+    if (gated && pl.nslab == 1) MI_SKINNY_NARROW(TAG, OT, 1);    \
+    else if (gated && pl.nslab == 2) MI_SKINNY_NARROW(TAG, OT, 2);\
+    else if (gated) MI_SKINNY_T(TAG, OT, true);                  \
+    else MI_SKINNY_T(TAG, OT, false);                            \
   } while (0)
   if (int8) {
     if (dtype == MI_DTYPE_BF16) MI_SKINNY_G(i8_tag, bf16_tag);
@@ -807,6 +817,7 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
     else MI_SKINNY_G(f16_tag, f16_tag);
   }
 #undef MI_SKINNY_G
+#undef MI_SKINNY_NARROW
 #undef MI_SKINNY_T
 #undef MI_SKINNY
   return launch_status();
@@ -821,6 +832,29 @@ int launch_grouped_t(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
   if (attr != hipSuccess) return MI_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, grid, dim3(64 * (4 + 4)), lds, s, p);
   return launch_status();
+}
+
+// Tile of the gated form: 80 output columns when that lands the tile count just under 256, else 64 — unless that leaves
+// fewer than half of the CUs with a workgroup, then 32- or 16-column tiles (MI_GATED_NSLAB=<1|2|4|5> overrides: tuning).
+SkinnyPlan gated_plan(int m, int inter) {
+  SkinnyPlan pl;
+  const int mm = m > 256 ? 256 : m;
+  pl.mt = mm <= 64 ? 4 : mm <= 128 ? 8 : 16;   // 257-512 rows: two row blocks of 16 m-tiles (grid.y)
+  pl.split = 1;
+  const int t80 = (inter + 79) / 80, t64 = (inter + 63) / 64, t32 = (inter + 31) / 32, t16 = (inter + 15) / 16;
+  static const int force = [] {
+    const char* e = getenv("MI_GATED_NSLAB");
+    return e ? atoi(e) : 0;
+  }();
+  int ns;
+  if (force == 1 || force == 2 || force == 4 || force == 5) ns = force;
+  else if (t80 > 128 && t80 <= 256) ns = 5;
+  else if (t64 >= 128) ns = 4;     // measured (profiles/r03r_gated_narrow.log): I 9472 at 64-256 rows: 64-column tiles
+  else if (t32 >= 128) ns = 2;     // I 4736 at 128 rows: 38.0 -> 29.6 us (library pair 30.3)
+  else ns = 1;                     // I 3072 at 32 rows (the code predictor's MLP): 8.92 -> 8.70 ms per call
+  pl.nslab = ns;
+  pl.tiles = ns == 5 ? t80 : ns == 4 ? t64 : ns == 2 ? t32 : t16;
+  return pl;
 }
 
 int linear_dbg() {   // MI_LINEAR_DBG: timing experiments only (see SkinnyParams::dbg); read per call
@@ -954,12 +988,7 @@ extern "C" int mi_linear_silu_mul(void* out, const void* x, const void* weight, 
   if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)weight) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
   // a tile = 16 NSLAB output columns (gate + up rows of each); no split-K: the activation needs the whole sum
-  SkinnyPlan pl;
-  pl.mt = m <= 64 ? 4 : m <= 128 ? 8 : 16;   // 257-512 rows: two row blocks of 16 m-tiles (grid.y)
-  const int t80 = (inter + 79) / 80, t64 = (inter + 63) / 64;
-  if (t80 > 128 && t80 <= 256) { pl.nslab = 5; pl.tiles = t80; }
-  else { pl.nslab = 4; pl.tiles = t64; }
-  pl.split = 1;
+  SkinnyPlan pl = gated_plan(m, inter);
   SkinnyParams p;
   p.x = reinterpret_cast<const uint16_t*>(x);
   p.w = reinterpret_cast<const uint16_t*>(weight);
