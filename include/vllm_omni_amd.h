@@ -137,6 +137,23 @@ int mi_rope_cache_attend_block(void* out, const void* q, const void* k, const vo
                                int64_t cache_token_stride, int64_t cache_head_stride, float scale,
                                int dtype, void* stream);
 
+/* The same op fed by the fp32 split-K partials [split][T][(nq + 2 nkv) * 128] of
+ * qkv_proj (mi_linear_partials), as mi_rope_neox_and_cache_splitk is: a value is
+ * rnd(sum over slices in order (+ qkv_bias)), so results equal mi_linear +
+ * mi_rope_cache_attend_block bit for bit — the reduce launch and the RoPE launch
+ * of a decode step at <= 32 rows ride in the attention launch. */
+int mi_rope_cache_attend_block_splitk(void* out, const void* partials, int32_t split,
+                                      const void* qkv_bias, const int64_t* positions,
+                                      int32_t max_position_bound, const float* cos_sin_cache,
+                                      int32_t max_position, int32_t rot_dim,
+                                      const void* q_norm_weight, const void* k_norm_weight,
+                                      float norm_eps, void* k_cache, void* v_cache,
+                                      const int32_t* block_ids, int64_t block_ids_stride,
+                                      int32_t num_tokens, int32_t num_q_heads, int32_t num_kv_heads,
+                                      int32_t head_dim, int32_t block_size, int64_t out_token_stride,
+                                      int64_t cache_block_stride, int64_t cache_token_stride,
+                                      int64_t cache_head_stride, float scale, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * A5 — paged-attention decode (q_len == 1).
  * Replaces the decode half of upstream `Attention.forward` (TRITON_ATTN on

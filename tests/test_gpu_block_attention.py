@@ -142,6 +142,33 @@ def test_block_attention_uniform_position_equals_the_per_row_form(dev, p):
         assert torch.equal(o, outs[0]) and torch.equal(ck, caches[0][0]) and torch.equal(cv, caches[0][1])
 
 
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("p", [0, 9, 16, 33])
+def test_block_attention_from_qkv_partials_is_bit_identical(dev, p, bias):
+    """qkv_proj's split-K partials straight into the attention launch == ``linear`` then ``rope_cache_attend_block``:
+    same output bits, same cache bits (the code predictor's route at <= 32 rows)."""
+    from vllm_omni_amd import ops
+
+    dtype, nq, nkv, bs, T, d, H = torch.bfloat16, 16, 8, 64, 24, 128, 1024
+    g = torch.Generator().manual_seed(300 + p)
+    x = torch.randn(T, H, generator=g).to(dtype).to(dev)
+    w = (torch.randn((nq + 2 * nkv) * d, H, generator=g) * H ** -0.5).to(dtype).to(dev)
+    b = torch.randn((nq + 2 * nkv) * d, generator=g).to(dtype).to(dev) if bias else None
+    _, kc, vc, _, qw, kw, blocks, pos, csc = _setup(dev, dtype, T, nq, nkv, bs, [p] * T, True, seed=400 + p)
+    part = ops.linear_partials(x, w, b)
+    assert part is not None and part.split > 1
+    ka, va = kc.to(dev), vc.to(dev)
+    out_a = ops.rope_cache_attend_block_splitk(part, nq, nkv, d, p, csc.to(dev), ka, va, blocks.to(dev), d ** -0.5,
+                                               q_norm_weight=qw.to(dev), k_norm_weight=kw.to(dev))
+    qkv = ops.linear(x, w, b)
+    q, k, v = qkv.split([nq * d, nkv * d, nkv * d], dim=-1)
+    kb, vb = kc.to(dev), vc.to(dev)
+    out_b = torch.empty(T, nq * d, dtype=dtype, device=dev)
+    ops.rope_cache_attend_block(out_b, q, k, v, pos.to(dev), csc.to(dev), d, kb, vb, blocks.to(dev), d ** -0.5,
+                                q_norm_weight=qw.to(dev), k_norm_weight=kw.to(dev), max_position_bound=p)
+    assert torch.equal(out_a, out_b) and torch.equal(ka, kb) and torch.equal(va, vb)
+
+
 def test_block_attention_rejects_what_it_does_not_cover(dev):
     from vllm_omni_amd import ops
     from vllm_omni_amd._C import MIError

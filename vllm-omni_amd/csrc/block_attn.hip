@@ -41,6 +41,11 @@ struct BlockAttnParams {
   int32_t T, nkv, block_size;
   int32_t uniform_pos;     // >= 0: every row's new token sits at this position (`positions` is not read)
   float scale_log2e;
+  // PART: q / k / v are the fp32 split-K partials [S][T][(nq + 2 nkv) * 128] of qkv_proj (mi_linear_partials); a value
+  // is rnd16(sum over slices in order (+ bias)) — what mi_linear_reduce would have stored
+  const float* part;
+  const uint16_t* qkv_bias;
+  int32_t S, nq;
 };
 
 // sum over the 64 lanes, in every lane: DPP inside each row of 16, row exchanges across (common.h) — no LDS-permute
@@ -51,7 +56,7 @@ constexpr int kHD = 128;
 
 // TILES: 16-token tiles that cover the tokens already in any block of the launch (host bound on `positions`): the
 // K fragments and V rows of a lane are registers, so a launch early in a sequence runs at twice the occupancy.
-template <typename Tag, int G, bool NORM, int TILES>
+template <typename Tag, int G, bool NORM, int TILES, bool PART = false>
 __global__ __launch_bounds__(256) void block_attn_kernel(const BlockAttnParams p) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -107,12 +112,36 @@ __global__ __launch_bounds__(256) void block_attn_kernel(const BlockAttnParams p
     ox = E::from_bits(E::to_bits(x * cs - y * sn));   // neox: (x, y) = (d, d + 64)
     oy = E::from_bits(E::to_bits(y * cs + x * sn));
   };
+  // column `col` of this token's qkv row (q heads, then k heads, then v heads), as the 16-bit value the GEMM stores
+  const int64_t row_len = (int64_t)(p.nq + 2 * p.nkv) * kHD;
+  auto from_part = [&](int col) -> float {
+    const float* p0 = p.part + (int64_t)t * row_len + col;
+    float v[16];
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl)
+      if (sl < p.S) v[sl] = p0[(int64_t)sl * p.T * row_len];
+    float a = v[0];
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl)
+      if (sl < p.S) a += v[sl];
+    if (p.qkv_bias) a += E::from_bits(p.qkv_bias[col]);
+    return E::from_bits(E::to_bits(a));
+  };
   float kx, ky;
-  {
+  if constexpr (PART) {
+    const int col = (p.nq + kvh) * kHD;
+    norm_rope(from_part(col + lane), from_part(col + 64 + lane), p.k_norm_w, kx, ky);
+  } else {
     const uint16_t* kr = p.k + (int64_t)t * p.k_tok + kvh * kHD;
     norm_rope(E::from_bits(kr[lane]), E::from_bits(kr[64 + lane]), p.k_norm_w, kx, ky);
   }
-  const uint32_t vnew = *reinterpret_cast<const uint32_t*>(p.v + (int64_t)t * p.v_tok + kvh * kHD + 2 * lane);
+  uint32_t vnew;
+  if constexpr (PART) {
+    const int col = (p.nq + p.nkv + kvh) * kHD + 2 * lane;
+    vnew = E::pack(from_part(col), from_part(col + 1));
+  } else {
+    vnew = *reinterpret_cast<const uint32_t*>(p.v + (int64_t)t * p.v_tok + kvh * kHD + 2 * lane);
+  }
   if (live) {
     uint16_t* kd = kblk + (int64_t)pos * p.c_tok;
     kd[lane] = E::to_bits(kx);
@@ -122,9 +151,14 @@ __global__ __launch_bounds__(256) void block_attn_kernel(const BlockAttnParams p
   float s_new[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const uint16_t* qr = p.q + (int64_t)t * p.q_tok + (kvh * G + g) * kHD;
     float qx, qy;
-    norm_rope(E::from_bits(qr[lane]), E::from_bits(qr[64 + lane]), p.q_norm_w, qx, qy);
+    if constexpr (PART) {
+      const int col = (kvh * G + g) * kHD;
+      norm_rope(from_part(col + lane), from_part(col + 64 + lane), p.q_norm_w, qx, qy);
+    } else {
+      const uint16_t* qr = p.q + (int64_t)t * p.q_tok + (kvh * G + g) * kHD;
+      norm_rope(E::from_bits(qr[lane]), E::from_bits(qr[64 + lane]), p.q_norm_w, qx, qy);
+    }
     lq[w][g * kHD + lane] = E::to_bits(qx);
     lq[w][g * kHD + 64 + lane] = E::to_bits(qy);
     s_new[g] = wave_sum(qx * kx + qy * ky);
@@ -211,8 +245,13 @@ int launch_block_attn(const BlockAttnParams& p, bool norm, int tiles, hipStream_
   const dim3 grid((unsigned)(((int64_t)p.T * p.nkv + 3) / 4)), block(256);
 #define MI_BA_T(N)                                                                                        \
   do {                                                                                                    \
-    if (norm) hipLaunchKernelGGL((block_attn_kernel<Tag, G, true, N>), grid, block, 0, s, p);            \
-    else hipLaunchKernelGGL((block_attn_kernel<Tag, G, false, N>), grid, block, 0, s, p);                \
+    if (p.part) {                                                                                         \
+      if (norm) hipLaunchKernelGGL((block_attn_kernel<Tag, G, true, N, true>), grid, block, 0, s, p);    \
+      else hipLaunchKernelGGL((block_attn_kernel<Tag, G, false, N, true>), grid, block, 0, s, p);        \
+    } else {                                                                                              \
+      if (norm) hipLaunchKernelGGL((block_attn_kernel<Tag, G, true, N>), grid, block, 0, s, p);          \
+      else hipLaunchKernelGGL((block_attn_kernel<Tag, G, false, N>), grid, block, 0, s, p);              \
+    }                                                                                                     \
   } while (0)
   if (tiles <= 1) MI_BA_T(1);
   else if (tiles == 2) MI_BA_T(2);
@@ -225,25 +264,67 @@ int launch_block_attn(const BlockAttnParams& p, bool norm, int tiles, hipStream_
 }  // namespace
 }  // namespace mi
 
+namespace {
+int block_attend(void* out, const void* q, const void* k, const void* v, const float* partials, int32_t split,
+                 const void* qkv_bias, const int64_t* positions, int32_t max_position_bound, const float* cos_sin_cache,
+                 int32_t max_position, int32_t rot_dim, const void* q_norm_weight, const void* k_norm_weight, float norm_eps,
+                 void* k_cache, void* v_cache, const int32_t* block_ids, int64_t block_ids_stride, int32_t num_tokens,
+                 int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size, int64_t out_token_stride,
+                 int64_t q_token_stride, int64_t k_token_stride, int64_t v_token_stride, int64_t cache_block_stride,
+                 int64_t cache_token_stride, int64_t cache_head_stride, float scale, int dtype, void* stream);
+}  // namespace
+
+extern "C" int mi_rope_cache_attend_block_splitk(
+    void* out, const void* partials, int32_t split, const void* qkv_bias, const int64_t* positions,
+    int32_t max_position_bound, const float* cos_sin_cache, int32_t max_position, int32_t rot_dim,
+    const void* q_norm_weight, const void* k_norm_weight, float norm_eps, void* k_cache, void* v_cache,
+    const int32_t* block_ids, int64_t block_ids_stride, int32_t num_tokens, int32_t num_q_heads, int32_t num_kv_heads,
+    int32_t head_dim, int32_t block_size, int64_t out_token_stride, int64_t cache_block_stride,
+    int64_t cache_token_stride, int64_t cache_head_stride, float scale, int dtype, void* stream) {
+  if (num_tokens == 0) return MI_OK;
+  if (!partials || split < 1 || split > 16 || ((uintptr_t)partials & 3)) return MI_ERR_INVALID_ARG;
+  return block_attend(out, nullptr, nullptr, nullptr, reinterpret_cast<const float*>(partials), split, qkv_bias, positions,
+                      max_position_bound, cos_sin_cache, max_position, rot_dim, q_norm_weight, k_norm_weight, norm_eps,
+                      k_cache, v_cache, block_ids, block_ids_stride, num_tokens, num_q_heads, num_kv_heads, head_dim,
+                      block_size, out_token_stride, 0, 0, 0, cache_block_stride, cache_token_stride, cache_head_stride,
+                      scale, dtype, stream);
+}
+
 extern "C" int mi_rope_cache_attend_block(
     void* out, const void* q, const void* k, const void* v, const int64_t* positions, int32_t max_position_bound,
-    const float* cos_sin_cache,
-    int32_t max_position, int32_t rot_dim, const void* q_norm_weight, const void* k_norm_weight, float norm_eps, void* k_cache,
-    void* v_cache, const int32_t* block_ids, int64_t block_ids_stride, int32_t num_tokens, int32_t num_q_heads,
-    int32_t num_kv_heads, int32_t head_dim, int32_t block_size, int64_t out_token_stride, int64_t q_token_stride,
-    int64_t k_token_stride, int64_t v_token_stride, int64_t cache_block_stride, int64_t cache_token_stride,
-    int64_t cache_head_stride, float scale, int dtype, void* stream) {
+    const float* cos_sin_cache, int32_t max_position, int32_t rot_dim, const void* q_norm_weight,
+    const void* k_norm_weight, float norm_eps, void* k_cache, void* v_cache, const int32_t* block_ids,
+    int64_t block_ids_stride, int32_t num_tokens, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+    int32_t block_size, int64_t out_token_stride, int64_t q_token_stride, int64_t k_token_stride,
+    int64_t v_token_stride, int64_t cache_block_stride, int64_t cache_token_stride, int64_t cache_head_stride,
+    float scale, int dtype, void* stream) {
+  if (num_tokens == 0) return MI_OK;
+  if (!q || !k || !v || ((uintptr_t)v & 3) || v_token_stride % 2) return MI_ERR_INVALID_ARG;
+  return block_attend(out, q, k, v, nullptr, 0, nullptr, positions, max_position_bound, cos_sin_cache, max_position, rot_dim,
+                      q_norm_weight, k_norm_weight, norm_eps, k_cache, v_cache, block_ids, block_ids_stride, num_tokens,
+                      num_q_heads, num_kv_heads, head_dim, block_size, out_token_stride, q_token_stride, k_token_stride,
+                      v_token_stride, cache_block_stride, cache_token_stride, cache_head_stride, scale, dtype, stream);
+}
+
+namespace {
+int block_attend(void* out, const void* q, const void* k, const void* v, const float* partials, int32_t split,
+                 const void* qkv_bias, const int64_t* positions, int32_t max_position_bound, const float* cos_sin_cache,
+                 int32_t max_position, int32_t rot_dim, const void* q_norm_weight, const void* k_norm_weight, float norm_eps,
+                 void* k_cache, void* v_cache, const int32_t* block_ids, int64_t block_ids_stride, int32_t num_tokens,
+                 int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size, int64_t out_token_stride,
+                 int64_t q_token_stride, int64_t k_token_stride, int64_t v_token_stride, int64_t cache_block_stride,
+                 int64_t cache_token_stride, int64_t cache_head_stride, float scale, int dtype, void* stream) {
+
   using namespace mi;
   if (num_tokens == 0) return MI_OK;
-  if (!out || !q || !k || !v || !cos_sin_cache || !k_cache || !v_cache || !block_ids) return MI_ERR_INVALID_ARG;
+  if (!out || !cos_sin_cache || !k_cache || !v_cache || !block_ids) return MI_ERR_INVALID_ARG;
   if (max_position_bound < 0 || max_position_bound >= block_size) return MI_ERR_INVALID_ARG;
   if (num_tokens < 0 || num_q_heads <= 0 || num_kv_heads <= 0 || max_position <= 0 || block_size <= 0) return MI_ERR_INVALID_ARG;
   if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
   if (head_dim != kHD || rot_dim != kHD || block_size > 64 || num_q_heads % num_kv_heads) return MI_ERR_UNSUPPORTED;
   if ((q_norm_weight != nullptr) != (k_norm_weight != nullptr)) return MI_ERR_INVALID_ARG;
-  if (out_token_stride % 2 || v_token_stride % 2 || cache_block_stride % 8 || cache_token_stride % 8 || cache_head_stride % 8)
-    return MI_ERR_INVALID_ARG;
-  if (((uintptr_t)out | (uintptr_t)v) & 3 || ((uintptr_t)k_cache | (uintptr_t)v_cache) & 15 || ((uintptr_t)cos_sin_cache & 3))
+  if (out_token_stride % 2 || cache_block_stride % 8 || cache_token_stride % 8 || cache_head_stride % 8) return MI_ERR_INVALID_ARG;
+  if (((uintptr_t)out & 3) || ((uintptr_t)k_cache | (uintptr_t)v_cache) & 15 || ((uintptr_t)cos_sin_cache & 3))
     return MI_ERR_INVALID_ARG;
   BlockAttnParams p;
   p.out = reinterpret_cast<uint16_t*>(out);
@@ -264,6 +345,10 @@ extern "C" int mi_rope_cache_attend_block(
   p.bt_stride = block_ids_stride;
   p.T = num_tokens; p.nkv = num_kv_heads; p.block_size = block_size;
   p.uniform_pos = positions ? -1 : max_position_bound;
+  p.part = partials;
+  p.qkv_bias = reinterpret_cast<const uint16_t*>(qkv_bias);
+  p.S = split;
+  p.nq = num_q_heads;
   const int tiles = (max_position_bound + 15) / 16;
   p.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -281,3 +366,4 @@ extern "C" int mi_rope_cache_attend_block(
   MI_BA(f16_tag);
 #undef MI_BA
 }
+}  // namespace

@@ -276,6 +276,14 @@ class Attention:
         """``forward_fused_rope`` when qkv_proj handed over split-K partials: their reduction (+ bias) happens inside
         the RoPE + KV-write launch; same result bit for bit."""
         md = get_forward_context().attn_metadata
+        if (md.single_block and rope._section(positions) is None and _BLOCK_ATTENTION
+                and ops.block_attention_supported(self.num_heads, self.num_kv_heads, self.head_size, self._kb.shape[1],
+                                                  rope.cos_sin_cache.shape[1])):
+            pos = positions if md.uniform_position is None else int(md.uniform_position)
+            return ops.rope_cache_attend_block_splitk(qkv, self.num_heads, self.num_kv_heads, self.head_size, pos,
+                                                      rope.cos_sin_cache, self._kb, self._vb, md.block_table[:, 0], self.scale,
+                                                      q_norm_weight=q_norm_weight, k_norm_weight=k_norm_weight,
+                                                      norm_eps=norm_eps, max_position_bound=md.max_seq_len - 1)
         q = ops.rope_neox_and_cache_splitk(qkv, self.num_heads, self.num_kv_heads, self.head_size, positions,
                                            rope.cos_sin_cache, self._kb, self._vb, md.slot_mapping,
                                            mrope_section=rope._section(positions), q_norm_weight=q_norm_weight,

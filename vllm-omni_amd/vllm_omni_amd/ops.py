@@ -173,6 +173,38 @@ def rope_cache_attend_block(out: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
     return out
 
 
+def rope_cache_attend_block_splitk(part: "SplitKPartials", num_q_heads: int, num_kv_heads: int, head_dim: int,
+                                   positions: Union[torch.Tensor, int], cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
+                                   v_cache: torch.Tensor, block_ids: torch.Tensor, scale: float,
+                                   q_norm_weight: Optional[torch.Tensor] = None,
+                                   k_norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 1e-6,
+                                   max_position_bound: Optional[int] = None) -> torch.Tensor:
+    """``rope_cache_attend_block`` fed by the split-K partials of ``qkv_proj`` (``linear_partials``): returns the
+    attention output [T, nq*d]; bit-identical to ``linear`` + ``rope_cache_attend_block``."""
+    _gpu(cos_sin_cache, k_cache, v_cache, block_ids, q_norm_weight, k_norm_weight)
+    part._live()
+    if part.n != (num_q_heads + 2 * num_kv_heads) * head_dim:
+        raise ValueError("partials row is not [q heads | k heads | v heads]")
+    if isinstance(positions, int):
+        bound, positions = positions, None
+    else:
+        _gpu(positions)
+        if positions.dtype != torch.int64 or positions.dim() != 1:
+            raise TypeError("positions must be int64 [T] (or a host int)")
+        bound = k_cache.shape[1] - 1 if max_position_bound is None else int(max_position_bound)
+    if cos_sin_cache.dtype != torch.float32 or block_ids.dtype != torch.int32 or block_ids.dim() != 1:
+        raise TypeError("cos_sin_cache must be float32, block_ids int32 [T]")
+    max_pos, rot_dim = cos_sin_cache.shape
+    cb, ct, ch = _cache_strides(k_cache, v_cache)
+    out = torch.empty(part.m, num_q_heads * head_dim, dtype=part.dtype, device=part.device)
+    check("mi_rope_cache_attend_block_splitk", lib.mi_rope_cache_attend_block_splitk(
+        _p(out), _p(part.part), part.split, _p(part.bias), _p(positions), bound, _p(cos_sin_cache), max_pos, rot_dim,
+        _p(q_norm_weight), _p(k_norm_weight), float(norm_eps), _p(k_cache), _p(v_cache), _p(block_ids), block_ids.stride(0),
+        part.m, num_q_heads, num_kv_heads, head_dim, k_cache.shape[1], out.stride(0), cb, ct, ch, float(scale),
+        _dt(part.dtype), _stream()))
+    return out
+
+
 # --------------------------------------------------------------------------- A5
 # Default decode mode (see include/vllm_omni_amd.h, flags): True = P may be rounded to the cache dtype
 # before P.V, as the reference's TRITON_ATTN kernel does -> matrix-core kernel where built (head_dim 128,
