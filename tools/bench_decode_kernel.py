@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--modes", default="0,1,2", help="0 = exact fp32-P VALU, 1 = packed dot2 VALU, 2 = MFMA, 3 = MFMA + nt (production), "
                     "4 = MFMA + nt with the single-rounding P of round 2 (A/B)")
     ap.add_argument("--two-kernels", action="store_true", help="merge the partitions with decode_reduce_kernel (A/B)")
+    ap.add_argument("--ragged", default=None, metavar="LO",
+                    help="sequence lengths uniform in [LO * ctx, ctx] (seeded) instead of every sequence at ctx: what a serving "
+                         "batch looks like; GB/s then counts the bytes of the actual lengths")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -44,9 +47,13 @@ def main():
         kb, vb = kv[:, 0].permute(0, 2, 1, 3), kv[:, 1].permute(0, 2, 1, 3)
     table = (torch.randperm(nb - 1, device=dev)[: a.batch * blocks_per_seq] + 1).view(a.batch, -1).to(torch.int32)
     seq_lens = torch.full((a.batch,), a.ctx, dtype=torch.int32, device=dev)
+    if a.ragged is not None:
+        lo = max(1, int(float(a.ragged) * a.ctx))
+        seq_lens = torch.randint(lo, a.ctx + 1, (a.batch,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)
+        seq_lens[0] = a.ctx
     q = torch.randn(a.batch, a.nq * a.d, dtype=torch.bfloat16, device=dev)
     out = torch.empty_like(q)
-    algo_bytes = 2 * a.nkv * a.d * 2 * a.ctx * a.batch
+    algo_bytes = 2 * a.nkv * a.d * 2 * int(seq_lens.sum())
     print(f"layout={a.layout} batch={a.batch} ctx={a.ctx} nq={a.nq} nkv={a.nkv} d={a.d} "
           f"algorithmic bytes/launch={algo_bytes / 1e9:.3f} GB")
     for mode in [int(x) for x in a.modes.split(",")]:
