@@ -304,7 +304,7 @@ int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_
  *                  weight_round_dtype as HF does; -1 = keep fp32); per-expert
  *                  pair counts (zeroed inside).  num_experts in {64, 128, 256}.
  *   mi_moe_align   groups the T*k (token, slot) pairs by expert, each group padded
- *                  to a multiple of rows_per_tile (32 or 64; mi_moe_rows_per_tile()
+ *                  to a multiple of rows_per_tile (32, 64, 128 or 256; mi_moe_rows_per_tile()
  *                  picks by mean pairs per expert): sorted_pairs[row] = pair or -1,
  *                  row_of_pair[pair], tile_expert[row / rows_per_tile], num_tiles[0].
  *                  Buffers sized by mi_moe_max_rows().
@@ -318,7 +318,7 @@ int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_
  *   mi_moe_combine out[t] = sum_j w[t, j] * partial[row_of_pair[t*k + j]]
  *                  (+ g * shared_out[t], g = sigmoid(x[t] . shared_gate_weight) or 1).
  * ---------------------------------------------------------------------- */
-int32_t mi_moe_rows_per_tile(int32_t num_tokens, int32_t top_k, int32_t num_experts); /* 32 or 64 */
+int32_t mi_moe_rows_per_tile(int32_t num_tokens, int32_t top_k, int32_t num_experts); /* 32, 64 or (prefill chunks) 256 */
 int64_t mi_moe_max_rows(int32_t num_tokens, int32_t top_k, int32_t num_experts, int32_t rows_per_tile);
 int mi_moe_route(int32_t* topk_ids, float* topk_weights, int32_t* expert_counts, const void* router_logits,
                  int32_t num_tokens, int32_t num_experts, int64_t logits_row_stride, int32_t top_k,

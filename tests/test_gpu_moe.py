@@ -68,6 +68,7 @@ def test_route_ties_take_the_lowest_expert_and_counts_add_up(dev):
     (37, 128, 8, 1024, 384, 768),      # the talker shape, ragged token count
     (1, 128, 8, 1024, 384, 768),       # one token: 8 tiles of one live row
     (300, 64, 4, 256, 128, None),      # several tiles per expert, no shared expert
+    (1500, 64, 8, 256, 128, None),     # a prefill chunk: ~190 rows per expert (two 128-row tiles, one 256-row tile)
     (5, 64, 2, 128, 64, 128),
 ])
 def test_fused_moe_matches_oracle(dev, dtype, T, E, k, H, I, S):
@@ -83,8 +84,9 @@ def test_fused_moe_matches_oracle(dev, dtype, T, E, k, H, I, S):
     # both tile heights give the same rows (an output row does not depend on which tile computed it)
     from vllm_omni_amd import ops as _ops
     lg = torch.nn.functional.linear(x.to(dev), blk.gate_weight)
-    assert torch.equal(_ops.fused_moe(x.to(dev), lg, blk.gate_up_proj, blk.down_proj, k, False, rows_per_tile=32),
-                       _ops.fused_moe(x.to(dev), lg, blk.gate_up_proj, blk.down_proj, k, False, rows_per_tile=64))
+    by_tile = [_ops.fused_moe(x.to(dev), lg, blk.gate_up_proj, blk.down_proj, k, False, rows_per_tile=r)
+               for r in (32, 64, 128, 256)]      # 128 / 256: the prefill-chunk tiles of the ring kernel
+    assert all(torch.equal(by_tile[0], o) for o in by_tile[1:])
     # the device's routing (from its own 16-bit router logits), checked against the oracle's on the same logits
     from vllm_omni_amd import ops
     logits = torch.nn.functional.linear(x.to(dev), blk.gate_weight)

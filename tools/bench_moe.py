@@ -48,6 +48,8 @@ def main():
         t_fused = timeit(lambda: ops.fused_moe(x, logits, blk.gate_up_proj, blk.down_proj, k, False))
         # the two expert-GEMM kernels x the two tile heights, interleaved rounds in one process
         arms = [("ring", 32), ("ring", 64), ("direct", 32), ("direct", 64)]
+        if t * k >= 64 * e:     # prefill-sized: the tall tiles of the ring kernel
+            arms = [("ring", 64), ("ring", 128), ("ring", 256), ("direct", 64)]
         res = {a_: [] for a_ in arms}
         for _ in range(4):
             for mode, rpt in arms:
@@ -69,7 +71,7 @@ def main():
                 y = F.linear(F.silu(g) * u, blk.down_proj[ex]) * w[tok, pos, None].to(x.dtype)
                 out.index_add_(0, tok, y)
             return out
-        t_loop = timeit(torch_loop, iters=3, warm=1)
+        t_loop = timeit(torch_loop, iters=3, warm=1) if t <= 1024 else float("nan")
         print(f"T={t:4d}: {hit} experts hit | expert path (route..combine) {t_fused:7.1f} us = "
               f"{wbytes * hit / e / t_fused / 1e6:5.2f} TB/s of expert weights | whole layer incl. router + shared expert "
               f"{t_layer:7.1f} us | per-expert torch loop {t_loop:8.1f} us")

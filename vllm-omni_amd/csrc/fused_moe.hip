@@ -377,6 +377,11 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(uint16_t* __restrict__
 }  // namespace
 }  // namespace mi
 
+namespace {
+// 32 / 64: both expert GEMM kernels; 128 / 256 (prefill chunks): the ring kernel only
+bool moe_rows_per_tile_ok(int32_t r) { return r == 32 || r == 64 || r == 128 || r == 256; }
+}  // namespace
+
 extern "C" int32_t mi_moe_rows_per_tile(int32_t num_tokens, int32_t top_k, int32_t num_experts) {
   if (num_tokens <= 0 || top_k <= 0 || num_experts <= 0) return 32;
   // The ring kernel (skinny_gemm.hip, grouped form) stages a 64-row image per tile whatever the tile height, and every
@@ -385,11 +390,15 @@ extern "C" int32_t mi_moe_rows_per_tile(int32_t num_tokens, int32_t top_k, int32
   // The fragments-from-global kernel (MI_MOE_GEMM=direct) is faster with 32-row tiles at every size measured.
   const char* e = getenv("MI_MOE_GEMM");
   if (e && strcmp(e, "direct") == 0) return 32;
+  // Prefill chunks (an expert sees hundreds of rows): 256-row tiles stream an expert's weights 4x less often than 64-row
+  // ones — 459 against 497 us at 8192 tokens, 277 / 294 at 4096, level at 2048, behind at 1024
+  // (profiles/r03w_moe_tall_tiles.log); the gain is small because K is short here (1024 / 384: 16 / 6 ring steps per tile)
+  if ((int64_t)num_tokens * top_k >= 256 * (int64_t)num_experts) return 256;
   return (int64_t)num_tokens * top_k > 24 * (int64_t)num_experts ? 64 : 32;
 }
 
 extern "C" int64_t mi_moe_max_rows(int32_t num_tokens, int32_t top_k, int32_t num_experts, int32_t rows_per_tile) {
-  if (num_tokens <= 0 || top_k <= 0 || num_experts <= 0 || (rows_per_tile != 32 && rows_per_tile != 64)) return 0;
+  if (num_tokens <= 0 || top_k <= 0 || num_experts <= 0 || !moe_rows_per_tile_ok(rows_per_tile)) return 0;
   const int64_t pairs = (int64_t)num_tokens * top_k;
   const int64_t hit = pairs < num_experts ? pairs : num_experts;  // each hit expert pads by < rows_per_tile rows
   return (pairs + hit * (rows_per_tile - 1) + rows_per_tile - 1) / rows_per_tile * rows_per_tile;
@@ -438,7 +447,7 @@ extern "C" int mi_moe_align(int32_t* sorted_pairs, int32_t* row_of_pair, int32_t
   if (!sorted_pairs || !row_of_pair || !tile_expert || !num_tiles || !topk_ids || !expert_counts || num_pairs < 0)
     return MI_ERR_INVALID_ARG;
   if (num_experts <= 0 || num_experts > 256 || max_rows > 0x7fffffff) return MI_ERR_UNSUPPORTED;
-  if (rows_per_tile != 32 && rows_per_tile != 64) return MI_ERR_INVALID_ARG;
+  if (!moe_rows_per_tile_ok(rows_per_tile)) return MI_ERR_INVALID_ARG;
   // one workgroup per 4096 pairs, at most 32 (a decode batch of 512 tokens x top-8 is exactly one)
   int nwg = (num_pairs + 4095) / 4096;
   if (nwg > 32) nwg = 32;
@@ -458,7 +467,7 @@ extern "C" int mi_moe_expert_gemm(void* out, const void* a_rows, const void* wei
   if (!out || !a_rows || !weights || !sorted_pairs || !tile_expert || !num_tiles || max_tiles < 0)
     return MI_ERR_INVALID_ARG;
   if (k <= 0 || k % 64 || n_out <= 0 || n_out % (gated ? 64 : 128)) return MI_ERR_UNSUPPORTED;
-  if (rows_per_tile != 32 && rows_per_tile != 64) return MI_ERR_INVALID_ARG;
+  if (!moe_rows_per_tile_ok(rows_per_tile)) return MI_ERR_INVALID_ARG;
   if (a_row_stride % 8 || out_row_stride % 4 || weight_expert_stride % 8) return MI_ERR_INVALID_ARG;
   if (((uintptr_t)a_rows | (uintptr_t)weights) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -479,6 +488,7 @@ extern "C" int mi_moe_expert_gemm(void* out, const void* a_rows, const void* wei
       if (rc != MI_ERR_UNSUPPORTED) return rc;
     }
   }
+  if (rows_per_tile > 64) return MI_ERR_UNSUPPORTED;   // the fragments-from-global kernel has 32- and 64-row tiles only
   MoeGemmParams p;
   p.a_rows = reinterpret_cast<const uint16_t*>(a_rows);
   p.w = reinterpret_cast<const uint16_t*>(weights);

@@ -823,15 +823,25 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
   return launch_status();
 }
 
-template <typename Tag, bool GATED>
+// MT: 16-row m-tiles of a tile's row image: 4 (<= 64 token rows per tile: decode batches), 8 / 16 (128 / 256 rows: prefill
+// chunks, where an expert sees hundreds of rows and a 64-row tile would stream its weights 8-16 times)
+template <typename Tag, bool GATED, int MT>
 int launch_grouped_t(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
-  auto kern = skinny_gemm_kernel<Tag, Tag, 4, 4, 1, 4, GATED, true, MI_SKINNY_GROUPED_NST>;
-  constexpr int lds = MI_SKINNY_GROUPED_NST * (4 * 2048 + 4 * 4096);
+  constexpr int MH = MT == 4 ? 1 : 2;
+  constexpr int nst = MT == 4 ? MI_SKINNY_GROUPED_NST : 3;
+  auto kern = skinny_gemm_kernel<Tag, Tag, 4, MT, MH, 4, GATED, true, nst>;
+  constexpr int lds = nst * (MT * 2048 + 4 * 4096);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return MI_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, grid, dim3(64 * (4 + 4)), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (4 * MH + 4)), lds, s, p);
   return launch_status();
+}
+template <typename Tag, bool GATED>
+int launch_grouped_rows(const SkinnyParams& p, const dim3 grid, int rpt, hipStream_t s) {
+  if (rpt <= 64) return launch_grouped_t<Tag, GATED, 4>(p, grid, s);
+  if (rpt <= 128) return launch_grouped_t<Tag, GATED, 8>(p, grid, s);
+  return launch_grouped_t<Tag, GATED, 16>(p, grid, s);
 }
 
 // Tile of the gated form: 80 output columns when that lands the tile count just under 256, else 64 — unless that leaves
@@ -1130,7 +1140,7 @@ extern "C" int mi_int8_linear_silu_mul(void* out, const int8_t* xq, const float*
 // ---------------------------------------------------------------------------------- grouped form (sparse-MoE experts)
 namespace mi {
 int launch_grouped_skinny(const GroupedGemmArgs& a, hipStream_t s) {
-  if (a.k % 64 || a.n_out % (a.gated ? 64 : 128) || a.rows_per_tile > 64 || a.rows_per_tile <= 0) return MI_ERR_UNSUPPORTED;
+  if (a.k % 64 || a.n_out % (a.gated ? 64 : 128) || a.rows_per_tile > 256 || a.rows_per_tile <= 0) return MI_ERR_UNSUPPORTED;
   if (a.dtype != MI_DTYPE_BF16 && a.dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
   if (a.a_row_stride % 8 || a.out_row_stride % 4 || a.weight_expert_stride % 8) return MI_ERR_UNSUPPORTED;
   SkinnyParams p;
@@ -1140,7 +1150,7 @@ int launch_grouped_skinny(const GroupedGemmArgs& a, hipStream_t s) {
   p.out = reinterpret_cast<uint16_t*>(a.out);
   p.part = nullptr;
   p.xs = p.ws = nullptr;
-  p.M = a.rows_per_tile;   // valid rows of a tile (the image holds 64: the rest repeat a valid row, never stored)
+  p.M = a.rows_per_tile;   // valid rows of a tile (the image holds 64 / 128 / 256: the rest repeat a valid row, never stored)
   p.N = a.n_out;
   p.K = a.k;
   p.S = 1;
@@ -1154,7 +1164,9 @@ int launch_grouped_skinny(const GroupedGemmArgs& a, hipStream_t s) {
   p.ldx = a.a_row_stride;
   p.ldo = a.out_row_stride;
   const dim3 grid(a.gated ? a.n_out / 64 : a.n_out / 128, a.max_tiles);
-  if (a.dtype == MI_DTYPE_BF16) return a.gated ? launch_grouped_t<bf16_tag, true>(p, grid, s) : launch_grouped_t<bf16_tag, false>(p, grid, s);
-  return a.gated ? launch_grouped_t<f16_tag, true>(p, grid, s) : launch_grouped_t<f16_tag, false>(p, grid, s);
+  const int rpt = a.rows_per_tile;
+  if (a.dtype == MI_DTYPE_BF16)
+    return a.gated ? launch_grouped_rows<bf16_tag, true>(p, grid, rpt, s) : launch_grouped_rows<bf16_tag, false>(p, grid, rpt, s);
+  return a.gated ? launch_grouped_rows<f16_tag, true>(p, grid, rpt, s) : launch_grouped_rows<f16_tag, false>(p, grid, rpt, s);
 }
 }  // namespace mi
