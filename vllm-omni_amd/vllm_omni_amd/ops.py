@@ -760,19 +760,20 @@ class Int8SplitKPartials:
 
 
 def int8_linear_partials(x, wq: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor]) -> Optional[Int8SplitKPartials]:
-    """The split-K W8A8 kernel without its reduce launch, or None when this shape has no split-K plan."""
-    if isinstance(x, QuantizedActs):
-        xq, xs, lead, dtype = x.xq, x.xs, x.lead, x.dtype
-    else:
-        xq, xs = dynamic_int8_quant(x.reshape(-1, x.shape[-1]))
-        lead, dtype = tuple(x.shape[:-1]), x.dtype
-    m, k = xq.shape
-    n = wq.shape[0]
+    """The split-K W8A8 kernel without its reduce launch, or None when this shape has no split-K plan (decided BEFORE
+    the activation is quantised: the caller's fallback quantises it itself)."""
+    n, k = wq.shape
+    m = x.xq.shape[0] if isinstance(x, QuantizedActs) else x.numel() // x.shape[-1]
     if not int8_linear_supported(m, n, k):
         return None
     need = lib.mi_int8_linear_workspace_bytes(m, n, k)
     if not need:
         return None
+    if isinstance(x, QuantizedActs):
+        xq, xs, lead, dtype = x.xq, x.xs, x.lead, x.dtype
+    else:
+        xq, xs = dynamic_int8_quant(x.reshape(-1, x.shape[-1]))
+        lead, dtype = tuple(x.shape[:-1]), x.dtype
     ws = _linear_workspace(xq.device, need)
     split = ctypes.c_int32(0)
     check("mi_int8_linear_partials", lib.mi_int8_linear_partials(_p(xq), _p(wq), m, n, k, xq.stride(0), _p(ws), ws.numel(),
