@@ -302,12 +302,14 @@ int mi_mask_logits_argmax(void* logits, int64_t* ids, int32_t num_tokens, int32_
  *   mi_moe_route   p = softmax_fp32(router_logits[t, :]); top-k ids (int32) and
  *                  weights (fp32, optionally renormalised, optionally rounded to
  *                  weight_round_dtype as HF does; -1 = keep fp32); per-expert
- *                  pair counts (zeroed inside).  num_experts in {64, 128, 256}.
+ *                  pair counts (zeroed inside; expert_counts may be NULL: no counting,
+ *                  one launch less).  num_experts in {64, 128, 256}.
  *   mi_moe_align   groups the T*k (token, slot) pairs by expert, each group padded
  *                  to a multiple of rows_per_tile (32, 64, 128 or 256; mi_moe_rows_per_tile()
  *                  picks by mean pairs per expert): sorted_pairs[row] = pair or -1,
  *                  row_of_pair[pair], tile_expert[row / rows_per_tile], num_tiles[0].
- *                  Buffers sized by mi_moe_max_rows().
+ *                  Buffers sized by mi_moe_max_rows().  expert_counts NULL: counted
+ *                  from topk_ids inside the launch.
  *   mi_moe_expert_gemm  gated != 0: out[row, :n_out] = silu(a[tok] . Wg_e^T) *
  *                  (a[tok] . Wu_e^T), weights [E, 2*n_out, k] (gate rows then up
  *                  rows), a = x [T, k], tok = sorted_pairs[row] / top_k;

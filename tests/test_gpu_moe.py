@@ -115,11 +115,12 @@ def test_fused_moe_matches_oracle(dev, dtype, T, E, k, H, I, S):
 
 
 @pytest.mark.parametrize("T", [77, 8192, 5000, 513])   # one workgroup; 16, 10 and 2 workgroups (4096 pairs each)
-@pytest.mark.parametrize("rpt", [32, 64])
-def test_align_groups_pairs_by_expert(dev, rpt, T):
+@pytest.mark.parametrize("rpt,given_counts", [(32, True), (64, True), (64, False), (256, False)])
+def test_align_groups_pairs_by_expert(dev, rpt, T, given_counts):
     """Bit-exact integer structure: every pair appears exactly once, in a row range owned by its expert, ranges are
     padded to 32 rows with -1, tile_expert names the owner of every tile — for a decode batch (one workgroup) and for
-    prefill-sized token counts (several workgroups, each counting the pairs in front of its chunk itself)."""
+    prefill-sized token counts (several workgroups, each counting the pairs in front of its chunk itself); with the
+    caller's per-expert counts, and (``expert_counts`` NULL, what ``fused_moe`` passes) counting the ids inside the launch."""
     from vllm_omni_amd import _C, ops
 
     lib = _C.lib
@@ -131,7 +132,7 @@ def test_align_groups_pairs_by_expert(dev, rpt, T):
     i32 = dict(dtype=torch.int32, device=dev)
     sp, rop, te, nt = torch.empty(max_rows, **i32), torch.empty(T * k, **i32), torch.empty(max_rows // rpt, **i32), torch.empty(1, **i32)
     ops.check("mi_moe_align", lib.mi_moe_align(sp.data_ptr(), rop.data_ptr(), te.data_ptr(), nt.data_ptr(), ids.data_ptr(),
-                                               counts.data_ptr(), T * k, E, max_rows, rpt,
+                                               counts.data_ptr() if given_counts else None, T * k, E, max_rows, rpt,
                                                torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     n_tiles = int(nt.item())

@@ -110,9 +110,10 @@ __global__ __launch_bounds__(1024) void moe_route_kernel(const void* __restrict_
       else if (round_dt == MI_DTYPE_F16) w = Elem<f16_tag>::from_bits(Elem<f16_tag>::to_bits(w));
       ids[t * top_k + lane] = mye;
       weights[t * top_k + lane] = w;
-      atomicAdd(&hist[mye], 1);
+      if (counts) atomicAdd(&hist[mye], 1);
     }
   }
+  if (!counts) return;   // the grouping that follows counts the ids itself (mi_moe_align with expert_counts == NULL)
   __syncthreads();
   for (int e = threadIdx.x; e < 64 * EPL; e += 1024) {
     const int c = hist[e];
@@ -144,19 +145,6 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
   __shared__ int32_t total[256];   // pairs of every expert as the ids really have them (counts[] is the caller's word)
   const int tid = threadIdx.x;
   const int wg = blockIdx.x, nwg = gridDim.x;
-  // padded row offset of every expert: the loads and the roundings in parallel, the short running sum by one thread
-  if (tid < E) cursor[tid] = (counts[tid] + rpt - 1) / rpt * rpt;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int e = 0; e < E; ++e) {
-      start[e] = acc;
-      acc += cursor[e];
-    }
-    start[E] = acc;
-    if (wg == 0) num_tiles[0] = acc / rpt;
-  }
-  __syncthreads();
   for (int e = tid; e < E; e += 1024) cursor[e] = total[e] = 0;
   __syncthreads();
   // this workgroup's chunk of pairs (a multiple of 4096, so the four-pairs-per-trip loop below keeps its stride)
@@ -171,6 +159,21 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int32_t* __restri
       atomicAdd(&total[e], 1);
       if (i < lo) atomicAdd(&cursor[e], 1);
     }
+  }
+  __syncthreads();
+  // padded row offset of every expert — from the caller's counts, or (counts == NULL) from the ids just counted: the
+  // roundings in parallel, the short running sum by one thread
+  __shared__ int32_t padded[256];
+  if (tid < E) padded[tid] = ((counts ? counts[tid] : total[tid]) + rpt - 1) / rpt * rpt;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int e = 0; e < E; ++e) {
+      start[e] = acc;
+      acc += padded[e];
+    }
+    start[E] = acc;
+    if (wg == 0) num_tiles[0] = acc / rpt;
   }
   __syncthreads();
   // padding rows (-1) and tile owners: experts are dealt round-robin to the workgroups; a padding row is never a live
@@ -409,13 +412,14 @@ extern "C" int mi_moe_route(int32_t* topk_ids, float* topk_weights, int32_t* exp
                             int32_t norm_topk_prob, int logits_dtype, int weight_round_dtype, void* stream) {
   using namespace mi;
   if (num_tokens == 0) return MI_OK;
-  if (!topk_ids || !topk_weights || !expert_counts || !router_logits || num_tokens < 0) return MI_ERR_INVALID_ARG;
+  if (!topk_ids || !topk_weights || !router_logits || num_tokens < 0) return MI_ERR_INVALID_ARG;
   if (num_experts != 64 && num_experts != 128 && num_experts != 256) return MI_ERR_UNSUPPORTED;
   if (top_k <= 0 || top_k > 16 || top_k > num_experts) return MI_ERR_INVALID_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // expert_counts == NULL: no counting (and no launch to zero the counters) — mi_moe_align counts the ids itself.
   // (a kernel, not hipMemsetAsync: twenty memset nodes inside the decode hipGraph of the 20-layer talker ended in
   //  "write access to a read-only page" at replay on this stack, while the same graph with 2-3 of them was fine)
-  hipLaunchKernelGGL(moe_zero_counts_kernel, dim3(1), dim3(256), 0, s, expert_counts, num_experts);
+  if (expert_counts) hipLaunchKernelGGL(moe_zero_counts_kernel, dim3(1), dim3(256), 0, s, expert_counts, num_experts);
   // tokens per wave: 1 for decode batches (latency), up to 4 for prefill chunks (fewer, fuller count flushes)
   const int tpw = num_tokens >= 8192 ? 4 : num_tokens >= 1024 ? 2 : 1;
   const dim3 grid((num_tokens + 16 * tpw - 1) / (16 * tpw)), block(1024);
@@ -444,7 +448,7 @@ extern "C" int mi_moe_align(int32_t* sorted_pairs, int32_t* row_of_pair, int32_t
                             int32_t num_experts, int64_t max_rows, int32_t rows_per_tile, void* stream) {
   using namespace mi;
   if (num_pairs == 0) return MI_OK;
-  if (!sorted_pairs || !row_of_pair || !tile_expert || !num_tiles || !topk_ids || !expert_counts || num_pairs < 0)
+  if (!sorted_pairs || !row_of_pair || !tile_expert || !num_tiles || !topk_ids || num_pairs < 0)
     return MI_ERR_INVALID_ARG;
   if (num_experts <= 0 || num_experts > 256 || max_rows > 0x7fffffff) return MI_ERR_UNSUPPORTED;
   if (!moe_rows_per_tile_ok(rows_per_tile)) return MI_ERR_INVALID_ARG;

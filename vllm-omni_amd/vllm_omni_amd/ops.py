@@ -824,13 +824,15 @@ def int8_linear_silu_mul(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tenso
 
 
 # --------------------------------------------------------------------------- N4: fused sparse MoE
-def moe_route(router_logits: torch.Tensor, top_k: int, norm_topk_prob: bool, round_to: Optional[torch.dtype] = None):
-    """-> (topk_ids int32 [T, k], topk_weights fp32 [T, k], expert_counts int32 [E])."""
+def moe_route(router_logits: torch.Tensor, top_k: int, norm_topk_prob: bool, round_to: Optional[torch.dtype] = None,
+              want_counts: bool = True):
+    """-> (topk_ids int32 [T, k], topk_weights fp32 [T, k], expert_counts int32 [E] or None).  ``want_counts=False``:
+    no per-expert counting and no launch to zero the counters (``fused_moe``: the grouping counts the ids itself)."""
     _gpu(router_logits)
     t, e = router_logits.shape
     ids = torch.empty(t, top_k, dtype=torch.int32, device=router_logits.device)
     w = torch.empty(t, top_k, dtype=torch.float32, device=router_logits.device)
-    counts = torch.empty(e, dtype=torch.int32, device=router_logits.device)
+    counts = torch.empty(e, dtype=torch.int32, device=router_logits.device) if want_counts else None
     check("mi_moe_route", lib.mi_moe_route(_p(ids), _p(w), _p(counts), _p(router_logits), t, e, router_logits.stride(0),
                                            int(top_k), 1 if norm_topk_prob else 0, _dt(router_logits.dtype),
                                            -1 if round_to is None else _dt(round_to), _stream()))
@@ -850,10 +852,10 @@ def fused_moe(x: torch.Tensor, router_logits: torch.Tensor, w_gate_up: torch.Ten
     i = two_i // 2
     dev = x.device
     if routing is None:
-        ids, w, counts = moe_route(router_logits, top_k, norm_topk_prob, round_to=x.dtype)
+        ids, w, _ = moe_route(router_logits, top_k, norm_topk_prob, round_to=x.dtype, want_counts=False)
     else:
         ids, w = routing
-        counts = torch.bincount(ids.reshape(-1).long(), minlength=e).to(torch.int32)
+    counts = None     # mi_moe_align derives the per-expert counts from the ids
     pairs = t * top_k
     rpt = rows_per_tile or int(lib.mi_moe_rows_per_tile(t, top_k, e))
     max_rows = int(lib.mi_moe_max_rows(t, top_k, e, rpt))
