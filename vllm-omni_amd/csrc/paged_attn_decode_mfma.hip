@@ -232,6 +232,7 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   // issue order:  K0 V0 K1 V1 | K2 (after QK 0)  V2 (after PV 0) | K3 V3 | ...
   // so "image X has landed" == vmcnt(number of instructions issued after X's group).
   static_assert((2 * NS - 1) * kGrp <= 63, "the groups in flight must fit the 6-bit vmcnt");
+  static_assert(NS == 2 || NS == 4, "the step loop is unrolled for two or four stages (three skips steps)");
   auto wait_groups = [&](int groups) {  // wave-uniform; `groups` DMA groups were issued after the one waited for
     if constexpr (NS > 2) {
       if (groups >= 7) { wait_vmcnt<7 * kGrp>(); return; }
@@ -483,10 +484,14 @@ int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, b
     }                                                                                                       \
   } while (0)
 #define MI_LAUNCH(TAG, HDIM) MI_LAUNCH_NS(TAG, HDIM, 2)
+#ifndef MI_DECODE_NS64
+#define MI_DECODE_NS64 2   // ring stages at head_dim 64: a stage is half the bytes of head_dim 128's, yet four stages measured
+                           // level with two there as well (162.5 / 163.1 us at 512 x 2 heads x ctx 4096, 54.7 / 56.6 at 128)
+#endif
   if (dtype == MI_DTYPE_BF16) {
-    if (head_dim == 128) MI_LAUNCH(bf16_tag, 128); else MI_LAUNCH(bf16_tag, 64);
+    if (head_dim == 128) MI_LAUNCH(bf16_tag, 128); else MI_LAUNCH_NS(bf16_tag, 64, MI_DECODE_NS64);
   } else {
-    if (head_dim == 128) MI_LAUNCH(f16_tag, 128); else MI_LAUNCH(f16_tag, 64);
+    if (head_dim == 128) MI_LAUNCH(f16_tag, 128); else MI_LAUNCH_NS(f16_tag, 64, MI_DECODE_NS64);
   }
 #undef MI_LAUNCH
 #undef MI_LAUNCH_NS
