@@ -203,16 +203,17 @@ int mi_paged_attn_decode(void* out, const void* q, const void* k_cache, const vo
                          int64_t cache_token_stride, int64_t cache_head_stride,
                          int32_t partition_size, void* workspace, int64_t workspace_bytes,
                          int dtype, int out_dtype, int32_t flags, void* stream);
-/* Partition size the auto heuristic picks: the fewest partitions that leave >= 512 waves — ONE
- * (direct output, no workspace, no merge launch) once num_seqs * num_kv_heads >= 512; 256..8192 tokens. */
+/* Partition size the auto heuristic picks: the fewest partitions that leave >= 512 waves (>= 1024 at
+ * head_dim <= 64) — ONE (direct output, no workspace, no merge launch) once num_seqs * num_kv_heads
+ * reaches that; 256..8192 tokens. */
 int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
-                                            int32_t max_seq_len);
+                                            int32_t max_seq_len, int32_t head_dim);
 /* Partition size a call with these `flags` really uses: `requested` (0 = auto); any multiple of 32
  * tokens for the matrix-core kernel (it reloads its block-id window every 64 blocks), capped at
  * 64 KV blocks for the VALU kernel.  Size the workspace with THIS value. */
 int32_t mi_paged_attn_decode_effective_partition(int32_t num_seqs, int32_t num_kv_heads,
-                                                 int32_t max_seq_len, int32_t block_size,
-                                                 int32_t requested, int32_t flags);
+                                                 int32_t max_seq_len, int32_t head_dim,
+                                                 int32_t block_size, int32_t requested, int32_t flags);
 
 /* ------------------------------------------------------------------------
  * A6 — paged-attention prefill / chunked prefill (q_len >= 1, varlen, causal

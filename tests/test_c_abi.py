@@ -74,15 +74,17 @@ def test_argument_validation_without_gpu():
     assert lib.mi_paged_attn_decode_workspace_bytes(256, 28, 128, 4096, 4096) == 0
     # the fewest partitions that leave >= 512 waves (ONE at >= 512 sequence x KV-head pairs), 256..8192 tokens, never
     # beyond the (rounded) context
-    auto = lib.mi_paged_attn_decode_auto_partition
+    auto = lambda s, h, c, d=128: lib.mi_paged_attn_decode_auto_partition(s, h, c, d)   # noqa: E731
     assert auto(256, 4, 4096) == 4096 and auto(64, 4, 2048) == 1024 and auto(32, 4, 1024) == 256
     assert auto(1, 4, 8192) == 256 and auto(4, 2, 40) == 64 and auto(256, 1, 4096) == 2048
     assert auto(256, 4, 4112) == 4128 and auto(256, 4, 32768) == 8192 and auto(96, 4, 4096) == 2048
+    # head_dim 64: a wave carries half the bytes -> twice the waves
+    assert auto(512, 2, 4096, 64) == 4096 and auto(128, 2, 4096, 64) == 1024 and auto(64, 2, 4096, 64) == 512
     eff = lib.mi_paged_attn_decode_effective_partition
-    assert eff(256, 4, 4096, 16, 0, _C.MI_DECODE_PACKED_PV) == 4096                    # matrix-core kernel: any length
-    assert eff(256, 4, 4096, 16, 0, 0) == 1024                                         # VALU kernel: 64-block cap
-    assert eff(256, 4, 4096, 16, 0, _C.MI_DECODE_PACKED_PV | _C.MI_DECODE_FORCE_VALU) == 1024
-    assert eff(256, 4, 4096, 8, 0, _C.MI_DECODE_PACKED_PV) == 512                      # block 8: VALU kernel
+    assert eff(256, 4, 4096, 128, 16, 0, _C.MI_DECODE_PACKED_PV) == 4096               # matrix-core kernel: any length
+    assert eff(256, 4, 4096, 128, 16, 0, 0) == 1024                                    # VALU kernel: 64-block cap
+    assert eff(256, 4, 4096, 128, 16, 0, _C.MI_DECODE_PACKED_PV | _C.MI_DECODE_FORCE_VALU) == 1024
+    assert eff(256, 4, 4096, 128, 8, 0, _C.MI_DECODE_PACKED_PV) == 512                 # block 8: VALU kernel
 
 
 def test_blockpool_fifo_refcount_and_null_block():

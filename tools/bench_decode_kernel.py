@@ -59,7 +59,7 @@ def main():
     for mode in [int(x) for x in a.modes.split(",")]:
         packed, force_valu, nt, rp = mode != 0, mode == 1, mode >= 3, mode == 4
         for ps in [int(x) for x in a.parts.split(",")]:
-            eff = ops.decode_auto_partition(a.batch, a.nkv, a.ctx, a.bs, ps, packed_pv=packed, force_valu=force_valu)
+            eff = ops.decode_auto_partition(a.batch, a.nkv, a.ctx, a.bs, ps, packed_pv=packed, force_valu=force_valu, head_dim=a.d)
             nbytes = max(1, ops.decode_workspace_bytes(a.batch, a.nq, a.d, a.ctx, eff))
             # a prepared workspace = partitions merged inside the attention launch; --two-kernels: the separate merge
             ws = (torch.empty(nbytes, dtype=torch.uint8, device=dev) if a.two_kernels

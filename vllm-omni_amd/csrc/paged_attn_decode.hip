@@ -418,7 +418,7 @@ int round_up(int a, int b) { return (a + b - 1) / b * b; }
 }  // namespace mi
 
 extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t num_kv_heads,
-                                                       int32_t max_seq_len) {
+                                                       int32_t max_seq_len, int32_t head_dim) {
   // Measured on MI355X (tools/bench_decode_kernel.py; profiles/r03e_decode_long_parts*.log: B x ctx from 32 x 4096 to
   // 256 x 8192 and 64 x 16384, 4 / 2 / 1 KV heads): every partition costs a prologue (Q fragments, block-id window,
   // pipeline fill), an fp32 partial write and its share of the merge launch, so take the FEWEST partitions that still
@@ -426,9 +426,12 @@ extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t
   // (B 256 / ctx 4096: 315 us against 340 with four partitions of 1024; fewer than 512 waves loses: 256 waves run at
   // 55 % of that rate).  Never below 256 tokens, never above 8192 (a bound on the tail when ONE sequence of a batch is
   // far longer than the rest: one wave streams its whole partition).
+  // head_dim 64: a wave's ring holds half the bytes, so twice the waves (>= 1024: 128 sequences x 2 heads x ctx 4096 run
+  // 46.6 us in four partitions against 54.5 in two; 512 x 2 heads stay at ONE: profiles/r03zb_decode_parts_d64.log)
   if (num_seqs <= 0 || num_kv_heads <= 0 || max_seq_len <= 0) return 256;
   const int64_t pairs = (int64_t)num_seqs * num_kv_heads;
-  const int64_t parts = (512 + pairs - 1) / pairs;
+  const int64_t want = head_dim > 0 && head_dim <= 64 ? 1024 : 512;
+  const int64_t parts = (want + pairs - 1) / pairs;
   int64_t ps = mi::round_up((int32_t)((max_seq_len + parts - 1) / parts), 32);
   if (ps < 256) ps = 256;
   if (ps > 8192) ps = 8192;
@@ -440,11 +443,11 @@ extern "C" int32_t mi_paged_attn_decode_auto_partition(int32_t num_seqs, int32_t
 // FORCE_VALU, block_size >= 16, a multiple of 32 tokens) walks its block ids window by window and takes any length;
 // the VALU kernel keeps a partition's block ids in one 64-lane register: capped at 64 KV blocks.
 extern "C" int32_t mi_paged_attn_decode_effective_partition(int32_t num_seqs, int32_t num_kv_heads,
-                                                            int32_t max_seq_len, int32_t block_size,
-                                                            int32_t requested, int32_t flags) {
+                                                            int32_t max_seq_len, int32_t head_dim,
+                                                            int32_t block_size, int32_t requested, int32_t flags) {
   if (block_size <= 0) return 0;
   int32_t ps = requested > 0 ? requested
-                             : mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len);
+                             : mi_paged_attn_decode_auto_partition(num_seqs, num_kv_heads, max_seq_len, head_dim);
   const bool any_length = (flags & MI_DECODE_PACKED_PV) && !(flags & MI_DECODE_FORCE_VALU) && block_size >= 16 &&
                           ps % 32 == 0;
   const int32_t cap = 64 * block_size;
@@ -496,7 +499,7 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   if (((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) & 15)
     return MI_ERR_INVALID_ARG;
 
-  partition_size = mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len,
+  partition_size = mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len, head_dim,
                                                             block_size, partition_size, flags);
   if (partition_size <= 0 || partition_size % kTile) return MI_ERR_INVALID_ARG;
   const int num_parts = (max_seq_len + partition_size - 1) / partition_size;

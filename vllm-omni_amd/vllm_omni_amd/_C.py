@@ -48,8 +48,8 @@ SIGNATURES = {
                                             c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,
                                             c_int64, c_int64, c_int64, c_float, c_int, _P]),
     "mi_paged_attn_decode_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
-    "mi_paged_attn_decode_auto_partition": (c_int32, [c_int32, c_int32, c_int32]),
-    "mi_paged_attn_decode_effective_partition": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mi_paged_attn_decode_auto_partition": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "mi_paged_attn_decode_effective_partition": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "mi_paged_attn_decode": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, c_int32, c_int32, c_float, c_int64, c_int64,
                                       c_int64, c_int64, c_int64, c_int32, _P, c_int64, c_int,

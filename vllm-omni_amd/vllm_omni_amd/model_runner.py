@@ -535,10 +535,10 @@ class GPUARModelRunner:
         # partitions that leave >= 512 waves: ops.decode_auto_partition); the workspace is sized once for the largest
         # need any batch size of this runner can have.  `_decode_part` (reporting only) = the full batch's choice.
         self._decode_part = ops.decode_auto_partition(self.max_num_reqs, a.num_kv_heads, self.max_model_len,
-                                                       self.block_size)
+                                                       self.block_size, head_dim=a.head_dim)
         nbytes = max(ops.decode_workspace_bytes(b, a.num_heads, a.head_dim, self.max_model_len,
                                                 ops.decode_auto_partition(b, a.num_kv_heads, self.max_model_len,
-                                                                          self.block_size))
+                                                                          self.block_size, head_dim=a.head_dim))
                      for b in range(1, self.max_num_reqs + 1))
         if torch.device(self.device).type == "cuda":
             self._decode_ws = ops.new_decode_workspace(nbytes, self.device)   # zeroed counters: fused partition merge

@@ -219,11 +219,13 @@ def _decode_flags(packed_pv: Optional[bool], force_valu: bool) -> int:
 
 
 def decode_auto_partition(num_seqs: int, num_kv_heads: int, max_seq_len: int, block_size: int = 16,
-                          requested: int = 0, packed_pv: Optional[bool] = None, force_valu: bool = False) -> int:
+                          requested: int = 0, packed_pv: Optional[bool] = None, force_valu: bool = False,
+                          head_dim: int = 128) -> int:
     """Partition size a decode call will really use: ``requested``, or the auto choice — the fewest partitions that
-    leave >= 512 waves, ONE (direct output, no merge launch) once sequences x KV heads >= 512; any multiple of 32 tokens
-    for the matrix-core kernel, capped at 64 blocks for the VALU kernel (``packed_pv`` False / ``force_valu``)."""
-    return int(lib.mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len, block_size,
+    leave >= 512 waves (1024 at head_dim 64), ONE (direct output, no merge launch) once sequences x KV heads reach that;
+    any multiple of 32 tokens for the matrix-core kernel, capped at 64 blocks for the VALU kernel (``packed_pv`` False /
+    ``force_valu``)."""
+    return int(lib.mi_paged_attn_decode_effective_partition(num_seqs, num_kv_heads, max_seq_len, head_dim, block_size,
                                                             requested, _decode_flags(packed_pv, force_valu)))
 
 
@@ -292,7 +294,7 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
     cb, ct, ch = _cache_strides(k_cache, v_cache)
     if s == 0:
         return out
-    partition_size = decode_auto_partition(s, hkv, max_seq_len, bs, partition_size, packed_pv, force_valu)
+    partition_size = decode_auto_partition(s, hkv, max_seq_len, bs, partition_size, packed_pv, force_valu, head_dim=d)
     need = decode_workspace_bytes(s, nq, d, max_seq_len, partition_size)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = new_decode_workspace(need, q.device)
