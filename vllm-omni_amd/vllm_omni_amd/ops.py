@@ -848,7 +848,7 @@ def fused_moe(x: torch.Tensor, router_logits: torch.Tensor, w_gate_up: torch.Ten
     """Sparse-MoE layer output for x [T, H]: route -> align -> gated expert GEMM -> down expert GEMM ->
     weighted combine (+ sigmoid-gated shared expert output computed by the caller).  w_gate_up [E, 2I, H] (gate rows
     then up rows), w_down [E, H, I].  ``routing`` = (ids int32, weights fp32) skips the router (tests)."""
-    _gpu(x, router_logits, w_gate_up, w_down, shared_out, shared_gate_weight)
+    _gpu(x, router_logits, w_gate_up, w_down, None if callable(shared_out) else shared_out, shared_gate_weight)
     t, h = x.shape
     e, two_i, _ = w_gate_up.shape
     i = two_i // 2
@@ -878,6 +878,9 @@ def fused_moe(x: torch.Tensor, router_logits: torch.Tensor, w_gate_up: torch.Ten
         _p(part), _p(act), _p(w_down), _p(sorted_pairs), _p(tile_expert), _p(num_tiles), max_rows // rpt, 0, h, i, top_k,
         act.stride(0), part.stride(0), w_down.stride(0), rpt, dt, _stream()))
     out = torch.empty_like(x)
+    if callable(shared_out):      # the caller computed it beside this path (another stream): join here
+        shared_out = shared_out()
+        _gpu(shared_out)
     check("mi_moe_combine", lib.mi_moe_combine(
         _p(out), _p(part), _p(row_of_pair), _p(w), _p(shared_out), _p(x), _p(shared_gate_weight), t, h, top_k,
         part.stride(0), out.stride(0), x.stride(0), shared_out.stride(0) if shared_out is not None else 0, dt, _stream()))
