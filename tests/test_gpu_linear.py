@@ -142,15 +142,16 @@ def test_linear_silu_mul_matches_unfused_pair(m, inter, k, dtype):
 
 
 def test_mlp_uses_the_fused_gate_up_kernel_when_the_policy_says_so(monkeypatch):
-    """Qwen2MLP: act_fn(gate_up_proj(x)) runs as one launch for I >= 8192 per rank (auto), as two steps otherwise; both
-    ways equal the two-step result to the fused kernel's tolerance."""
+    """Qwen2MLP: act_fn(gate_up_proj(x)) runs as one launch for I >= 8192 per rank and for a small dense MLP
+    (hidden <= 2048, I <= 4096: the code predictor's) — auto — and as two steps otherwise; both ways equal the two-step
+    result to the fused kernel's tolerance."""
     from vllm_omni_amd import layers, ops
     fused = []
     real = ops.linear_silu_mul
     monkeypatch.setattr(ops, "linear_silu_mul", lambda *a, **k: (fused.append(1), real(*a, **k))[1])
     monkeypatch.setattr(layers, "_LINEAR_MODE", "auto")
     g = torch.Generator(device="cuda").manual_seed(5)
-    for inter, expect in [(8192, 1), (4096, 0)]:
+    for inter, expect in [(8192, 1), (6144, 0), (3072, 1)]:
         gu = layers.MergedColumnParallelLinear(512, [inter] * 2, bias=False, dtype=torch.bfloat16, device="cuda")
         gu.weight = (torch.randn(2 * inter, 512, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
         x = torch.randn(64, 512, device="cuda", generator=g).to(torch.bfloat16)

@@ -232,7 +232,11 @@ def test_linear_routing_policy_matches_the_measurements():
     for n, k in [(4608, H), (H, H), (H, I // 4), (H, I // 8), (2048, 1024), (1024, 2048), (1024, 3072)]:
         assert L._streaming_kernel_wins(32, n, k) and L._streaming_kernel_wins(1, n, k), (n, k)
     assert not L._streaming_kernel_wins(32, 512, 1024)
-    assert L._fused_gate_up_wins(32, 3072, 1024) and not L._fused_gate_up_wins(64, 3072, 1024)   # the code predictor's MLP
+    # the code predictor's small MLP (6144 x 1024, 1024 x 3072): the fused pair up to 256 rows, not at 512
+    for m in (32, 64, 128, 256):
+        assert L._fused_gate_up_wins(m, 3072, 1024) and L._streaming_kernel_wins(m, 1024, 3072), m
+    assert not L._fused_gate_up_wins(512, 3072, 1024) and not L._streaming_kernel_wins(512, 1024, 3072)
+    assert not L._streaming_kernel_wins(64, 1024, 2048) and not L._streaming_kernel_wins(64, 4096, 1024)   # its o / qkv
     # ... o_proj joins only with the deferred reduce; the code predictor's 1024 x 2048 o_proj never does
     assert L._deferred_kernel_wins(256, H, H) and L._deferred_kernel_wins(32, H, H)
     assert not L._deferred_kernel_wins(256, 1024, 2048) and not L._deferred_kernel_wins(512, H, H)

@@ -320,7 +320,12 @@ def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
     # against 13.4 us, o 11.7 / 12.6 (profiles/r03c_skinny_shard_shapes.log), the code predictor's 1-6 M-element
     # linears: 9.16 against 9.70 ms per call at batch 32 (profiles/r03j_predictor_linear_modes.log) — not at 64 rows
     # (o_proj 11.6 against 8.7) and not at 512 (19.5 against 15.9 ms per predictor call)
-    return m <= 32 and n * k >= (1 << 20)
+    if m <= 32 and n * k >= (1 << 20):
+        return True
+    # the down_proj of a SMALL dense MLP (the code predictor's 1024 x 3072) up to 256 rows: with the fused gate_up in
+    # front of it the pair runs 8.67 against 9.53 ms per predictor call at 64 rows, 11.47 / 12.17 at 256, level at 128
+    # (profiles/r03j_predictor_linear_modes.log)
+    return m <= 256 and n <= 2048 and k <= 4096 and k > 2 * n and n * k >= (1 << 20)
 
 
 def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
@@ -371,7 +376,10 @@ def _fused_gate_up_wins(m: int, inter: int, k: int) -> bool:
         return True
     # <= 32 rows: the fused launch replaces a GEMM the kernel already wins (see _streaming_kernel_wins) AND the
     # SiluAndMul launch behind it (the code predictor's 6144 x 1024 gate_up_proj at batch 32)
-    return m <= 32 and 2 * inter * k >= (1 << 20) and os.environ.get("VLLM_OMNI_AMD_FUSE_SMALL_GATE_UP", "1") == "1"
+    if os.environ.get("VLLM_OMNI_AMD_FUSE_SMALL_GATE_UP", "1") != "1" or 2 * inter * k < (1 << 20):
+        return False
+    # ... and, up to 256 rows, the gate_up of a small dense MLP (the code predictor's 6144 x 1024; see _streaming_kernel_wins)
+    return m <= 32 or (m <= 256 and k <= 2048 and inter <= 4096)
 
 
 def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_reduce: bool = False):
