@@ -349,18 +349,40 @@ __global__ __launch_bounds__(64) void decode_reduce_kernel(const DecodeParams p)
   const int np = min(p.num_parts, (num_tiles + p.part_tiles - 1) / p.part_tiles);
   const int64_t slot0 = ((int64_t)seq * p.num_q_heads + qh) * p.num_parts;
   const float2* ml = reinterpret_cast<const float2*>(p.part_ml) + slot0;
+  // Eight partitions per trip, every load of a trip issued before the first use (a loop that loads, uses and loops is
+  // `np` dependent round trips: 7.5 us for 16 partitions at batch 8); the sums run in partition order as before.
+  constexpr int CH = 8;
   float mm = kNegBig;
-  for (int i = 0; i < np; ++i) mm = fmaxf(mm, ml[i].x);
+  for (int i0 = 0; i0 < np; i0 += CH) {
+    float2 x[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) x[j] = i0 + j < np ? ml[i0 + j] : make_float2(kNegBig, 0.f);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) mm = fmaxf(mm, x[j].x);
+  }
   float L = 0.f, a[DPL];
 #pragma unroll
   for (int d = 0; d < DPL; ++d) a[d] = 0.f;
-  for (int i = 0; i < np; ++i) {
-    const float2 x = ml[i];
-    const float w = fast_exp2(x.x - mm);
-    L += w * x.y;
-    const float* po = p.part_o + (slot0 + i) * HD + lane * DPL;
+  for (int i0 = 0; i0 < np; i0 += CH) {
+    float2 x[CH];
+    float po[CH][DPL];
 #pragma unroll
-    for (int d = 0; d < DPL; ++d) a[d] += w * po[d];
+    for (int j = 0; j < CH; ++j) {
+      const bool on = i0 + j < np;
+      x[j] = on ? ml[i0 + j] : make_float2(kNegBig, 0.f);
+      const float* src = p.part_o + (slot0 + (on ? i0 + j : 0)) * HD + lane * DPL;
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) po[j][d] = on ? src[d] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      if (i0 + j < np) {
+        const float w = fast_exp2(x[j].x - mm);
+        L += w * x[j].y;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) a[d] += w * po[j][d];
+      }
+    }
   }
   const float inv = np > 0 ? 1.f / L : 0.f;
   const int64_t o = (int64_t)seq * p.out_stride + (int64_t)qh * HD + lane * DPL;
