@@ -22,7 +22,13 @@ def shapes(cfg, tp):
 
     nq, nkv, _ = partition_heads(cfg.num_attention_heads, cfg.num_key_value_heads, tp)
     d, h, i = cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
-    return [  # (name, N, K, bias)
+    moe = []
+    if getattr(cfg, "num_experts", 0):   # the sparse-MoE block's dense GEMMs: router, shared expert (experts: in-tree kernels)
+        moe.append(("moe.router", cfg.num_experts, h, False))
+        sh = getattr(cfg, "shared_expert_intermediate_size", 0) or 0
+        if sh:
+            moe += [("moe.shared_gate_up", 2 * sh, h, False), ("moe.shared_down", h, sh, False)]
+    return moe + [  # (name, N, K, bias)
         ("thinker_to_talker_proj", h, cfg.embedding_size, True),
         ("qkv_proj", (nq + 2 * nkv) * d, h, cfg.attention_bias),
         ("o_proj", h, nq * d, False),
