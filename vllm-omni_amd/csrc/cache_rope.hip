@@ -137,7 +137,10 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
     return make_uint4(E::pack(lo.x, lo.y), E::pack(lo.z, lo.w), E::pack(hi.x, hi.y), E::pack(hi.z, hi.w));
   };
 
-  for (int it = threadIdx.x; it < n_heads * iph; it += blockDim.x) {
+  // gridDim.y > 1 (few tokens: a decode batch of <= 64 rows is <= 64 workgroups otherwise): the items of a token are
+  // dealt to several workgroups in chunks of 256 — a multiple of every items-per-head, so a head's lanes stay together
+  const int it0 = blockIdx.y * blockDim.x + threadIdx.x, it_step = blockDim.x * gridDim.y;
+  for (int it = it0; it < n_heads * iph; it += it_step) {
     const int head = it / iph;
     const int j = it % iph;
     const bool is_q = head < p.num_q_heads;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
   // V -> cache (pure copy)
   if (p.vc && slot >= 0) {
     const int per_head = HD / 8;
-    for (int i = threadIdx.x; i < p.num_kv_heads * per_head; i += blockDim.x) {
+    for (int i = it0; i < p.num_kv_heads * per_head; i += it_step) {
       const int h = i / per_head, d = (i % per_head) * 8;
       uint4 vv;
       if constexpr (PART) vv = from_partials((p.num_q_heads + p.num_kv_heads + h) * HD + d);
@@ -245,7 +248,9 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const RopeParams p) {
 
 template <typename Tag>
 int launch_rope(const RopeParams& p, bool mrope, bool norm, int num_tokens, hipStream_t s) {
-  const dim3 grid(num_tokens), block(256);
+  const int items = (p.num_q_heads + p.num_kv_heads) * (p.rot_dim / 16 + (p.head_dim - p.rot_dim) / 8);
+  const int gy = num_tokens <= 64 ? std::min(4, (items + 255) / 256) : 1;
+  const dim3 grid(num_tokens, gy), block(256);
   if (p.part) {
     if (mrope && norm) hipLaunchKernelGGL((rope_cache_kernel<Tag, true, true, true>), grid, block, 0, s, p);
     else if (mrope) hipLaunchKernelGGL((rope_cache_kernel<Tag, true, false, true>), grid, block, 0, s, p);
