@@ -437,6 +437,28 @@ def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bo
     return elapsed, runner, local_batch
 
 
+def time_allreduce(dev, rows: int, cols: int, calls: int = 50) -> dict:
+    """The decode step's tensor-parallel exchange on its own: ``calls`` back-to-back all-reduces of the step's message
+    ([rows, hidden] bf16, what o_proj / down_proj of every layer reduce) through the product's own call
+    (``tensor_model_parallel_all_reduce``: RCCL or the in-tree kernel, whichever the plan runs), wall clock around the
+    burst + synchronize, eager (inside the captured step the same launches carry no host cost).  Every rank of the
+    group calls it the same number of times."""
+    from vllm_omni_amd.distributed import tensor_model_parallel_all_reduce
+
+    x = torch.randn(rows, cols, device=dev, dtype=torch.bfloat16)
+    with torch.inference_mode():
+        for _ in range(5):
+            tensor_model_parallel_all_reduce(x.clone())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            tensor_model_parallel_all_reduce(x)     # in place on the same buffer: values do not matter, timing does
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"message_bytes": rows * cols * 2, "us_per_message": round(dt / calls * 1e6, 1), "calls": calls,
+            "how": "back-to-back eager calls of the product's all-reduce on the step's [rows, hidden] bf16 message"}
+
+
 def main():
     a = parse_args()
     launched = "WORLD_SIZE" in os.environ
@@ -532,6 +554,8 @@ def main():
                          "kernel, library GEMM elsewhere; same bf16 inputs, fp32 accumulation)"},
             "roofline": roofline,
         }
+        if "allreduce_probe" in head:   # measured time of the headline plan's all-reduce per message (tp > 1)
+            out["allreduce_probe"] = head["allreduce_probe"]
         others = [{k: v for k, v in r.items() if k != "roofline"} for r in results if r is not head]
         if others:
             out["alt_plans"] = others
@@ -591,6 +615,12 @@ def main():
                "decode_partition": runner._decode_part,
                "tuned_gemm_csv_loaded": bool(getattr(runner, "tuned_gemms", False)),
                "roofline": roofline_of(runner, local_batch, tp)}
+        if tp > 1:   # measured all-reduce time per message of this plan's transport (2 x layers of them per step)
+            try:
+                res["allreduce_probe"] = dict(time_allreduce(dev, local_batch, cfg.hidden_size),
+                                              messages_per_step=2 * cfg.num_hidden_layers)
+            except Exception as e:  # noqa: BLE001 - the probe must never cost the plan its number
+                res["allreduce_probe"] = {"error": repr(e)[:200]}
         del runner
         import gc
 
