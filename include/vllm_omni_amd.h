@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 /* dtype enum shared by every entry point */
 enum {
@@ -509,6 +509,25 @@ int mi_fused_add_rms_norm_splitk(void* out, const void* partials, int32_t split,
 int mi_linear_silu_mul(void* out, const void* x, const void* weight, int32_t m, int32_t inter,
                        int32_t k, int64_t x_row_stride, int64_t out_row_stride, int dtype,
                        void* stream);
+/* Tile plans measured for a deployment's shapes (tools/tune_linear_plans.py ->
+ * vllm_omni_amd/tuned/linear_plans_gfx950.json), replacing the built-in heuristic of the
+ * three entry points above for 16-bit operands — the counterpart of the TunableOp
+ * selections the library GEMMs of the same layers run on.  A plan is (rows per row
+ * block: 64 / 128 / 256, weight rows per tile: 32 .. 256 in steps of 32 — for the
+ * gated form 2 x the output columns of a tile —, split-K factor 1 .. 16) and applies
+ * to row counts m_lo < m <= m_hi of the shape (n, k).  purpose: MI_LINEAR_PLAN_FULL
+ * (mi_linear), _PARTIALS (mi_linear_partials; falls back to the FULL entry), _GATED
+ * (mi_linear_silu_mul: n = inter).  A row block of fewer rows than m runs
+ * ceil(m / rows) blocks per weight tile, dealt to one XCD so that the tile leaves
+ * HBM once.  Host-side table, thread-safe; affects launches made after the call.
+ * MI_ERR_INVALID_ARG for a malformed plan, MI_ERR_UNSUPPORTED for a tile shape that
+ * is not built. */
+enum { MI_LINEAR_PLAN_FULL = 0, MI_LINEAR_PLAN_PARTIALS = 1, MI_LINEAR_PLAN_GATED = 2 };
+int mi_linear_plan_set(int32_t purpose, int32_t m_lo, int32_t m_hi, int32_t n, int32_t k,
+                       int32_t rows_per_block, int32_t weight_rows_per_tile, int32_t split);
+void mi_linear_plan_clear(void);
+/* The plan a call would run: out[0..2] = rows per block, weight rows per tile, split. */
+int mi_linear_plan_get(int32_t purpose, int32_t m, int32_t n, int32_t k, int32_t* out);
 
 
 /* ------------------------------------------------------------------------

@@ -130,3 +130,65 @@ def test_slot_mapping_matches_oracle_bit_exact():
     bad = np.array([maxb * 32], dtype=np.int64)
     assert _C.lib.mi_compute_slot_mapping(out.ctypes.data, table.ctypes.data, maxb, req.ctypes.data, bad.ctypes.data, 1,
                                           32) == _C.MI_ERR_INVALID_ARG
+
+
+def test_linear_plan_registry_host_side():
+    """mi_linear_plan_set / _get / _clear (round 4): a registered plan replaces the heuristic for its row range only; the
+    partials entry point falls back to the full plan; malformed and unbuilt plans are refused."""
+    from vllm_omni_amd import _C
+    from vllm_omni_amd.tuned import linear_plans
+
+    linear_plans.reset()
+    lib = _C.lib
+    buf = (ctypes.c_int32 * 3)()
+    n, k = 3584, 4736
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_FULL, 128, n, k, buf) == _C.MI_OK
+    heuristic = list(buf)
+    assert heuristic[0] == 128 and heuristic[2] >= 2           # 128-row image, split-K
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 64, 128, n, k, 64, 96, 3) == _C.MI_OK
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_FULL, 128, n, k, buf) == _C.MI_OK and list(buf) == [64, 96, 3]
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_PARTIALS, 100, n, k, buf) == _C.MI_OK and list(buf) == [64, 96, 3]
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_FULL, 64, n, k, buf) == _C.MI_OK and list(buf) != [64, 96, 3]
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_FULL, 129, n, k, buf) == _C.MI_OK and list(buf) != [64, 96, 3]
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_PARTIALS, 64, 128, n, k, 128, 128, 8) == _C.MI_OK
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_PARTIALS, 128, n, k, buf) == _C.MI_OK and list(buf) == [128, 128, 8]
+    assert lib.mi_linear_workspace_bytes(128, n, k) == 8 * 128 * n * 4      # one workspace serves both entry points
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_GATED, 0, 128, 4736, 3584, 64, 96, 1) == _C.MI_OK
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_GATED, 128, 4736, 3584, buf) == _C.MI_OK and list(buf) == [64, 96, 1]
+    # refused: unbuilt tile, malformed ranges / splits, a split on the gated form, a partials plan without a split
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 0, 128, n, k, 64, 224, 1) == _C.MI_ERR_UNSUPPORTED
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 0, 128, n, k, 256, 96, 1) == _C.MI_ERR_UNSUPPORTED
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 128, 128, n, k, 64, 96, 1) == _C.MI_ERR_INVALID_ARG
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 0, 128, n, k, 64, 96, 17) == _C.MI_ERR_INVALID_ARG
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_GATED, 0, 128, 4736, 3584, 64, 96, 2) == _C.MI_ERR_INVALID_ARG
+    assert lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_PARTIALS, 0, 128, n, k, 64, 96, 1) == _C.MI_ERR_INVALID_ARG
+    assert lib.mi_linear_plan_set(7, 0, 128, n, k, 64, 96, 1) == _C.MI_ERR_INVALID_ARG
+    lib.mi_linear_plan_clear()
+    assert lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_FULL, 128, n, k, buf) == _C.MI_OK and list(buf) == heuristic
+
+
+def test_tuned_linear_plan_table_loads_and_buckets_rows(monkeypatch):
+    """vllm_omni_amd/tuned/linear_plans_gfx950.json: every entry registers; an entry tuned at m rows serves the row counts
+    above the next lower tuned m; VLLM_OMNI_AMD_LINEAR_PLANS=0 disables the table."""
+    import json
+
+    from vllm_omni_amd import _C
+    from vllm_omni_amd.tuned import linear_plans
+
+    linear_plans.reset()
+    doc = json.load(open(linear_plans.RESULTS))
+    assert doc["arch"] == "gfx950" and len(doc["entries"]) >= 40
+    assert linear_plans.load() == len({(e["gated"], e["n"], e["k"], e["m"]) for e in doc["entries"]})
+    buf = (ctypes.c_int32 * 3)()
+    for e in doc["entries"]:
+        got = linear_plans.lookup(e["m"], e["n"], e["k"], e["gated"])
+        assert got is not None and got["m"] == e["m"]
+        purpose = _C.MI_LINEAR_PLAN_GATED if e["gated"] else _C.MI_LINEAR_PLAN_FULL
+        assert _C.lib.mi_linear_plan_get(purpose, e["m"], e["n"], e["k"], buf) == _C.MI_OK
+        assert list(buf) == [e["full"]["rows"], e["full"]["wrows"], e["full"]["split"]]
+    assert linear_plans.lookup(33, 3584, 4736, False)["m"] == 64 and linear_plans.lookup(257, 3584, 4736, False) is None
+    assert linear_plans.lookup(128, 3584, 4737, False) is None
+    linear_plans.reset()
+    monkeypatch.setenv("VLLM_OMNI_AMD_LINEAR_PLANS", "0")
+    assert linear_plans.load() == 0 and linear_plans.lookup(128, 3584, 4736, False) is None
+    linear_plans.reset()

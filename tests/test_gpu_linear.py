@@ -164,9 +164,11 @@ def test_mlp_uses_the_fused_gate_up_kernel_when_the_policy_says_so(monkeypatch):
 
 
 @pytest.mark.parametrize("m,n,k,bias", [(256, 3584, 18944, False), (32, 3584, 18944, True), (100, 512, 2048, True)])
-def test_deferred_splitk_reduce_is_bit_identical(m, n, k, bias):
+def test_deferred_splitk_reduce_is_bit_identical(plan_registry, m, n, k, bias):
     """linear_partials + fused_add_rms_norm_splitk == linear + fused_add_rms_norm, bit for bit (same slice order, same
-    roundings), for the output and for the updated residual; materialize() == linear."""
+    roundings), for the output and for the updated residual; materialize() == linear.  (Both entry points on the SAME
+    tile plan — the built-in one here; a tuned table may give them different split-K factors, and then they differ by
+    fp32 summation order.)"""
     from vllm_omni_amd import ops
     g = torch.Generator(device="cuda").manual_seed(m + n + k)
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
@@ -190,7 +192,7 @@ def test_deferred_splitk_reduce_is_bit_identical(m, n, k, bias):
         part.materialize()
 
 
-def test_linear_partials_none_without_split():
+def test_linear_partials_none_without_split(plan_registry):
     from vllm_omni_amd import ops
     x = torch.zeros(256, 3584, device="cuda", dtype=torch.bfloat16)
     w = torch.zeros(37888, 3584, device="cuda", dtype=torch.bfloat16)
@@ -198,7 +200,7 @@ def test_linear_partials_none_without_split():
 
 
 @pytest.mark.parametrize("mrope,qk_norm,bias", [(False, False, True), (True, False, True), (False, True, False)])
-def test_rope_and_cache_from_qkv_partials_is_bit_identical(mrope, qk_norm, bias):
+def test_rope_and_cache_from_qkv_partials_is_bit_identical(plan_registry, mrope, qk_norm, bias):
     """qkv_proj's split-K partials straight into the fused RoPE + KV-write kernel == linear -> rope_neox_and_cache:
     rotated q, K cache and V cache bit for bit (plain RoPE, M-RoPE, q/k-norm; with and without bias)."""
     from vllm_omni_amd import ops
@@ -265,3 +267,126 @@ def test_linear_random_shapes_fuzz():
             zr = act * up
             ztol = zr.abs() * 2.0 ** -8 + (up.abs() * 1.1 * gt.abs() + act.abs() * up.abs()) * 2.0 ** -8 + 1e-3
             assert bool(((z.float() - zr).abs() <= ztol).all()), ("gated", case, m, inter, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: registered tile plans (mi_linear_plan_set) — the per-rank shapes of the tensor-parallel plans (qwen2_old.py:
+# 89-102: 28 / tp query heads, max(1, 4 / tp) KV heads; 47-60,109-124 the four projections) on every built tile shape.
+def _talker_shard_shapes(tp):
+    nq, nkv = 28 // tp, max(1, 4 // tp)
+    return {"qkv": ((nq + 2 * nkv) * 128, 3584), "o": (3584, nq * 128), "down": (3584, 18944 // tp)}
+
+
+@pytest.fixture
+def plan_registry():
+    from vllm_omni_amd import _C
+    from vllm_omni_amd.tuned import linear_plans
+
+    linear_plans.reset()
+    yield _C
+    linear_plans.reset()
+
+
+_PLAIN_PLANS = [(64, w, s) for w in (32, 64, 96, 128, 160, 192, 256) for s in (1, 3)] + \
+               [(128, w, s) for w in (32, 64, 96, 128, 160) for s in (1, 4)] + [(256, 128, 2), (256, 160, 1)]
+
+
+@pytest.mark.parametrize("rows,wrows,split", _PLAIN_PLANS)
+def test_registered_plain_plans_match_reference(plan_registry, rows, wrows, split):
+    """Every built (rows per block, weight rows per tile, split-K) on a TP-4 shard shape with 128 rows, a ragged row
+    count that leaves the last row block partly empty, and a tile count that is not a multiple of 8 (the id -> (item,
+    row block) map pads the grid): against the float64 reference; the partials-only half + its reduce == the one call,
+    bit for bit."""
+    from vllm_omni_amd import ops
+    _C = plan_registry
+    g = torch.Generator(device="cuda").manual_seed(rows + wrows + split)
+    for m, (n, k) in [(128, _talker_shard_shapes(4)["down"]), (100, (1152, 896)), (256, (3584, 896)), (37, (208, 256))]:
+        assert _C.lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 0, 512, n, k, rows, wrows, split) == _C.MI_OK
+        import ctypes
+        buf = (ctypes.c_int32 * 3)()
+        assert _C.lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_FULL, m, n, k, buf) == _C.MI_OK
+        assert list(buf)[:2] == [rows, wrows] and buf[2] == (split if split <= k // 64 else 1), list(buf)
+        x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+        b = torch.randn(n, device="cuda", generator=g).to(torch.bfloat16)
+        y = ops.linear(x, w, b)
+        ref = _ref(x, w, b)
+        err = (y.double() - ref).abs()
+        tol = ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().amax(dim=1, keepdim=True).clamp_min(1.0)
+        assert bool((err <= tol).all()), f"m={m} n={n} k={k}: max err {err.max().item():.4g}"
+        part = ops.linear_partials(x, w, b)
+        if buf[2] > 1:
+            assert part is not None and part.split == buf[2]
+            assert torch.equal(part.materialize(), y)
+        else:
+            assert part is None
+
+
+@pytest.mark.parametrize("rows,wrows", [(64, w) for w in (32, 64, 96, 128, 160, 192)] + [(128, w) for w in (32, 64, 96, 128, 160)]
+                         + [(256, 32), (256, 64), (256, 128), (256, 160)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_registered_gated_plans_match_unfused_pair(plan_registry, rows, wrows, dtype):
+    """gate_up_proj + SiluAndMul on every built gated tile (weight rows per tile = 2 x its output columns), TP-4 shard
+    shape at 128 and 256 rows, ragged rows and a last tile that hangs over the intermediate size."""
+    from vllm_omni_amd import ops
+    _C = plan_registry
+    g = torch.Generator(device="cuda").manual_seed(rows + wrows)
+    for m, inter, k in [(128, 4736, 3584), (256, 4736, 1024), (100, 304, 256)]:
+        assert _C.lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_GATED, 0, 512, inter, k, rows, wrows, 1) == _C.MI_OK
+        x = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+        w = (torch.randn(2 * inter, k, device="cuda", generator=g) * k ** -0.5).to(dtype)
+        y = ops.linear_silu_mul(x, w)
+        gu = (x.double() @ w.double().t()).to(dtype).float()
+        gate, up = gu[:, :inter], gu[:, inter:]
+        ref = gate / (1.0 + torch.exp(-gate)) * up
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        slack = (up.abs() * 1.1 * gate.abs() + (gate / (1.0 + torch.exp(-gate))).abs() * up.abs()) * ulp
+        err = (y.float() - ref).abs()
+        assert bool((err <= ref.abs() * ulp + slack + 1e-3).all()), f"m={m} inter={inter}: max err {err.max().item():.4g}"
+
+
+def test_plans_of_different_tile_shapes_give_the_same_sums_up_to_order(plan_registry):
+    """Two plans of one problem differ only in fp32 summation order (split-K slices): same 16-bit output to one ulp."""
+    from vllm_omni_amd import ops
+    _C = plan_registry
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n, k, m = 3584, 4736, 128
+    x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+    outs = []
+    for rows, wrows, split in [(64, 96, 1), (128, 64, 1), (64, 32, 1)]:
+        assert _C.lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 0, 512, n, k, rows, wrows, split) == _C.MI_OK
+        outs.append(ops.linear(x, w))
+    # no split: every output element is ONE fp32 chain over k in the same (permuted) order, whatever the tile shape
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_tuned_table_routes_the_shard_shapes(plan_registry, monkeypatch):
+    """tuned/linear_plans_gfx950.json (tools/tune_linear_plans.py): loading it registers a plan per measured shape, and
+    layers routes a TP-4 rank's projections at 128 rows by its timings — the fused gate_up where it is ahead of the
+    library pair, o_proj / down_proj on the kernel — with results equal to the reference."""
+    from vllm_omni_amd import layers, ops
+    from vllm_omni_amd.tuned import linear_plans
+    monkeypatch.setattr(layers, "_LINEAR_MODE", "auto")
+    assert linear_plans.load() >= 40
+    e = linear_plans.lookup(128, 4736, 3584, True)
+    assert e is not None and e["m"] == 128 and e["full"]["us"] < e["library_us"]
+    assert linear_plans.lookup(100, 3584, 4736, False)["m"] == 128 and linear_plans.lookup(300, 3584, 4736, False) is None
+    calls = {"fused": 0, "linear": 0}
+    rf, rl = ops.linear_silu_mul, ops.linear
+    monkeypatch.setattr(ops, "linear_silu_mul", lambda *a, **k: (calls.__setitem__("fused", calls["fused"] + 1), rf(*a, **k))[1])
+    monkeypatch.setattr(ops, "linear", lambda *a, **k: (calls.__setitem__("linear", calls["linear"] + 1), rl(*a, **k))[1])
+    g = torch.Generator(device="cuda").manual_seed(2)
+    gu = layers.MergedColumnParallelLinear(3584, [4736] * 2, bias=False, dtype=torch.bfloat16, device="cuda")
+    gu.weight = (torch.randn(2 * 4736, 3584, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    x = torch.randn(128, 3584, device="cuda", generator=g).to(torch.bfloat16)
+    y = layers.fused_gate_up_silu(gu, x)
+    assert y is not None and calls["fused"] == 1
+    z = ops.silu_and_mul(torch.nn.functional.linear(x, gu.weight))
+    assert (y.float() - z.float()).abs().max().item() <= 0.02 * z.float().abs().max().item() + 1e-3
+    dn = layers.RowParallelLinear(4736, 3584, bias=False, dtype=torch.bfloat16, device="cuda")
+    dn.weight = (torch.randn(3584, 4736, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    xa = torch.randn(128, 4736, device="cuda", generator=g).to(torch.bfloat16)
+    yd, _ = dn(xa)
+    assert calls["linear"] == 1
+    assert (yd.double() - xa.double() @ dn.weight.double().t()).abs().max().item() < 0.05

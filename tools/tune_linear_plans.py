@@ -1,0 +1,50 @@
+"""Measures the tile plan of the decode-batch linear kernel for every (tensor-parallel degree, rows per rank) pair the
+headline talker's plans produce, and writes vllm_omni_amd/tuned/linear_plans_gfx950.json — the table
+`vllm_omni_amd.tuned.linear_plans` registers with the library (mi_linear_plan_set) and `layers.py` routes by.  The
+counterpart of tools/tune_gemms.py (TunableOp selections of the library GEMMs the same layers fall back to).
+
+  python tools/tune_linear_plans.py [--out PATH] [--tp 1,2,4] [--rows 32,64,128,256]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_shard_gemm import sweep, talker_shapes  # noqa: E402
+from vllm_omni_amd import _C  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    here = os.path.dirname(os.path.abspath(__file__))
+    ap.add_argument("--out", default=os.path.join(here, "..", "vllm-omni_amd", "vllm_omni_amd", "tuned", "linear_plans_gfx950.json"))
+    ap.add_argument("--tp", default="1,2,4")
+    ap.add_argument("--rows", default="32,64,128,256")
+    a = ap.parse_args()
+    from vllm_omni_amd.tuned import enable_tuned_gemms
+
+    print("tuned library selections loaded:", enable_tuned_gemms(), flush=True)
+    _C.lib.mi_linear_plan_clear()          # the "built-in" column must be the heuristic, not an earlier table
+    g = torch.Generator(device="cuda").manual_seed(0)
+    entries = []
+    for tp in (int(t) for t in a.tp.split(",")):
+        for m in (int(r) for r in a.rows.split(",")):
+            for name, n, k, gated, bias in talker_shapes(tp):
+                e = sweep(name, n, k, gated, bias, m, g, log=lambda s: print(s, flush=True), top=3)
+                e["tp"] = tp
+                entries.append(e)
+    doc = {"device": torch.cuda.get_device_name(0), "arch": "gfx950", "generated_by": "tools/tune_linear_plans.py",
+           "note": "us per call replayed from a hipGraph, weights rotating over > 256 MB; library = TunableOp-selected "
+                   "hipBLASLt/rocBLAS GEMM (gated: + the SiluAndMul launch); full = mi_linear incl. its reduce launch; "
+                   "partials = mi_linear_partials alone (the reduce rides in the consumer)",
+           "entries": entries}
+    with open(a.out, "w") as f:
+        json.dump(doc, f, indent=1)
+    print("wrote", a.out, len(entries), "entries")
+
+
+if __name__ == "__main__":
+    main()

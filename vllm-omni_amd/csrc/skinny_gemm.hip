@@ -24,6 +24,9 @@
 //     in the epilogue, rounded as the unfused pair rounds.
 // Measured in situ at 256 rows: down_proj 47 us + reduce against 77 us for the TunableOp-selected
 // library kernel, gate_up_proj + SiluAndMul 71 us against 81 + 7 us; which layers use it: layers.py.
+#include <mutex>
+#include <vector>
+
 #include "mfma_attn_common.h"
 #include "skinny_grouped.h"
 
@@ -37,11 +40,12 @@
 #ifndef MI_SKINNY_MH8
 #define MI_SKINNY_MH8 2          // consumer waves per slab at 65-128 rows (8 m-tiles)
 #endif
-#ifndef MI_SKINNY_NST4
-// ring stages at <= 64 rows.  A stage is 28 / 24 KB there, so five / six fit (`(NSLAB) == 5 ? 5 : 6`); measured level
-// with three at 32 and 64 rows on all four talker projections (profiles/r03k_ring_depth_ab.log: gate_up 6.04 against
-// 5.96 TB/s, down 4.94 / 4.97, the two small ones 0.1-0.4 us slower) — the ring depth is not what bounds them
-#define MI_SKINNY_NST4(NSLAB) 3
+#ifndef MI_SKINNY_RING_KB
+// LDS the ring of the first-generation kernel may take: stages = clamp(MI_SKINNY_RING_KB / stage, 3, 8).  A step's
+// pieces take ~1.1 us from issue to landing, so a CU needs ~75 KB in flight to take in the ~68 GB/s its L1 path
+// delivers (MI355X_MICROARCH.md, ring-gemm); three stages of a 20 KB step keep 40 KB in flight.  (Round 3 measured
+// deeper rings level at <= 64 rows on the dp8 shapes — HBM-bound there, profiles/r03k_ring_depth_ab.log.)
+#define MI_SKINNY_RING_KB 144
 #endif
 #ifndef MI_SKINNY_GROUPED_NST
 #define MI_SKINNY_GROUPED_NST 3  // ring stages of the grouped (sparse-MoE expert) form: 72 KB, two workgroups per CU
@@ -73,6 +77,7 @@ struct SkinnyParams {
   const float* xs;        // int8 operands: per-row activation scales [M]
   const float* ws;        // int8 operands: per-output-channel weight scales [N] (GATED: [2 N], gate then up)
   int32_t M, N, K, S;     // GATED: N = output columns I; the weight has 2 I rows (gate rows, then up rows)
+  int32_t RB, U;          // first-generation kernel, not GROUPED: row blocks of 16 MT rows; U = tiles x S work items per row block
   // GROUPED (sparse-MoE expert GEMMs, fused_moe.hip): grid.y = one tile of `rpt` token rows that share one expert
   const int32_t* row_map;      // [max_rows] pair index per row or -1
   const int32_t* tile_expert;  // [max_tiles]
@@ -193,17 +198,25 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
   using acc_t = typename AccOf<Tag>::type;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = GROUPED ? 0 : blockIdx.y * (16 * MT);   // more than 16 MT rows (int8 at batch 512): one row block per grid.y
   const uint16_t* wbase = p.w;
+  int m0 = 0, wg = blockIdx.x;
   if constexpr (GROUPED) {
     // the maps were written by the alignment kernel just before this launch: keep their reads off a stale scalar cache
     scalar_cache_acquire();
     if ((int)blockIdx.y >= p.num_tiles[0]) return;   // whole workgroup, before any barrier
     wbase += (int64_t)p.tile_expert[blockIdx.y] * p.w_expert_stride;
+  } else {
+    // More rows than one image holds (16 MT): RB row blocks per (tile, slice).  Workgroup ids go round-robin over the 8
+    // XCDs, so the row blocks of one work item are dealt 8 ids apart: id = 8 RB q + 8 rb + j <-> item u = 8 q + j, row
+    // block rb.  They start together and on ONE XCD: the weight tile they share leaves HBM once and serves the others
+    // from that XCD's L2 (speed only: nothing depends on the placement).
+    const int per = 8 * p.RB, q = wg / per, rem = wg - q * per;
+    m0 = (rem >> 3) * (16 * MT);
+    wg = 8 * q + (rem & 7);
+    if (wg >= p.U) return;   // whole workgroup, before any barrier
   }
-  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so slice = id % S puts every k slice of x on the
-  // XCDs congruent to it (S = 8: one slice per XCD) — its rows are then re-read from ONE L2 by all the tiles
-  const int wg = blockIdx.x;
+  // XCD-aware order: slice = item % S puts every k slice of x on the XCDs congruent to it (S = 8: one slice per XCD) —
+  // its rows are then re-read from ONE L2 by all the tiles
   const int s = wg % p.S, tile = wg / p.S;
   const int nb = p.K >> 6;
   const int b_lo = (int)((int64_t)s * nb / p.S), b_hi = (int)((int64_t)(s + 1) * nb / p.S);
@@ -707,10 +720,58 @@ struct SkinnyPlan {
   int nslab, mt, tiles, split;
 };
 
+constexpr int ring_stages(int mt, int nslab) {
+  const int stage = mt * 2048 + nslab * 4096;
+  const int n = MI_SKINNY_RING_KB * 1024 / stage;
+  return n < 3 ? 3 : n > 8 ? 8 : n;
+}
+
 // Tile shape and split-K factor for one problem.  Goal: one workgroup per CU in ONE round (256 CUs), every CU busy.
 //   * 160-row tiles when that lands the tile count just under 256 (gate_up_proj: 37888 / 160 = 237 tiles), else
 //     128-row tiles with K cut into S slices so that tiles x S <= 256;
 //   * S is capped so the fp32 partials stay a fraction of the weight bytes and every slice keeps >= 4 k-blocks.
+// ---- tile plans registered by the host (mi_linear_plan_set): measured per deployment shape, like the TunableOp
+// selections of the library GEMMs.  Tile shapes that are built (launch_skinny): 16-bit operands only.
+constexpr bool plan_built(int mt, int ns, bool gated) {
+  if (mt == 4) return gated ? (ns >= 1 && ns <= 6) : ((ns >= 1 && ns <= 6) || ns == 8);
+  if (mt == 8) return ns >= 1 && ns <= 5;
+  if (mt == 16) return gated ? (ns == 1 || ns == 2 || ns == 4 || ns == 5) : (ns == 4 || ns == 5);
+  return false;
+}
+struct PlanEntry {
+  int purpose, m_lo, m_hi, n, k, mt, nslab, split;
+};
+std::mutex g_plan_mu;
+std::vector<PlanEntry> g_plans;
+
+void plan_fill(SkinnyPlan* pl, int mt, int ns, int split, int n_rows, bool gated) {
+  pl->mt = mt; pl->nslab = ns; pl->split = gated ? 1 : split;
+  const int cols = gated ? 16 * ns : 32 * ns;
+  pl->tiles = (n_rows + cols - 1) / cols;
+}
+
+// k == 0 matches any k (the gated entry point's plan does not depend on it)
+bool plan_lookup(int purpose, int m, int n, int k, SkinnyPlan* pl) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  for (const PlanEntry& e : g_plans) {
+    if (e.purpose != purpose || e.n != n || (k && e.k != k) || m <= e.m_lo || m > e.m_hi) continue;
+    plan_fill(pl, e.mt, e.nslab, e.split <= k / 64 || !k ? e.split : 1, n, purpose == MI_LINEAR_PLAN_GATED);
+    return true;
+  }
+  return false;
+}
+
+// MI_LINEAR_PLAN=<mt>,<nslab>,<split> / MI_GATED_PLAN=<mt>,<nslab>: tuning overrides, read per call (tools/bench_shard_gemm.py)
+bool plan_override(const char* var, int n_rows, bool gated, int k, SkinnyPlan* pl) {
+  const char* e = getenv(var);
+  if (!e || !*e) return false;
+  int mt = 0, ns = 0, sp = 1;
+  if (sscanf(e, "%d,%d,%d", &mt, &ns, &sp) < 2) return false;
+  if (!plan_built(mt, ns, gated) || sp < 1 || sp > 16) return false;
+  plan_fill(pl, mt, ns, sp <= k / 64 ? sp : 1, n_rows, gated);
+  return true;
+}
+
 SkinnyPlan skinny_plan(int m, int n, int k, int force_split) {
   SkinnyPlan pl;
   pl.mt = m <= 64 ? 4 : m <= 128 ? 8 : 16;
@@ -754,10 +815,13 @@ int launch_v2(const SkinnyParams& p, const dim3 grid, hipStream_t s) {
 
 // `dtype`: the type of the 16-bit OUTPUT (and of the operands, unless `int8`: then x / w are int8 rows and the sums
 // int32).  A launch covers ceil(M / (16 mt)) row blocks (grid.y): M > 256 only arises with int8 operands.
-int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int dtype, hipStream_t s, bool int8 = false) {
-  const dim3 grid(pl.tiles * pl.split, (p.M + 16 * pl.mt - 1) / (16 * pl.mt));
+int launch_skinny(const SkinnyParams& p_in, const SkinnyPlan& pl, bool gated, int dtype, hipStream_t s, bool int8 = false) {
+  SkinnyParams p = p_in;
+  p.RB = (p.M + 16 * pl.mt - 1) / (16 * pl.mt);
+  p.U = pl.tiles * pl.split;
   if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_ERR_UNSUPPORTED;
   if (pl.mt == 16 && pl.nslab >= 4 && linear_v2()) {
+    const dim3 grid(pl.tiles * pl.split, p.RB);   // second generation: one 256-row block per grid.y
 #define MI_V2(TAG, OT)                                                                                                   \
     do {                                                                                                                 \
       if (pl.nslab == 5) return gated ? launch_v2<TAG, OT, 10, 6, true>(p, grid, s) : launch_v2<TAG, OT, 10, 5, false>(p, grid, s); \
@@ -772,9 +836,10 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
     }
 #undef MI_V2
   }
+  const dim3 grid((p.U + 7) / 8 * 8 * p.RB);   // first generation: row blocks folded into the id (see the kernel)
 #define MI_SKINNY(TAG, OT, NSLAB, MT, MH, NL, GATED)                                                              \
   do {                                                                                                            \
-    constexpr int nst = MT == 4 ? MI_SKINNY_NST4(NSLAB) : 3;                                                      \
+    constexpr int nst = ring_stages(MT, NSLAB);                                                                   \
     auto kern = skinny_gemm_kernel<TAG, OT, NSLAB, MT, MH, NL, GATED, false, nst>;                                \
     constexpr int lds = nst * (MT * 2048 + NSLAB * 4096);                                                         \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
@@ -809,6 +874,30 @@ int launch_skinny(const SkinnyParams& p, const SkinnyPlan& pl, bool gated, int d
     else if (gated) MI_SKINNY_T(TAG, OT, true);                  \
     else MI_SKINNY_T(TAG, OT, false);                            \
   } while (0)
+  // shard shapes (16-bit operands): 64-row blocks with 32 to 256 weight rows per tile, 128-row blocks with 32 to 96 — the
+  // tiles that balance a workgroup's x and weight intake when a TP shard has 64-256 rows (shard_plan)
+#define MI_SKINNY_SHARD(TAG, OT)                                                         \
+  do {                                                                                   \
+    if (pl.mt == 4) {                                                                    \
+      if (pl.nslab == 1 && !gated) { MI_SKINNY(TAG, OT, 1, 4, 1, 4, false); return launch_status(); }   \
+      if (pl.nslab == 2 && !gated) { MI_SKINNY(TAG, OT, 2, 4, 1, 4, false); return launch_status(); }   \
+      if (pl.nslab == 3 && !gated) { MI_SKINNY(TAG, OT, 3, 4, 1, 4, false); return launch_status(); }   \
+      if (pl.nslab == 3 && gated) { MI_SKINNY(TAG, OT, 3, 4, 1, 4, true); return launch_status(); }     \
+      if (pl.nslab == 6 && !gated) { MI_SKINNY(TAG, OT, 6, 4, 1, 4, false); return launch_status(); }   \
+      if (pl.nslab == 6 && gated) { MI_SKINNY(TAG, OT, 6, 4, 1, 4, true); return launch_status(); }     \
+      if (pl.nslab == 8 && !gated) { MI_SKINNY(TAG, OT, 8, 4, 1, 4, false); return launch_status(); }   \
+    } else if (pl.mt == 8) {                                                             \
+      if (pl.nslab == 1 && !gated) { MI_SKINNY(TAG, OT, 1, 8, 2, 4, false); return launch_status(); }   \
+      if (pl.nslab == 2 && !gated) { MI_SKINNY(TAG, OT, 2, 8, 2, 4, false); return launch_status(); }   \
+      if (pl.nslab == 3 && !gated) { MI_SKINNY(TAG, OT, 3, 8, 2, 4, false); return launch_status(); }   \
+      if (pl.nslab == 3 && gated) { MI_SKINNY(TAG, OT, 3, 8, 2, 4, true); return launch_status(); }     \
+    }                                                                                    \
+  } while (0)
+  if (!int8) {
+    if (dtype == MI_DTYPE_BF16) MI_SKINNY_SHARD(bf16_tag, bf16_tag);
+    else MI_SKINNY_SHARD(f16_tag, f16_tag);
+  }
+#undef MI_SKINNY_SHARD
   if (int8) {
     if (dtype == MI_DTYPE_BF16) MI_SKINNY_G(i8_tag, bf16_tag);
     else MI_SKINNY_G(i8_tag, f16_tag);
@@ -848,6 +937,8 @@ int launch_grouped_rows(const SkinnyParams& p, const dim3 grid, int rpt, hipStre
 // fewer than half of the CUs with a workgroup, then 32- or 16-column tiles (MI_GATED_NSLAB=<1|2|4|5> overrides: tuning).
 SkinnyPlan gated_plan(int m, int inter) {
   SkinnyPlan pl;
+  if (plan_override("MI_GATED_PLAN", inter, true, 0, &pl)) return pl;
+  if (plan_lookup(MI_LINEAR_PLAN_GATED, m, inter, 0, &pl)) return pl;
   const int mm = m > 256 ? 256 : m;
   pl.mt = mm <= 64 ? 4 : mm <= 128 ? 8 : 16;   // 257-512 rows: two row blocks of 16 m-tiles (grid.y)
   pl.split = 1;
@@ -888,7 +979,11 @@ int forced_split() {   // MI_LINEAR_SPLIT=<S>: tuning override of the split-K fa
 namespace {
 // 16-bit plan for up to 512 rows: 257-512 rows run as two row blocks per weight tile (grid.y), with the split halved so
 // the grid still fits one round — the same arrangement as the W8A8 entry points below
-mi::SkinnyPlan linear_plan(int m, int n, int k) {
+mi::SkinnyPlan linear_plan(int m, int n, int k, int purpose = MI_LINEAR_PLAN_FULL) {
+  mi::SkinnyPlan reg;
+  if (mi::plan_override("MI_LINEAR_PLAN", n, false, k, &reg)) return reg;
+  if (purpose == MI_LINEAR_PLAN_PARTIALS && mi::plan_lookup(MI_LINEAR_PLAN_PARTIALS, m, n, k, &reg)) return reg;
+  if (mi::plan_lookup(MI_LINEAR_PLAN_FULL, m, n, k, &reg)) return reg;
   mi::SkinnyPlan pl = mi::skinny_plan(m > 256 ? 256 : m, n, k, forced_split());
   if (m > 256 && forced_split() <= 0) pl.split = pl.split > 1 ? (pl.split + 1) / 2 : 1;
   return pl;
@@ -898,8 +993,43 @@ mi::SkinnyPlan linear_plan(int m, int n, int k) {
 extern "C" int64_t mi_linear_workspace_bytes(int32_t m, int32_t n, int32_t k) {
   using namespace mi;
   if (m <= 0 || n <= 0 || k <= 0) return 0;
-  const SkinnyPlan pl = linear_plan(m, n, k);
-  return pl.split > 1 ? (int64_t)pl.split * m * n * (int64_t)sizeof(float) : 0;
+  const SkinnyPlan pl = linear_plan(m, n, k), pp = linear_plan(m, n, k, MI_LINEAR_PLAN_PARTIALS);
+  const int split = pl.split > pp.split ? pl.split : pp.split;   // one workspace serves both entry points
+  return split > 1 ? (int64_t)split * m * n * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int mi_linear_plan_set(int32_t purpose, int32_t m_lo, int32_t m_hi, int32_t n, int32_t k, int32_t rows_per_block,
+                                  int32_t weight_rows_per_tile, int32_t split) {
+  using namespace mi;
+  if (purpose < MI_LINEAR_PLAN_FULL || purpose > MI_LINEAR_PLAN_GATED || m_lo < 0 || m_hi <= m_lo || n <= 0 || k < 0) return MI_ERR_INVALID_ARG;
+  if (purpose != MI_LINEAR_PLAN_GATED && k <= 0) return MI_ERR_INVALID_ARG;
+  if (rows_per_block % 64 || weight_rows_per_tile % 32 || split < 1 || split > 16) return MI_ERR_INVALID_ARG;
+  const bool gated = purpose == MI_LINEAR_PLAN_GATED;
+  const int mt = rows_per_block / 16, ns = weight_rows_per_tile / 32;
+  if (!plan_built(mt, ns, gated)) return MI_ERR_UNSUPPORTED;
+  if (gated && split != 1) return MI_ERR_INVALID_ARG;   // the activation needs the whole sum
+  if (purpose == MI_LINEAR_PLAN_PARTIALS && split < 2) return MI_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  for (PlanEntry& e : g_plans)
+    if (e.purpose == purpose && e.n == n && e.k == k && e.m_lo == m_lo && e.m_hi == m_hi) {
+      e.mt = mt; e.nslab = ns; e.split = split;
+      return MI_OK;
+    }
+  g_plans.push_back(PlanEntry{purpose, m_lo, m_hi, n, k, mt, ns, split});
+  return MI_OK;
+}
+
+extern "C" void mi_linear_plan_clear(void) {
+  std::lock_guard<std::mutex> lk(mi::g_plan_mu);
+  mi::g_plans.clear();
+}
+
+extern "C" int mi_linear_plan_get(int32_t purpose, int32_t m, int32_t n, int32_t k, int32_t* out) {
+  using namespace mi;
+  if (!out || m <= 0 || n <= 0 || purpose < MI_LINEAR_PLAN_FULL || purpose > MI_LINEAR_PLAN_GATED) return MI_ERR_INVALID_ARG;
+  const SkinnyPlan pl = purpose == MI_LINEAR_PLAN_GATED ? gated_plan(m, n) : linear_plan(m, n, k, purpose);
+  out[0] = 16 * pl.mt; out[1] = 32 * pl.nslab; out[2] = pl.split;
+  return MI_OK;
 }
 
 extern "C" int mi_linear(void* out, const void* x, const void* weight, const void* bias, int32_t m, int32_t n, int32_t k,
@@ -949,7 +1079,7 @@ extern "C" int mi_linear_partials(const void* x, const void* weight, int32_t m, 
   if (m > 512 || k % 64 || n % 16 || x_row_stride % 8) return MI_ERR_UNSUPPORTED;
   if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)weight) & 15) return MI_ERR_INVALID_ARG;
-  const SkinnyPlan pl = linear_plan(m, n, k);
+  const SkinnyPlan pl = linear_plan(m, n, k, MI_LINEAR_PLAN_PARTIALS);
   if (pl.split <= 1) return MI_ERR_UNSUPPORTED;   // nothing to defer: mi_linear writes the output directly
   if (!workspace || ((uintptr_t)workspace & 15)) return MI_ERR_INVALID_ARG;
   if (workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(float)) return MI_ERR_WORKSPACE;

@@ -17,7 +17,8 @@ MI_DTYPE_F16, MI_DTYPE_BF16, MI_DTYPE_F32 = 0, 1, 2
 MI_OK = 0
 MI_ERR_INVALID_ARG, MI_ERR_UNSUPPORTED, MI_ERR_WORKSPACE = -1, -2, -3
 MI_ERR_LAUNCH, MI_ERR_EXHAUSTED, MI_ERR_STATE = -4, -5, -6
-ABI_VERSION = 1
+ABI_VERSION = 2
+MI_LINEAR_PLAN_FULL, MI_LINEAR_PLAN_PARTIALS, MI_LINEAR_PLAN_GATED = 0, 1, 2
 MI_DECODE_PACKED_PV = 1
 MI_DECODE_FORCE_VALU = 2
 MI_DECODE_NONTEMPORAL = 4
@@ -84,6 +85,9 @@ SIGNATURES = {
                                              c_int, _P]),
     "mi_linear_silu_mul": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_linear": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, _P, c_int64, c_int, _P]),
+    "mi_linear_plan_set": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mi_linear_plan_clear": (None, []),
+    "mi_linear_plan_get": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_int32)]),
     "mi_kv_pack": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                            c_int64, c_int64, c_int64, _P]),
     "mi_sample_tokens": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P]),

@@ -309,6 +309,25 @@ _DEFER_REDUCE = os.environ.get("VLLM_OMNI_AMD_DEFER_REDUCE", "1") != "0"   # spl
 # level with the library GEMM at every batch size measured (15.14 vs 15.15 ms/step at 256 rows, 4.79 vs 4.80 at 32),
 # so it is off unless asked for
 _DEFER_QKV = os.environ.get("VLLM_OMNI_AMD_DEFER_QKV", "0") == "1"
+# with a tuned entry for the shape the table decides (qkv partials into the RoPE launch when measured ahead); "0" pins
+# qkv_proj to a 16-bit output
+_DEFER_QKV_TUNED = os.environ.get("VLLM_OMNI_AMD_DEFER_QKV", "1") != "0"
+
+
+def _tuned(m: int, n: int, k: int, gated: bool = False):
+    """The measured entry of this shape in ``tuned/linear_plans_gfx950.json`` (tools/tune_linear_plans.py), or None:
+    which tile plan the kernel runs there (registered with the library on first use) and what it, its partials-only
+    half and the library GEMM take.  Shapes outside the table keep the round-3 rules below."""
+    if _LINEAR_MODE != "auto":
+        return None
+    from .tuned import linear_plans
+
+    linear_plans.load()
+    return linear_plans.lookup(m, n, k, gated)
+
+
+# what folding a split-K reduce into the consumer (fused-add RMSNorm, RoPE + KV write) adds to that launch, in us
+_DEFERRED_REDUCE_US = 1.0
 
 
 def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
@@ -353,6 +372,9 @@ def fused_gate_up_silu(layer, x: torch.Tensor) -> Optional[torch.Tensor]:
     n, k = w.shape
     if n % 32 or not ops.linear_supported(m, n // 2, k, x.dtype):
         return None
+    e = _tuned(m, n // 2, k, gated=True)
+    if e is not None and e.get("full"):
+        return ops.linear_silu_mul(x, w) if e["full"]["us"] < e["library_us"] else None
     if _LINEAR_MODE not in ("kernel", "mlp", "mlp+o") and not _fused_gate_up_wins(m, n // 2, k):
         return None
     return ops.linear_silu_mul(x, w)
@@ -396,6 +418,17 @@ def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_re
     if _LINEAR_MODE != "library" and x.is_cuda:
         m = x.numel() // x.shape[-1]
         n, k = w.shape
+        e = _tuned(m, n, k) if ops.linear_supported(m, n, k, x.dtype) else None
+        if e is not None and e.get("full"):
+            # measured at this shape: the cheapest of {library, kernel + its reduce launch, partials reduced downstream}
+            best_direct = min(e["library_us"], e["full"]["us"])
+            part = e.get("partials")
+            if defer_reduce and _DEFER_REDUCE and part and part["us"] + _DEFERRED_REDUCE_US < best_direct and (
+                    defer_reduce != "rope" or _DEFER_QKV_TUNED):
+                pr = ops.linear_partials(x, w, bias)
+                if pr is not None:
+                    return pr
+            return ops.linear(x, w, bias) if e["full"]["us"] < e["library_us"] else F.linear(x, w, bias)
         if ops.linear_supported(m, n, k, x.dtype):
             wins = (_LINEAR_MODE == "kernel" or _streaming_kernel_wins(m, n, k)
                     or (_LINEAR_MODE in ("mlp", "mlp+o") and getattr(layer, "_is_down_proj", False))
