@@ -31,6 +31,7 @@ import json
 import os
 import sys
 import time
+from typing import Optional
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "vllm-omni_amd"))
@@ -241,22 +242,28 @@ def fill_kv_cache(runner, seed: int) -> None:
 
 
 def time_decode_launches(runner, steps: int):
-    """Instrumented pass: HIP events around every paged-attention decode launch (on the stream the
-    kernel is launched on), eager mode, same inputs as the timed region.  Returns (avg ms, launches)."""
+    """Instrumented pass: HIP events around every paged-attention decode CALL of an eager step (on the stream the kernel
+    is launched on), same inputs as the timed region.  A call = the attention launch (with RoPE + KV write inside on
+    pure-decode steps) + the partition-merge launch where the context is partitioned, and the interval includes the
+    host's launch latency — on a 45 us kernel that is 10-20 %, so this figure is reported beside the kernel-only one of
+    ``time_decode_kernel``, not as the roofline figure.  Returns (avg ms, calls)."""
     from vllm_omni_amd import ops
 
     events: list[tuple[torch.cuda.Event, torch.cuda.Event]] = []
-    orig = ops.paged_attn_decode
+    origs = {n: getattr(ops, n) for n in ("paged_attn_decode", "rope_cache_paged_attn_decode")}
 
-    def timed(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(*a, **k)
-        e1.record()
-        events.append((e0, e1))
-        return r
+    def wrap(orig):
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+            return r
+        return timed
 
-    ops.paged_attn_decode = timed
+    for n, f in origs.items():
+        setattr(ops, n, wrap(f))
     was = runner.enforce_eager
     runner.enforce_eager = True
     try:
@@ -266,10 +273,62 @@ def time_decode_launches(runner, steps: int):
             runner.sample_tokens()
         torch.cuda.synchronize()
     finally:
-        ops.paged_attn_decode = orig
+        for n, f in origs.items():
+            setattr(ops, n, f)
         runner.enforce_eager = was
     ms = [a.elapsed_time(b) for a, b in events]
     return (float(np.mean(ms)) if ms else float("nan")), len(ms)
+
+
+def time_decode_kernel(runner, reps: int = 4):
+    """The decode attention KERNEL alone, on the step's own inputs: one launch per decoder layer — that layer's KV cache,
+    the step's block tables, sequence lengths, positions and slots as they sit in the runner's device buffers after the
+    timed region, the launch bound and partition choice of the captured step, RoPE + KV write inside exactly as the
+    step runs it — issued back to back, HIP events around each pass of L launches on the launching stream.  Back to
+    back: the host's launch latency hides behind the previous launch (as it does inside the captured graph) instead
+    of sitting inside the interval; every layer has its own KV cache (GBs apart), so nothing is re-read from a cache.
+    The partition-merge launch is left out (MI_DECODE_SKIP_MERGE), so the figure is the kernel rocprofv3's kernel trace
+    reports under the same name.  Returns (avg ms per launch, launches timed, variant)."""
+    from vllm_omni_amd import ops
+
+    layers = getattr(runner.model, "language_model", runner.model).model.layers
+    attn0 = layers[0].self_attn
+    n = runner.input_batch.num_reqs
+    nq, d = attn0.attn.num_heads, attn0.attn.head_size
+    bt = runner.input_batch.block_table[0]
+    table, lens = bt.block_table.gpu[:n], runner.seq_lens.gpu[:n]
+    pos, slots = runner.positions.gpu[:n], bt.slot_mapping.gpu[:n]
+    bound = runner.max_model_len
+    g = torch.Generator(device=runner.device).manual_seed(7)
+    qkv = torch.randn(n, (nq + 2 * attn0.attn.num_kv_heads) * d, device=runner.device, generator=g).to(torch.bfloat16)
+    q, k, v = qkv.split([nq * d, attn0.attn.num_kv_heads * d, attn0.attn.num_kv_heads * d], dim=-1)
+    out = torch.empty(n, nq * d, dtype=torch.bfloat16, device=runner.device)
+    rope = attn0.rotary_pos_emb
+    fused = ops.rope_decode_fusable(q, attn0.attn._kb, pos, rope.cos_sin_cache.shape[1], 0, n, bound) and attn0.q_norm is None
+
+    def one_pass():
+        for ly in layers:
+            at = ly.self_attn.attn
+            if fused:
+                ops.rope_cache_paged_attn_decode(out, q, k, v, pos, rope.cos_sin_cache, at._kb, at._vb, slots, table, lens,
+                                                 bound, at.scale, workspace=runner._decode_ws, _skip_merge=True)
+            else:
+                ops.paged_attn_decode(out, q, at._kb, at._vb, table, lens, bound, at.scale, workspace=runner._decode_ws,
+                                      _skip_merge=True)
+
+    with torch.inference_mode():
+        one_pass()
+        torch.cuda.synchronize()
+        ev = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            one_pass()
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+    total = sum(a.elapsed_time(b) for a, b in ev)
+    return total / (reps * len(layers)), reps * len(layers), ("RoPE + KV write inside" if fused else "attention only")
 
 
 def cpu_baseline(cfg, batch: int, ctx: int, block_size: int, budget_s: float = 20.0):
@@ -411,30 +470,54 @@ def run_plan(a, cfg, dev, world: int, rank: int, tp: int, dp: int, rehearsal: bo
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(k: int) -> None:
+    def run_steps(k: int, stamps: Optional[list] = None) -> None:
         """k engine steps; every step's output (ids + hidden states) is on the host when this returns.  Pipelined
-        mode retrieves step i's output after step i+1 has been launched (upstream's async scheduling)."""
+        mode retrieves step i's output after step i+1 has been launched (upstream's async scheduling).  ``stamps``
+        receives the wall clock at which each step's output reached the host (per-step distribution)."""
         pending = None
         for _ in range(k):
             runner.execute_model(sched.schedule())
             out = runner.sample_tokens(async_output=not a.sync_output)
             if pending is not None:
                 pending.get_output()
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
+            elif a.sync_output and stamps is not None:
+                stamps.append(time.perf_counter())
             pending = None if a.sync_output else out
         if pending is not None:
             pending.get_output()
+            if stamps is not None:
+                stamps.append(time.perf_counter())
 
     run_steps(a.warmup)
     barrier()
+    stamps: list = []
     t0 = time.perf_counter()
-    run_steps(a.steps)
+    run_steps(a.steps, stamps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # per-step wall times of THIS rank inside the timed region: the interval between consecutive outputs reaching the
+    # host (the first one, which also holds the pipeline fill, is measured from the start of the region)
+    runner._bench_step_ms = [(b - a_) * 1e3 for a_, b in zip([t0] + stamps[:-1], stamps)]
     return elapsed, runner, local_batch
+
+
+def step_distribution(step_ms: list) -> dict:
+    """p10 / p50 / p90 of the per-step wall times recorded inside the timed region (median
+    with p10 / p90, so that box-to-box spread can be told from a regression); `ms_per_step` stays the mean of the
+    region, which is what `value` is computed from."""
+    if len(step_ms) < 2:
+        return {}
+    v = sorted(step_ms[1:]) if len(step_ms) > 4 else sorted(step_ms)   # the first interval also holds the pipeline fill
+    q = lambda f: v[min(len(v) - 1, max(0, int(round(f * (len(v) - 1)))))]   # noqa: E731
+    return {"ms_per_step_p10": round(q(0.10), 3), "ms_per_step_p50": round(q(0.50), 3), "ms_per_step_p90": round(q(0.90), 3),
+            "ms_per_step_how": f"rank 0, {len(v)} intervals between consecutive step outputs reaching the host inside "
+                               "the timed region (first interval excluded: pipeline fill)"}
 
 
 def time_allreduce(dev, rows: int, cols: int, calls: int = 50) -> dict:
@@ -538,7 +621,9 @@ def main():
                             f"{' + code predictor' if a.code_predictor else ''}, bs={a.batch} ctx={a.ctx} (not the headline shape)"),
             "value": round(tokens_per_s, 1),
             "unit": "tokens/s", "n_gpus": n_ranks_seen, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3),
+            **{k: head[k] for k in ("ms_per_step_p10", "ms_per_step_p50", "ms_per_step_p90", "ms_per_step_how") if k in head},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16" if a.quantization is None else "bf16 (attention, norms, activations) + int8 W8A8 decoder linears",
             "data": "synthetic (random-init weights, N(0,1) KV cache, random non-contiguous block tables, fixed ctx)",
             "config": {"workload": f"{cfg.name} decode step, global batch {a.batch}, ctx {a.ctx}, block {a.block_size}",
@@ -572,7 +657,8 @@ def main():
             return {"bound": "hbm", "kernel": "mi::decode_mfma_kernel (paged-attention decode)", "achieved": None,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
                     "algorithmic_bytes_per_launch": algo_bytes}
-        kern_ms, launches = time_decode_launches(runner, a.roofline_steps)
+        call_ms, calls = time_decode_launches(runner, a.roofline_steps)
+        kern_ms, launches, variant = time_decode_kernel(runner)
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_decode_bytes_per_launch.json")
@@ -594,7 +680,12 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 4),
                 "launches_timed": launches,
-                "timing": "HIP events around every decode launch in an instrumented eager pass right after the timed region"}
+                "timing": "HIP events around passes of one decode-kernel launch per layer, issued back to back on the "
+                          "step's own inputs right after the timed region (" + variant + "; the partition-merge launch "
+                          "left out): the kernel rocprofv3's kernel trace lists as decode_mfma_kernel",
+                "eager_call_ms": round(call_ms, 4), "eager_calls_timed": calls,
+                "eager_call_how": "HIP events around each decode call of an instrumented EAGER step: attention launch + "
+                                  "merge launch (if partitioned) + the host's launch latency — the round-1..3 figure"}
 
     def measure(tp: int, dp: int, label: str, role: str, eager: bool = False, allreduce: str = "rccl") -> dict:
         # fault injection for rehearsing the safety net (never set by the driver): "skip:<text>", "raise:<text>",
@@ -610,7 +701,7 @@ def main():
         elapsed, runner, local_batch = run_plan(a, cfg, dev, world, rank, tp, dp, rehearsal, eager, allreduce)
         ms = elapsed / a.steps * 1e3
         res = {"parallelism": label, "role": role, "tp": tp, "allreduce": allreduce if tp > 1 else "none",
-               "ms_per_step": round(ms, 3),
+               "ms_per_step": round(ms, 3), **step_distribution(getattr(runner, "_bench_step_ms", [])),
                "value": round(a.batch * a.steps / elapsed, 1), "hipgraph": bool(runner._graphs),
                "decode_partition": runner._decode_part,
                "tuned_gemm_csv_loaded": bool(getattr(runner, "tuned_gemms", False)),

@@ -190,6 +190,9 @@ int mi_rope_cache_attend_block_splitk(void* out, const void* partials, int32_t s
  * partial sums follow): with the flag the caller vouches that this region was zero before the first launch on the
  * workspace; every launch leaves it at zero (hipGraph replays need nothing in between). */
 #define MI_DECODE_FUSED_MERGE 16
+/* MI_DECODE_SKIP_MERGE (measurement only: bench.py's per-kernel roofline timing): the merge launch of a partitioned
+ * context is left out — `out` is NOT written when the context is partitioned.  Never set by the product. */
+#define MI_DECODE_SKIP_MERGE 32
 #define MI_DECODE_COUNTER_BYTES (1 << 20)
 int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_t num_q_heads,
                                              int32_t head_dim, int32_t max_seq_len,
@@ -203,6 +206,27 @@ int mi_paged_attn_decode(void* out, const void* q, const void* k_cache, const vo
                          int64_t cache_token_stride, int64_t cache_head_stride,
                          int32_t partition_size, void* workspace, int64_t workspace_bytes,
                          int dtype, int out_dtype, int32_t flags, void* stream);
+/* A4 + A7 + A5 in ONE launch for a pure-decode step (round 4): q [S, nq*d], k / v [S, nkv*d] arrive as qkv_proj wrote
+ * them (views of one qkv row are fine); every wave rotates its q heads in registers (neox, fp32 table row of
+ * positions[s], one rounding — mi_rope_neox_and_cache's arithmetic), and the wave that owns a sequence's last context
+ * partition rotates the token's k, writes it and v to cache row slot_mapping[s] (< 0: no write) and waits for the
+ * stores before it starts streaming — no other wave of the launch reads that row.  Result and cache contents equal
+ * mi_rope_neox_and_cache followed by mi_paged_attn_decode bit for bit; q is left un-rotated in memory.  Matrix-core
+ * kernel only (flags: PACKED_PV | NONTEMPORAL, no ROUNDED_P / FORCE_VALU; block_size >= 16; partition % 32 == 0),
+ * rot_dim == head_dim, 1-D positions, no q/k-norm: MI_ERR_UNSUPPORTED otherwise (callers run the two launches).
+ * Replaces the rotary_pos_emb + attn pair of qwen2_old.py:153-154 on decode steps. */
+int mi_rope_cache_paged_attn_decode(void* out, const void* q, const void* k, const void* v,
+                                    const int64_t* positions, const float* cos_sin_cache,
+                                    int32_t max_position, int32_t rot_dim, void* k_cache, void* v_cache,
+                                    const int64_t* slot_mapping, const int32_t* block_table,
+                                    const int32_t* seq_lens, int32_t num_seqs, int32_t num_q_heads,
+                                    int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                    int32_t block_table_stride, int32_t max_seq_len, float scale,
+                                    int64_t q_token_stride, int64_t k_token_stride, int64_t v_token_stride,
+                                    int64_t out_token_stride, int64_t cache_block_stride,
+                                    int64_t cache_token_stride, int64_t cache_head_stride,
+                                    int32_t partition_size, void* workspace, int64_t workspace_bytes,
+                                    int dtype, int out_dtype, int32_t flags, void* stream);
 /* Partition size the auto heuristic picks: the fewest partitions that leave >= 512 waves (>= 1024 at
  * head_dim <= 64) — ONE (direct output, no workspace, no merge launch) once num_seqs * num_kv_heads
  * reaches that; 256..8192 tokens. */

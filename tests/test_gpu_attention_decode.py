@@ -364,3 +364,155 @@ def test_long_partitions_walk_the_block_id_windows(dev, dtype):
     got = run(8192, dtype, kbv=(kd.to(dtype).to(dev), vd.to(dtype).to(dev)), qq=qq.to(dtype)).float()
     for s, e in enumerate(expect):
         assert torch.equal(got[s], torch.full((nq, d), e)), (s, targets[s])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: RoPE + KV write inside the decode launch (mi_rope_cache_paged_attn_decode; qwen2_old.py:153-154 as ONE launch)
+ROPE_CASES = [
+    # S, nq, nkv, d, bs, seq_lens (INCLUDING this step's token), partition_size
+    (5, 28, 4, 128, 16, [1, 16, 33, 300, 0], 0),          # S-A geometry; first token of a sequence; an inert padded row
+    (4, 7, 1, 128, 16, [32, 64, 1025, 2048], 1024),       # TP-4 shard: the token opens / ends a partition and a 32-token step
+    (4, 7, 1, 128, 16, [31, 65, 1024, 2049], 256),        # many partitions: exactly one wave per KV head owns the write
+    (3, 16, 2, 64, 16, [1, 33, 300], 0),                  # S-B geometry (d = 64)
+    (3, 32, 2, 128, 32, [18, 47, 129], 64),               # G = 16: two waves per KV head, block 32
+    (2, 8, 8, 128, 16, [17, 40], 0),                      # MHA
+]
+
+
+@pytest.mark.parametrize("layout", ["nb2", "head_major"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ROPE_CASES)
+def test_rope_fused_decode_equals_the_two_launches_bit_for_bit(dev, case, dtype, layout):
+    """q rotated in registers + the token's k / v written by the owning wave + attention == rope_neox_and_cache followed
+    by paged_attn_decode: output, K cache and V cache bit for bit (and therefore inside the oracle tolerance the two
+    launches are tested at), un-rotated q left alone, rows with slot -1 write nothing."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.layers import build_cos_sin_cache
+    S, nq, nkv, d, bs, lens, ps = case
+    kv, kb, vb, table, _, seq_lens = _mk_case(S, nq, nkv, d, bs, [max(n, 1) for n in lens], dtype, seed=11, layout=layout)
+    seq_lens = torch.tensor(lens, dtype=torch.int32)
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(S, (nq + 2 * nkv) * d, generator=g).to(dtype).to(dev)
+    csc = build_cos_sin_cache(d, 8192, 1e6, device=dev)
+    pos = torch.tensor([max(n - 1, 0) for n in lens], dtype=torch.int64)
+    slots = torch.tensor([int(table[i, (n - 1) // bs]) * bs + (n - 1) % bs if n > 0 else -1 for i, n in enumerate(lens)],
+                         dtype=torch.int64)
+    msl = max(max(lens), 1)
+
+    def caches():
+        kvg = kv.to(dev).clone()
+        if layout == "nb2":
+            return kvg, kvg[:, 0], kvg[:, 1]
+        return kvg, kvg[:, 0].permute(0, 2, 1, 3), kvg[:, 1].permute(0, 2, 1, 3)
+
+    outs = []
+    for fused in (False, True):
+        store, kc, vc = caches()
+        row = qkv.clone()
+        q, k, v = row.split([nq * d, nkv * d, nkv * d], dim=-1)
+        out = torch.full((S, nq * d), float("nan"), dtype=dtype, device=dev)
+        if fused:
+            assert ops.rope_decode_fusable(q, kc, pos, d, ps, S, msl)
+            ops.rope_cache_paged_attn_decode(out, q, k, v, pos.to(dev), csc, kc, vc, slots.to(dev), table.to(dev),
+                                             seq_lens.to(dev), msl, d ** -0.5, partition_size=ps)
+            assert torch.equal(row, qkv)                      # q / k / v rows are inputs only
+        else:
+            ops.rope_neox_and_cache(q, k, v, pos.to(dev), csc, d, kc, vc, slots.to(dev))
+            ops.paged_attn_decode(out, q, kc, vc, table.to(dev), seq_lens.to(dev), msl, d ** -0.5, partition_size=ps)
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), store.cpu()))
+    assert torch.equal(outs[0][1], outs[1][1]), "cache contents differ"
+    assert not torch.equal(outs[1][1], kv), "nothing was written"
+    assert torch.equal(outs[0][0], outs[1][0]), "attention outputs differ"
+    # and against the oracle chain on the same inputs
+    q0, k0, v0 = qkv.cpu().split([nq * d, nkv * d, nkv * d], dim=-1)
+    live = [i for i, n in enumerate(lens) if n > 0]
+    table_cpu = ref_ops.build_cos_sin_cache(d, 8192, 1e6)
+    qr = ref_ops.rope_neox(pos, q0, d, table_cpu, round_to=dtype).view(S, nq, d)
+    kr = ref_ops.rope_neox(pos, k0, d, table_cpu, round_to=dtype).view(S, nkv, d)
+    kb2, vb2 = kb.clone(), vb.clone()
+    for i in live:
+        blk, off = int(slots[i]) // bs, int(slots[i]) % bs
+        kb2[blk, off] = kr[i]
+        vb2[blk, off] = v0[i].view(nkv, d)
+    ref = ref_ops.paged_attention_decode(qr, kb2, vb2, table, seq_lens, d ** -0.5)
+    got = outs[1][0].view(S, nq, d).float()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for i in live:
+        torch.testing.assert_close(got[i], ref[i], rtol=1e-3 + ulp, atol=1e-4 + ulp * float(ref[i].abs().max()))
+
+
+def test_rope_fused_decode_replays_from_a_graph_while_sequences_grow(dev):
+    """The fused launch inside a hipGraph: each replay appends one token per sequence (slot, position and seq_len are
+    device buffers the host rewrites) and must equal the eager two-launch step on a twin cache — eight steps that cross a
+    KV-block and a 32-token step boundary."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.layers import build_cos_sin_cache
+    S, nq, nkv, d, bs, dtype = 6, 7, 1, 128, 16, torch.bfloat16
+    start = [13, 30, 31, 47, 255, 1000]
+    g = torch.Generator().manual_seed(3)
+    nblk = (max(start) + 16) // bs + 1
+    table = (torch.randperm(S * nblk, generator=g) + 1).view(S, nblk).to(torch.int32).to(dev)
+    kc_a = torch.randn(S * nblk + 1, bs, nkv, d, generator=g).to(dtype).to(dev)
+    vc_a = torch.randn(S * nblk + 1, bs, nkv, d, generator=g).to(dtype).to(dev)
+    kc_b, vc_b = kc_a.clone(), vc_a.clone()
+    csc = build_cos_sin_cache(d, 4096, 1e6, device=dev)
+    qkv = torch.randn(S, (nq + 2) * d, generator=g).to(dtype).to(dev)
+    pos = torch.zeros(S, dtype=torch.int64, device=dev)
+    slots = torch.zeros(S, dtype=torch.int64, device=dev)
+    lens = torch.zeros(S, dtype=torch.int32, device=dev)
+    out_g = torch.zeros(S, nq * d, dtype=dtype, device=dev)
+    msl = 2048
+    q, k, v = qkv.split([nq * d, d, d], dim=-1)
+
+    def set_step(i):
+        n = [s + i + 1 for s in start]
+        pos.copy_(torch.tensor([x - 1 for x in n]))
+        lens.copy_(torch.tensor(n, dtype=torch.int32))
+        tb = table.cpu()
+        slots.copy_(torch.tensor([int(tb[j, (x - 1) // bs]) * bs + (x - 1) % bs for j, x in enumerate(n)]))
+
+    set_step(0)
+    ws = ops.new_decode_workspace(ops.decode_workspace_bytes(S, nq, d, msl, ops.decode_auto_partition(S, nkv, msl, bs)), dev)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ops.rope_cache_paged_attn_decode(out_g, q, k, v, pos, csc, kc_a, vc_a, slots, table, lens, msl, d ** -0.5, workspace=ws)
+    torch.cuda.current_stream().wait_stream(st)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.rope_cache_paged_attn_decode(out_g, q, k, v, pos, csc, kc_a, vc_a, slots, table, lens, msl, d ** -0.5, workspace=ws)
+    for i in range(8):
+        set_step(i)
+        qkv.copy_(torch.randn(S, (nq + 2) * d, generator=g).to(dtype))
+        graph.replay()
+        row = qkv.clone()
+        q2, k2, v2 = row.split([nq * d, d, d], dim=-1)
+        ops.rope_neox_and_cache(q2, k2, v2, pos, csc, d, kc_b, vc_b, slots)
+        out_e = torch.empty_like(out_g)
+        ops.paged_attn_decode(out_e, q2, kc_b, vc_b, table, lens, msl, d ** -0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(out_g, out_e), f"step {i}"
+        assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b), f"step {i}"
+
+
+def test_rope_fused_decode_refuses_what_it_does_not_cover(dev):
+    from vllm_omni_amd import ops
+    from vllm_omni_amd._C import MIError
+    from vllm_omni_amd.layers import build_cos_sin_cache
+    S, nq, nkv, d = 2, 8, 2, 128
+    csc = build_cos_sin_cache(d, 64, 1e4, device=dev)
+    pos2 = torch.zeros(3, S, dtype=torch.int64, device=dev)
+    kc8 = torch.zeros(8, 8, nkv, d, dtype=torch.bfloat16, device=dev)      # block 8: the VALU kernel's shape
+    kc16 = torch.zeros(8, 16, nkv, d, dtype=torch.bfloat16, device=dev)
+    assert not ops.rope_decode_fusable(None, kc8, pos2[0], d, 0, S, 40)
+    assert not ops.rope_decode_fusable(None, kc16, pos2, d, 0, S, 40)       # M-RoPE rows
+    assert not ops.rope_decode_fusable(None, kc16, pos2[0], 64, 0, S, 40)   # partial rotary
+    assert ops.rope_decode_fusable(None, kc16, pos2[0], d, 0, S, 40)
+    q = torch.zeros(S, nq * d, dtype=torch.bfloat16, device=dev)
+    kk = torch.zeros(S, nkv * d, dtype=torch.bfloat16, device=dev)
+    tb = torch.ones(S, 4, dtype=torch.int32, device=dev)
+    sl = torch.ones(S, dtype=torch.int32, device=dev)
+    with pytest.raises(MIError):
+        ops.rope_cache_paged_attn_decode(torch.empty_like(q), q, kk, kk, pos2[0], csc, kc8, kc8.clone(),
+                                         torch.zeros(S, dtype=torch.int64, device=dev), tb, sl, 40, 1.0)

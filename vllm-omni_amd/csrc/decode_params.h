@@ -24,10 +24,22 @@ struct DecodeParams {
   int32_t out_f32;
   float scale_log2e;
   int64_t q_stride, out_stride, blk_stride, tok_stride, head_stride;
+  // Fused RoPE + KV write (mi_rope_cache_paged_attn_decode; matrix-core kernel only): q arrives un-rotated and is
+  // rotated in registers; the wave that owns a sequence's LAST context partition rotates the token's k, writes it and
+  // v to cache row slot_mapping[seq], and only then starts streaming.  nullptr = q is rotated, the row is in the cache.
+  const void* k_new = nullptr;       // [num_seqs, kn_stride] un-rotated k of this step's token
+  const void* v_new = nullptr;
+  const int64_t* positions = nullptr;      // [num_seqs]
+  const int64_t* slot_mapping = nullptr;   // [num_seqs], < 0 = no write
+  const float* cos_sin = nullptr;          // [max_position, head_dim] = cos | sin
+  int32_t max_position = 0;
+  int64_t kn_stride = 0, vn_stride = 0;
 };
 
 // paged_attn_decode_mfma.hip
 int launch_decode_mfma(const DecodeParams& p, int heads_per_wave, int head_dim, int dtype, bool nontemporal,
                        bool split_p, hipStream_t stream);
+// the same launch with RoPE + KV write inside (p.k_new etc. set); nontemporal + split-P form only
+int launch_decode_mfma_rope(const DecodeParams& p, int heads_per_wave, int head_dim, int dtype, hipStream_t stream);
 
 }  // namespace mi

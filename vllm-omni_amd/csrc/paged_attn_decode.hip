@@ -491,17 +491,24 @@ extern "C" int64_t mi_paged_attn_decode_workspace_bytes(int32_t num_seqs, int32_
   return MI_DECODE_COUNTER_BYTES + (int64_t)num_seqs * num_q_heads * parts * (head_dim + 2) * (int64_t)sizeof(float);
 }
 
-extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cache,
-                                    const void* v_cache, const int32_t* block_table,
-                                    const int32_t* seq_lens, int32_t num_seqs,
-                                    int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
-                                    int32_t block_size, int32_t block_table_stride,
-                                    int32_t max_seq_len, float scale, int64_t q_token_stride,
-                                    int64_t out_token_stride, int64_t cache_block_stride,
-                                    int64_t cache_token_stride, int64_t cache_head_stride,
-                                    int32_t partition_size, void* workspace,
-                                    int64_t workspace_bytes, int dtype, int out_dtype,
-                                    int32_t flags, void* stream) {
+namespace {
+// RoPE + KV write of the step's token inside the launch (mi_rope_cache_paged_attn_decode)
+struct RopeFusion {
+  const void* k;
+  const void* v;
+  const int64_t* positions;
+  const int64_t* slot_mapping;
+  const float* cos_sin;
+  int32_t max_position;
+  int64_t k_stride, v_stride;
+};
+
+int decode_call(void* out, const void* q, const void* k_cache, const void* v_cache, const int32_t* block_table,
+                const int32_t* seq_lens, int32_t num_seqs, int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                int32_t block_size, int32_t block_table_stride, int32_t max_seq_len, float scale, int64_t q_token_stride,
+                int64_t out_token_stride, int64_t cache_block_stride, int64_t cache_token_stride,
+                int64_t cache_head_stride, int32_t partition_size, void* workspace, int64_t workspace_bytes, int dtype,
+                int out_dtype, int32_t flags, void* stream, const RopeFusion* rope) {
   using namespace mi;
   if (num_seqs == 0) return MI_OK;
   if (!out || !q || !k_cache || !v_cache || !block_table || !seq_lens) return MI_ERR_INVALID_ARG;
@@ -575,7 +582,15 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   // fp32-P VALU kernel, so every production launch is inside the rtol 1e-3 / atol 1e-4 bound.
   const bool packed = (flags & MI_DECODE_PACKED_PV) && (flags & MI_DECODE_FORCE_VALU);
   int rc;
-  if (use_mfma) {
+  if (rope) {
+    // built for the production form only: matrix-core kernel, nt streams, P as a hi + lo pair
+    if (!use_mfma || !(flags & MI_DECODE_NONTEMPORAL) || (flags & MI_DECODE_ROUNDED_P)) return MI_ERR_UNSUPPORTED;
+    p.k_new = rope->k; p.v_new = rope->v;
+    p.positions = rope->positions; p.slot_mapping = rope->slot_mapping;
+    p.cos_sin = rope->cos_sin; p.max_position = rope->max_position;
+    p.kn_stride = rope->k_stride; p.vn_stride = rope->v_stride;
+    rc = launch_decode_mfma_rope(p, G, head_dim, dtype, s);
+  } else if (use_mfma) {
     rc = launch_decode_mfma(p, G, head_dim, dtype, (flags & MI_DECODE_NONTEMPORAL) != 0,
                             (flags & MI_DECODE_ROUNDED_P) == 0, s);
   } else if (dtype == MI_DTYPE_BF16) {
@@ -587,7 +602,50 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
   }
   if (rc != MI_OK) return rc;
   if (p.part_count) return MI_OK;   // merged inside the launch
+  if (flags & MI_DECODE_SKIP_MERGE) return MI_OK;   // measurement of the attention kernel alone
   if (dtype == MI_DTYPE_BF16)
     return head_dim == 128 ? launch_reduce<bf16_tag, 128>(p, s) : launch_reduce<bf16_tag, 64>(p, s);
   return head_dim == 128 ? launch_reduce<f16_tag, 128>(p, s) : launch_reduce<f16_tag, 64>(p, s);
+}
+}  // namespace
+
+extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cache,
+                                    const void* v_cache, const int32_t* block_table,
+                                    const int32_t* seq_lens, int32_t num_seqs,
+                                    int32_t num_q_heads, int32_t num_kv_heads, int32_t head_dim,
+                                    int32_t block_size, int32_t block_table_stride,
+                                    int32_t max_seq_len, float scale, int64_t q_token_stride,
+                                    int64_t out_token_stride, int64_t cache_block_stride,
+                                    int64_t cache_token_stride, int64_t cache_head_stride,
+                                    int32_t partition_size, void* workspace,
+                                    int64_t workspace_bytes, int dtype, int out_dtype,
+                                    int32_t flags, void* stream) {
+  return decode_call(out, q, k_cache, v_cache, block_table, seq_lens, num_seqs, num_q_heads, num_kv_heads, head_dim,
+                     block_size, block_table_stride, max_seq_len, scale, q_token_stride, out_token_stride,
+                     cache_block_stride, cache_token_stride, cache_head_stride, partition_size, workspace,
+                     workspace_bytes, dtype, out_dtype, flags, stream, nullptr);
+}
+
+extern "C" int mi_rope_cache_paged_attn_decode(void* out, const void* q, const void* k, const void* v,
+                                               const int64_t* positions, const float* cos_sin_cache,
+                                               int32_t max_position, int32_t rot_dim, void* k_cache, void* v_cache,
+                                               const int64_t* slot_mapping, const int32_t* block_table,
+                                               const int32_t* seq_lens, int32_t num_seqs, int32_t num_q_heads,
+                                               int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                                               int32_t block_table_stride, int32_t max_seq_len, float scale,
+                                               int64_t q_token_stride, int64_t k_token_stride, int64_t v_token_stride,
+                                               int64_t out_token_stride, int64_t cache_block_stride,
+                                               int64_t cache_token_stride, int64_t cache_head_stride,
+                                               int32_t partition_size, void* workspace, int64_t workspace_bytes,
+                                               int dtype, int out_dtype, int32_t flags, void* stream) {
+  if (num_seqs == 0) return MI_OK;
+  if (!k || !v || !positions || !cos_sin_cache || !slot_mapping || max_position <= 0) return MI_ERR_INVALID_ARG;
+  if (rot_dim != head_dim) return MI_ERR_UNSUPPORTED;   // partial rotary: use the two launches
+  if (k_token_stride % 8 || v_token_stride % 8 || (((uintptr_t)k | (uintptr_t)v | (uintptr_t)cos_sin_cache) & 15))
+    return MI_ERR_INVALID_ARG;
+  const RopeFusion rf{k, v, positions, slot_mapping, cos_sin_cache, max_position, k_token_stride, v_token_stride};
+  return decode_call(out, q, k_cache, v_cache, block_table, seq_lens, num_seqs, num_q_heads, num_kv_heads, head_dim,
+                     block_size, block_table_stride, max_seq_len, scale, q_token_stride, out_token_stride,
+                     cache_block_stride, cache_token_stride, cache_head_stride, partition_size, workspace,
+                     workspace_bytes, dtype, out_dtype, flags, stream, &rf);
 }

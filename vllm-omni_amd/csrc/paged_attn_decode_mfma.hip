@@ -41,8 +41,15 @@
 #include "decode_params.h"
 #include "mfma_attn_common.h"
 
+#ifndef MI_DECODE_NS64
+#define MI_DECODE_NS64 2   // ring stages at head_dim 64: a stage is half the bytes of head_dim 128's, yet four stages measured
+                           // level with two there as well (162.5 / 163.1 us at 512 x 2 heads x ctx 4096, 54.7 / 56.6 at 128)
+#endif
+
 namespace mi {
 namespace {
+
+__device__ __forceinline__ int64_t bs_mask_of(int bs_log2) { return ((int64_t)1 << bs_log2) - 1; }
 
 // AUX = cache-policy bits of the DMA loads (0 = default, 2 = nt: K/V bytes are read exactly once).
 // 16- / 8-byte stores with device (agent) coherence: sc1 = write through to the point the other XCDs' loads see
@@ -58,7 +65,39 @@ __device__ __forceinline__ void store_agent_b64(float* p, f32x2_t v) {
 // shard shapes, small batches on long contexts) on the theory that a wave's own stream rate limits them — measured, it
 // is never ahead: 47.6 against 46.7 us at B 32 / ctx 4096 (512 waves), 94 against 88 at 256 x 7/1 heads, 338 against
 // 316 at the headline (profiles/r03g_decode_stages.log).  Only NS = 2 is instantiated.
-template <typename Tag, int HD, int AUX, bool SPLIT, int NS>
+// 8 consecutive 16-bit values <-> fp32 (the rotate-item of csrc/cache_rope.hip)
+template <typename Tag>
+__device__ __forceinline__ void unpack8(const uint4& r, float (&f)[8]) {
+  using E = Elem<Tag>;
+  f[0] = E::lo(r.x); f[1] = E::hi(r.x); f[2] = E::lo(r.y); f[3] = E::hi(r.y);
+  f[4] = E::lo(r.z); f[5] = E::hi(r.z); f[6] = E::lo(r.w); f[7] = E::hi(r.w);
+}
+template <typename Tag>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  using E = Elem<Tag>;
+  return make_uint4(E::pack(f[0], f[1]), E::pack(f[2], f[3]), E::pack(f[4], f[5]), E::pack(f[6], f[7]));
+}
+// neox rotation of dims [j0, j0 + 8) (x) and [half + j0, half + j0 + 8) (y) with the fp32 table row of the position:
+// rope_cache_kernel's arithmetic, expression for expression (tests/test_gpu_attention_decode.py checks the bits)
+template <typename Tag>
+__device__ __forceinline__ void rope_rotate8(uint4& xr, uint4& yr, const float* row, int j0, int half) {
+  float x[8], y[8], ox[8], oy[8];
+  unpack8<Tag>(xr, x);
+  unpack8<Tag>(yr, y);
+  const float4 c0 = *reinterpret_cast<const float4*>(row + j0), c1 = *reinterpret_cast<const float4*>(row + j0 + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(row + half + j0), s1 = *reinterpret_cast<const float4*>(row + half + j0 + 4);
+  const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ox[e] = x[e] * cs[e] - y[e] * sn[e];
+    oy[e] = y[e] * cs[e] + x[e] * sn[e];
+  }
+  xr = pack8<Tag>(ox);
+  yr = pack8<Tag>(oy);
+}
+
+template <typename Tag, int HD, int AUX, bool SPLIT, int NS, bool ROPE = false>
 __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p, const int gh) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -132,6 +171,40 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
 #pragma unroll
     for (int s = 0; s < KS; ++s)
       qf[s] = head_ok ? *reinterpret_cast<const uint4*>(qb + 32 * s) : make_uint4(0, 0, 0, 0);
+  }
+  if constexpr (ROPE) {
+    // ---- RoPE + KV write of this step's token (A4 + A7 inside the attention launch) ---------------------------
+    int64_t pos = p.positions[seq];
+    pos = pos < 0 ? 0 : (pos >= p.max_position ? (int64_t)p.max_position - 1 : pos);
+    const float* const row = p.cos_sin + pos * HD;   // rot_dim == head_dim
+    // q: dims 32 s + 8 g .. of head h pair with dims + HD / 2 = fragment s + KS / 2 of the same lane
+#pragma unroll
+    for (int s = 0; s < KS / 2; ++s) rope_rotate8<Tag>(qf[s], qf[s + KS / 2], row, 32 * s + 8 * g, HD / 2);
+    // k, v: the wave whose partition ends at the sequence's last token, once per KV head
+    if (t_end == steps_total && qh0 % p.kv_group == 0) {   // wave-uniform
+      const int64_t slot = p.slot_mapping[seq];
+      if (slot >= 0) {
+        const int64_t crow = (slot >> p.bs_log2) * p.blk_stride + (slot & bs_mask_of(p.bs_log2)) * p.tok_stride +
+                             (int64_t)kvh * p.head_stride;
+        constexpr int RI = HD / 16;   // rotate-items of one k head: lane j < RI = dims [8 j, 8 j + 8) and their partners
+        if (lane < RI) {
+          const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new) + (int64_t)seq * p.kn_stride + kvh * HD;
+          uint4 x = *reinterpret_cast<const uint4*>(kn + 8 * lane), y = *reinterpret_cast<const uint4*>(kn + HD / 2 + 8 * lane);
+          rope_rotate8<Tag>(x, y, row, 8 * lane, HD / 2);
+          uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k_cache)) + crow;
+          *reinterpret_cast<uint4*>(kc + 8 * lane) = x;
+          *reinterpret_cast<uint4*>(kc + HD / 2 + 8 * lane) = y;
+        } else if (lane < RI + HD / 8) {
+          const int j = lane - RI;
+          const uint16_t* vn = reinterpret_cast<const uint16_t*>(p.v_new) + (int64_t)seq * p.vn_stride + kvh * HD;
+          uint16_t* vc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.v_cache)) + crow;
+          *reinterpret_cast<uint4*>(vc + 8 * j) = *reinterpret_cast<const uint4*>(vn + 8 * j);
+        }
+      }
+      // the row's stores have been acknowledged before this wave's DMA (the only reader of that row in this launch,
+      // on this CU) can fetch it
+      wait_vmcnt<0>();
+    }
   }
 
   // ---- per-lane constants -------------------------------------------------------------
@@ -484,10 +557,6 @@ int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, b
     }                                                                                                       \
   } while (0)
 #define MI_LAUNCH(TAG, HDIM) MI_LAUNCH_NS(TAG, HDIM, 2)
-#ifndef MI_DECODE_NS64
-#define MI_DECODE_NS64 2   // ring stages at head_dim 64: a stage is half the bytes of head_dim 128's, yet four stages measured
-                           // level with two there as well (162.5 / 163.1 us at 512 x 2 heads x ctx 4096, 54.7 / 56.6 at 128)
-#endif
   if (dtype == MI_DTYPE_BF16) {
     if (head_dim == 128) MI_LAUNCH(bf16_tag, 128); else MI_LAUNCH_NS(bf16_tag, 64, MI_DECODE_NS64);
   } else {
@@ -495,6 +564,20 @@ int launch_decode_mfma(const DecodeParams& p, int gh, int head_dim, int dtype, b
   }
 #undef MI_LAUNCH
 #undef MI_LAUNCH_NS
+  return launch_status();
+}
+
+int launch_decode_mfma_rope(const DecodeParams& p, int gh, int head_dim, int dtype, hipStream_t stream) {
+  const int64_t waves = (int64_t)p.num_seqs * (p.num_q_heads / gh) * p.num_parts;
+  if (waves > INT32_MAX) return MI_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)waves), block(64);
+  if (dtype == MI_DTYPE_BF16) {
+    if (head_dim == 128) hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 128, 2, true, 2, true>), grid, block, 0, stream, p, gh);
+    else hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 64, 2, true, MI_DECODE_NS64, true>), grid, block, 0, stream, p, gh);
+  } else {
+    if (head_dim == 128) hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 128, 2, true, 2, true>), grid, block, 0, stream, p, gh);
+    else hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 64, 2, true, MI_DECODE_NS64, true>), grid, block, 0, stream, p, gh);
+  }
   return launch_status();
 }
 

@@ -24,6 +24,7 @@ MI_DECODE_FORCE_VALU = 2
 MI_DECODE_NONTEMPORAL = 4
 MI_DECODE_ROUNDED_P = 8
 MI_DECODE_FUSED_MERGE = 16
+MI_DECODE_SKIP_MERGE = 32
 MI_DECODE_COUNTER_BYTES = 1 << 20
 MI_ALLREDUCE_MAX_RANKS, MI_ALLREDUCE_HANDLE_BYTES = 8, 64
 
@@ -55,6 +56,10 @@ SIGNATURES = {
                                       c_int32, c_int32, c_int32, c_float, c_int64, c_int64,
                                       c_int64, c_int64, c_int64, c_int32, _P, c_int64, c_int,
                                       c_int, c_int32, _P]),
+    "mi_rope_cache_paged_attn_decode": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32,
+                                                 c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int64, c_int64,
+                                                 c_int64, c_int64, c_int64, c_int64, c_int64, c_int32, _P, c_int64, c_int,
+                                                 c_int, c_int32, _P]),
     "mi_paged_attn_prefill": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                                        c_int64, c_int64, c_int64, c_int64, c_int64, c_int, _P]),

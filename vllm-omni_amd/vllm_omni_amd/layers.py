@@ -246,6 +246,18 @@ class Attention:
 
     __call__ = forward
 
+    def rope_decode_fusable(self, rope: RotaryEmbedding, positions: torch.Tensor, q_norm_weight=None) -> bool:
+        """Whether this step's RoPE + KV write run inside the paged-attention launch (``ops.rope_cache_paged_attn_decode``):
+        a pure-decode step on the production decode kernel, plain positions, no q/k-norm, not a single-block sequence
+        (those have their own fused launch).  qkv_proj then hands over a 16-bit row, not split-K partials."""
+        md = get_forward_context().attn_metadata
+        if md is None or md.single_block or q_norm_weight is not None or positions.dim() != 1:
+            return False
+        nd = md.num_decodes
+        return (nd > 0 and nd == md.num_reqs and md.num_actual_tokens == nd
+                and ops.rope_decode_fusable(None, self._kb, positions, rope.cos_sin_cache.shape[1],
+                                            md.decode_partition_size, nd, md.max_seq_len))
+
     def forward_fused_rope(self, rope: RotaryEmbedding, positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
                            v: torch.Tensor, q_norm_weight=None, k_norm_weight=None, norm_eps: float = 1e-6,
                            output: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -266,6 +278,14 @@ class Attention:
             ops.rope_neox_and_cache(q, k, None, positions, rope.cos_sin_cache, self.head_size, mrope_section=sec,
                                     q_norm_weight=q_norm_weight, k_norm_weight=k_norm_weight, norm_eps=norm_eps)
             return out.zero_()
+        nd = md.num_decodes
+        if self.rope_decode_fusable(rope, positions, q_norm_weight):
+            # pure decode: RoPE + KV write ride in the attention launch (same bits, one launch less per layer)
+            ops.rope_cache_paged_attn_decode(out[:nd], q[:nd], k[:nd], v[:nd], positions[:nd], rope.cos_sin_cache, self._kb,
+                                             self._vb, md.slot_mapping[:nd], md.block_table[:nd], md.seq_lens[:nd],
+                                             md.max_seq_len, self.scale, partition_size=md.decode_partition_size,
+                                             workspace=md.decode_workspace)
+            return out
         ops.rope_neox_and_cache(q, k, v, positions, rope.cos_sin_cache, self.head_size, self._kb, self._vb,
                                 md.slot_mapping, mrope_section=sec, q_norm_weight=q_norm_weight,
                                 k_norm_weight=k_norm_weight, norm_eps=norm_eps)

@@ -263,6 +263,8 @@ def new_decode_workspace(nbytes: int, device) -> torch.Tensor:
 # store-acknowledge wait and an atomic round trip while it still holds its LDS slot (5 waves per CU), which costs more
 # streaming time than the 5-7 us merge launch it saves.  Kept (bit-identical, tested) for shapes with few, long waves.
 DECODE_FUSED_MERGE = os.environ.get("VLLM_OMNI_AMD_DECODE_FUSED_MERGE", "0") == "1"
+# RoPE + KV write of a pure-decode step inside the attention launch (rope_cache_paged_attn_decode); "0": two launches (A/B)
+ROPE_DECODE_FUSION = os.environ.get("VLLM_OMNI_AMD_ROPE_DECODE_FUSION", "1") != "0"
 
 
 def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
@@ -270,7 +272,7 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
                       partition_size: int = 0, workspace: Optional[torch.Tensor] = None,
                       packed_pv: Optional[bool] = None, force_valu: bool = False,
                       nontemporal: Optional[bool] = None, rounded_p: bool = False,
-                      fused_merge: Optional[bool] = None) -> torch.Tensor:
+                      fused_merge: Optional[bool] = None, _skip_merge: bool = False) -> torch.Tensor:
     """out[s, h] = softmax(q[s,h] . K^T * scale) . V over the paged cache (one query per sequence).
 
     q, out: [S, nq*d] (or [S, nq, d]); block_table int32 [S, max_blocks]; seq_lens int32 [S].
@@ -313,8 +315,57 @@ def paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor,
         | (_C.MI_DECODE_FORCE_VALU if force_valu else 0)
         | (_C.MI_DECODE_ROUNDED_P if rounded_p else 0)
         | (_C.MI_DECODE_FUSED_MERGE if fused_merge else 0)
+        | (_C.MI_DECODE_SKIP_MERGE if _skip_merge else 0)   # bench.py's kernel-only timing; never set by the product
         | (_C.MI_DECODE_NONTEMPORAL if (DECODE_NONTEMPORAL if nontemporal is None else nontemporal) else 0),
         _stream()))
+    return out
+
+
+def rope_decode_fusable(q: torch.Tensor, k_cache: torch.Tensor, positions: torch.Tensor, rot_dim: int,
+                        partition_size: int, num_seqs: int, max_seq_len: int) -> bool:
+    """Whether ``rope_cache_paged_attn_decode`` covers this call: the production decode kernel (matrix cores, nt
+    streams, hi + lo P), full rotary, 1-D positions."""
+    nb, bs, hkv, d = k_cache.shape
+    if not (DECODE_PACKED_PV and DECODE_NONTEMPORAL and ROPE_DECODE_FUSION) or positions.dim() != 1 or rot_dim != d or bs < 16:
+        return False
+    ps = decode_auto_partition(num_seqs, hkv, max_seq_len, bs, partition_size, None, False, head_dim=d)
+    return ps % 32 == 0
+
+
+def rope_cache_paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                                 positions: torch.Tensor, cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
+                                 v_cache: torch.Tensor, slot_mapping: torch.Tensor, block_table: torch.Tensor,
+                                 seq_lens: torch.Tensor, max_seq_len: int, scale: float, partition_size: int = 0,
+                                 workspace: Optional[torch.Tensor] = None, _skip_merge: bool = False) -> torch.Tensor:
+    """``rope_neox_and_cache`` + ``paged_attn_decode`` of a pure-decode step in ONE launch (same bits): q is rotated in
+    registers (the tensor keeps its un-rotated values), the token's rotated k and its v are written to the cache by the
+    wave that owns the sequence's last context partition.  q [S, nq*d], k / v [S, nkv*d]: views of the qkv row."""
+    _gpu(out, q, k, v, positions, cos_sin_cache, k_cache, v_cache, slot_mapping, block_table, seq_lens, workspace)
+    nb, bs, hkv, d = k_cache.shape
+    s = q.shape[0]
+    if s == 0:
+        return out
+    nq = q.numel() // (s * d)
+    if block_table.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise TypeError("block_table and seq_lens must be int32")
+    if positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64 or cos_sin_cache.dtype != torch.float32:
+        raise TypeError("positions / slot_mapping must be int64 and cos_sin_cache float32")
+    if positions.dim() != 1 or block_table.stride(1) != 1:
+        raise ValueError("1-D positions and contiguous block_table rows required")
+    max_pos, rot_dim = cos_sin_cache.shape
+    cb, ct, ch = _cache_strides(k_cache, v_cache)
+    partition_size = decode_auto_partition(s, hkv, max_seq_len, bs, partition_size, None, False, head_dim=d)
+    need = decode_workspace_bytes(s, nq, d, max_seq_len, partition_size)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = new_decode_workspace(need, q.device)
+    fused_merge = DECODE_FUSED_MERGE and _decode_ws_ready(workspace)
+    check("mi_rope_cache_paged_attn_decode", lib.mi_rope_cache_paged_attn_decode(
+        _p(out), _p(q), _p(k), _p(v), _p(positions), _p(cos_sin_cache), max_pos, rot_dim, _p(k_cache), _p(v_cache),
+        _p(slot_mapping), _p(block_table), _p(seq_lens), s, nq, hkv, d, bs, block_table.stride(0), int(max_seq_len),
+        float(scale), q.stride(0), k.stride(0), v.stride(0), out.stride(0), cb, ct, ch, int(partition_size), _p(workspace),
+        workspace.numel() * workspace.element_size() if workspace is not None else 0, _dt(q.dtype), _dt(out.dtype),
+        _C.MI_DECODE_PACKED_PV | _C.MI_DECODE_NONTEMPORAL | (_C.MI_DECODE_FUSED_MERGE if fused_merge else 0)
+        | (_C.MI_DECODE_SKIP_MERGE if _skip_merge else 0), _stream()))
     return out
 
 

@@ -160,7 +160,11 @@ class Qwen2Attention:
 
     def __call__(self, positions: torch.Tensor, hidden_states: torch.Tensor, defer_reduce: bool = False):
         has_cache = get_forward_context().attn_metadata is not None
-        qkv, _ = self.qkv_proj(hidden_states, "rope" if has_cache else False)
+        # split-K partials go into the RoPE + KV-write launch — unless that launch itself disappears into the attention
+        # kernel (pure decode steps): then qkv_proj writes its 16-bit row
+        fused = has_cache and self.attn.rope_decode_fusable(self.rotary_pos_emb, positions,
+                                                             self.q_norm.weight if self.q_norm else None)
+        qkv, _ = self.qkv_proj(hidden_states, "rope" if has_cache and not fused else False)
         if isinstance(qkv, ops.SplitKPartials):   # split-K reduce + bias inside the RoPE + KV-write launch (layers.py)
             attn_output = self.attn.forward_fused_rope_partials(
                 self.rotary_pos_emb, positions, qkv,
