@@ -507,6 +507,16 @@ int64_t mi_linear_workspace_bytes(int32_t m, int32_t n, int32_t k);
 int mi_linear(void* out, const void* x, const void* weight, const void* bias, int32_t m, int32_t n,
               int32_t k, int64_t x_row_stride, int64_t out_row_stride, void* workspace,
               int64_t workspace_bytes, int dtype, void* stream);
+/* mi_linear with its split-K reduce INSIDE the launch (round 4): every slice writes its fp32 slab through to the
+ * coherence point, and the slice of a (tile, row block) that arrives last — told by the value its one counter add
+ * returned — sums the slabs in slice order (+ bias, one rounding): the bits of mi_linear, one launch fewer.  `counters`:
+ * MI_LINEAR_COUNTER_BYTES of int32, zero before the FIRST launch; every launch leaves them zero (hipGraph replays need
+ * nothing in between).  Plans without a split, with more than 8 slices or on the 256-row kernel run as mi_linear. */
+#define MI_LINEAR_COUNTER_BYTES (16 << 10)
+int mi_linear_fused_reduce(void* out, const void* x, const void* weight, const void* bias, int32_t m,
+                           int32_t n, int32_t k, int64_t x_row_stride, int64_t out_row_stride,
+                           void* workspace, int64_t workspace_bytes, void* counters,
+                           int64_t counters_bytes, int dtype, void* stream);
 /* The two halves of a split-K mi_linear, for callers that fold the reduction
  * into the next kernel: mi_linear_partials runs the streaming kernel only and
  * leaves fp32 partials [split][m][n] in `workspace` (*split_out = split >= 2;

@@ -390,3 +390,45 @@ def test_tuned_table_routes_the_shard_shapes(plan_registry, monkeypatch):
     yd, _ = dn(xa)
     assert calls["linear"] == 1
     assert (yd.double() - xa.double() @ dn.weight.double().t()).abs().max().item() < 0.05
+
+
+@pytest.mark.parametrize("rows,wrows,split", [(64, 96, 3), (64, 128, 8), (128, 64, 4), (64, 32, 2), (128, 128, 6), (64, 256, 2)])
+def test_in_launch_splitk_reduce_equals_the_reduce_launch_bit_for_bit(plan_registry, monkeypatch, rows, wrows, split):
+    """mi_linear_fused_reduce: the last-arriving slice of a (tile, row block) sums the slabs — same slice order, same
+    rounding as the separate reduce launch — over repeated launches on one workspace (the counters must come back to
+    zero), ragged rows, a tile that hangs over n, with bias, and replayed from a hipGraph."""
+    from vllm_omni_amd import ops
+    _C = plan_registry
+    g = torch.Generator(device="cuda").manual_seed(rows + wrows + split)
+    for m, n, k in [(128, 3584, 4736), (100, 1152, 3584), (256, 3584, 896), (37, 208, 1024)]:
+        assert _C.lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 0, 512, n, k, rows, wrows, split) == _C.MI_OK
+        x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+        b = torch.randn(n, device="cuda", generator=g).to(torch.bfloat16)
+        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", False)
+        two = ops.linear(x, w, b)
+        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", True)
+        for _ in range(3):
+            one = ops.linear(x, w, b)
+            assert torch.equal(one, two), (m, n, k)
+        assert int(ops._LINEAR_CNT[x.device].abs().sum()) == 0
+    # replayed from a graph, inputs changing between replays
+    m, n, k = 128, 3584, 4736
+    x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ops.linear(x, w)
+    torch.cuda.current_stream().wait_stream(st)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = ops.linear(x, w)
+    for _ in range(3):
+        x.copy_(torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16))
+        graph.replay()
+        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", False)
+        ref = ops.linear(x, w)
+        monkeypatch.setattr(ops, "LINEAR_FUSED_REDUCE", True)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)

@@ -41,9 +41,17 @@ def main():
                 t = timed(lambda: (ops.linear_partials(x, nxt(), None) or ops.linear(x, nxt())))
             out.append(t)
         os.environ.pop("MI_LINEAR_DBG")
+        extra = ""
+        if not gated:
+            res = []
+            for fr in (False, True):
+                ops.LINEAR_FUSED_REDUCE = fr
+                res.append(timed(lambda: ops.linear(x, nxt())))
+            ops.LINEAR_FUSED_REDUCE = True
+            extra = f" || with its reduce: separate launch {res[0]:6.1f} us, inside the launch {res[1]:6.1f} us"
         os.environ.pop("MI_GATED_PLAN" if gated else "MI_LINEAR_PLAN")
         print(f"{name:8s} m={m} plan {plan:8s}: whole {out[0]:6.1f} us | DMA ring only {out[1]:6.1f} | consumers only {out[2]:6.1f} "
-              f"| no output stores {out[3]:6.1f} | neither (launch + barriers) {out[4]:6.1f}", flush=True)
+              f"| no output stores {out[3]:6.1f} | neither (launch + barriers) {out[4]:6.1f}{extra}", flush=True)
 
 
 if __name__ == "__main__":

@@ -78,6 +78,9 @@ struct SkinnyParams {
   const float* ws;        // int8 operands: per-output-channel weight scales [N] (GATED: [2 N], gate then up)
   int32_t M, N, K, S;     // GATED: N = output columns I; the weight has 2 I rows (gate rows, then up rows)
   int32_t RB, U;          // first-generation kernel, not GROUPED: row blocks of 16 MT rows; U = tiles x S work items per row block
+  // S > 1 with the reduce INSIDE the launch (mi_linear_fused_reduce): arrival counters [tiles x RB], zero before the
+  // first launch and left at zero by every launch; the slice of a (tile, row block) that arrives last sums the slabs
+  int32_t* cnt = nullptr;
   // GROUPED (sparse-MoE expert GEMMs, fused_moe.hip): grid.y = one tile of `rpt` token rows that share one expert
   const int32_t* row_map;      // [max_rows] pair index per row or -1
   const int32_t* tile_expert;  // [max_tiles]
@@ -116,6 +119,17 @@ __device__ __forceinline__ void finish_quad(const SkinnyParams& p, const typenam
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = a[r] + bv[r];
   }
+}
+
+constexpr int kAuxAgent = 16;   // buffer load / store aux: sc1 = device (agent) coherence, write-through stores
+
+__device__ __forceinline__ u32x4_t lds_poll128(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_store32(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ int kperm(int u, int kg) {
@@ -282,6 +296,12 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
       if (it + AHEAD < n_it && !(p.dbg & 1)) issue(it + AHEAD, stage);
       stage = stage == NST - 1 ? 0 : stage + 1;
     }
+    if constexpr (!GATED && !GROUPED) {
+      if (p.S > 1 && p.cnt) {   // the consumers' in-launch reduce meets twice more (see the epilogue)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
     return;
   }
 
@@ -355,6 +375,9 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
     return;
   }
   // D[n][m]: lane = column m (row r16 of m-tile j), rows n = 4 kg + r of the row group
+  const bool fused_reduce = !GATED && !GROUPED && p.S > 1 && p.cnt != nullptr;
+  const __amdgpu_buffer_rsrc_t part_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.part, 0, fused_reduce ? (int)((int64_t)p.S * p.M * p.N * 4) : 0, 0x00020000);
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int n = n_base + 16 * g + 4 * kg;
@@ -376,9 +399,88 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
         q.x = E::pack(v[0], v[1]);
         q.y = E::pack(v[2], v[3]);
         *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = q;
+      } else if (fused_reduce) {   // written through to the coherence point (sc1): no L2 write-back needed to publish
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[g][j]), part_rsrc,
+                                               (int)((((int64_t)s * p.M + m) * p.N + n) * 4), 0, kAuxAgent);
       } else {   // fp32 sums, or the exact int32 sums of int8 operands (same 16 bytes)
         *reinterpret_cast<acc_t*>(p.part + ((int64_t)s * p.M + m) * p.N + n) = acc[g][j];
       }
+    }
+  }
+  if constexpr (!GATED && !GROUPED && std::is_same_v<acc_t, f32x4_t>) {
+    if (!fused_reduce) return;
+    // ---- split-K reduce inside the launch: the slice of this (tile, row block) that arrives LAST sums the slabs ------
+    // Publish: every wave's slab stores are write-through and complete (vmcnt(0)) before the workgroup's one counter
+    // add; acquire: the last arriver reads the slabs with sc1 loads issued after its add has returned
+    // (MI355X_MICROARCH.md, valid hand-off forms; the decode kernel's in-launch merge uses the same pair).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint32_t flag = (uint32_t)(uintptr_t)(lds_void*)smem;   // the ring is dead: every read retired, no DMA in flight
+    if (wid == 0) {
+      int32_t* c = p.cnt + (tile * p.RB + m0 / (16 * MT));
+      int old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      const bool last = old == p.S - 1;
+      if (last && lane == 0) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      if (lane == 0) lds_store32(flag, last ? 1u : 0u);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (lds_poll128(flag)[0] == 0u) return;
+    // slab loads of `JB` m-tiles x both row groups x all slices in flight at once, then summed in slice order
+    // (skinny_reduce_kernel's arithmetic: the same bits as the separate reduce launch)
+    auto reduce_batch = [&](auto jb_c, auto smax_c, int j0) {
+      constexpr int JB = decltype(jb_c)::value, SM = decltype(smax_c)::value;
+      f32x4_t v[2][JB][SM];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int n = n_base + 16 * g + 4 * kg;
+        const int nn = n < p.N ? n : 0;
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const int m = m0 + 16 * (mh * MTW + j0 + jj) + r16;
+          const int mm = m < p.M ? m : p.M - 1;
+#pragma unroll
+          for (int sl = 0; sl < SM; ++sl)
+            if (sl < p.S)
+              v[g][jj][sl] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                  part_rsrc, (int)((((int64_t)sl * p.M + mm) * p.N + nn) * 4), 0, kAuxAgent));
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int n = n_base + 16 * g + 4 * kg;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = E::from_bits(p.bias[n + r]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+          const int m = m0 + 16 * (mh * MTW + j0 + jj) + r16;
+          if (m >= p.M) continue;
+          f32x4_t a = v[g][jj][0];
+#pragma unroll
+          for (int sl = 1; sl < SM; ++sl)
+            if (sl < p.S) a += v[g][jj][sl];
+          uint2 q;
+          q.x = E::pack(a[0] + bv[0], a[1] + bv[1]);
+          q.y = E::pack(a[2] + bv[2], a[3] + bv[3]);
+          *reinterpret_cast<uint2*>(p.out + (int64_t)m * p.ldo + n) = q;
+        }
+      }
+    };
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>;
+    if (p.S <= 4) {   // one round trip: 8 m-tile x group quads x <= 4 slices = 128 registers
+#pragma unroll
+      for (int j0 = 0; j0 < MTW; j0 += 4) reduce_batch(I4{}, I4{}, j0);
+    } else {
+#pragma unroll
+      for (int j0 = 0; j0 < MTW; j0 += 2) reduce_batch(I2{}, I8{}, j0);
     }
   }
 }
@@ -401,15 +503,6 @@ __global__ __launch_bounds__(64 * (NSLAB * MH + NL)) void skinny_gemm_kernel(con
 //     (MI355X_MICROARCH.md, price list row ring-gemm).  Spins are bounded.
 constexpr int kV2Loaders = 4, kV2Consumers = 8;
 constexpr uint32_t kSpinBound = 1u << 24;
-
-__device__ __forceinline__ u32x4_t lds_poll128(uint32_t addr) {
-  u32x4_t v;
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_store32(uint32_t addr, uint32_t v) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
 
 // NW weight fragments (one per 16-row group) + the 4 m-tile fragments of one k-step, and their wait, in ONE statement
 template <int NW>
@@ -1069,6 +1162,43 @@ extern "C" int mi_linear(void* out, const void* x, const void* weight, const voi
       hipLaunchKernelGGL((skinny_reduce_kernel<f16_tag>), rgrid, dim3(256), 0, s, o, p.part, b, m, n, pl.split, out_row_stride);
   }
   return launch_status();
+}
+
+// mi_linear with the split-K reduce inside the launch (first-generation kernel, <= 8 slices): the slice of a (tile, row
+// block) that arrives last sums the slabs in slice order — the bits of mi_linear, one launch less.  `counters`: >=
+// MI_LINEAR_COUNTER_BYTES of int32, zero before the first launch (every launch leaves them zero).
+extern "C" int mi_linear_fused_reduce(void* out, const void* x, const void* weight, const void* bias, int32_t m, int32_t n,
+                                      int32_t k, int64_t x_row_stride, int64_t out_row_stride, void* workspace,
+                                      int64_t workspace_bytes, void* counters, int64_t counters_bytes, int dtype,
+                                      void* stream) {
+  using namespace mi;
+  if (m == 0 || n == 0) return MI_OK;
+  if (!out || !x || !weight || m < 0 || n < 0 || k <= 0) return MI_ERR_INVALID_ARG;
+  if (m > 512 || k % 64 || n % 16 || x_row_stride % 8 || out_row_stride % 4) return MI_ERR_UNSUPPORTED;
+  if ((int64_t)m * x_row_stride * 2 >= ((int64_t)1 << 31)) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)weight) & 15 || ((uintptr_t)out & 7)) return MI_ERR_INVALID_ARG;
+  const SkinnyPlan pl = linear_plan(m, n, k);
+  const int rb = (m + 16 * pl.mt - 1) / (16 * pl.mt);
+  const bool in_launch = pl.split > 1 && pl.split <= 8 && !(pl.mt == 16 && pl.nslab >= 4 && linear_v2()) && !linear_dbg() &&
+                         (int64_t)pl.split * m * n * 4 < ((int64_t)1 << 31);
+  if (!in_launch)   // no split, or a plan the in-launch reduce is not built for: the two launches
+    return mi_linear(out, x, weight, bias, m, n, k, x_row_stride, out_row_stride, workspace, workspace_bytes, dtype, stream);
+  if (!workspace || ((uintptr_t)workspace & 15) || !counters || ((uintptr_t)counters & 3)) return MI_ERR_INVALID_ARG;
+  if (workspace_bytes < (int64_t)pl.split * m * n * (int64_t)sizeof(float)) return MI_ERR_WORKSPACE;
+  if (counters_bytes < MI_LINEAR_COUNTER_BYTES || (int64_t)pl.tiles * rb * 4 > MI_LINEAR_COUNTER_BYTES) return MI_ERR_WORKSPACE;
+  SkinnyParams p;
+  p.x = reinterpret_cast<const uint16_t*>(x);
+  p.w = reinterpret_cast<const uint16_t*>(weight);
+  p.bias = reinterpret_cast<const uint16_t*>(bias);
+  p.out = reinterpret_cast<uint16_t*>(out);
+  p.part = reinterpret_cast<float*>(workspace);
+  p.xs = p.ws = nullptr;
+  p.M = m; p.N = n; p.K = k; p.S = pl.split;
+  p.dbg = 0;
+  p.ldx = x_row_stride;
+  p.ldo = out_row_stride;
+  p.cnt = reinterpret_cast<int32_t*>(counters);
+  return launch_skinny(p, pl, false, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int mi_linear_partials(const void* x, const void* weight, int32_t m, int32_t n, int32_t k,

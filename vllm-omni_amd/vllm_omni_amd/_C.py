@@ -19,6 +19,7 @@ MI_ERR_INVALID_ARG, MI_ERR_UNSUPPORTED, MI_ERR_WORKSPACE = -1, -2, -3
 MI_ERR_LAUNCH, MI_ERR_EXHAUSTED, MI_ERR_STATE = -4, -5, -6
 ABI_VERSION = 2
 MI_LINEAR_PLAN_FULL, MI_LINEAR_PLAN_PARTIALS, MI_LINEAR_PLAN_GATED = 0, 1, 2
+MI_LINEAR_COUNTER_BYTES = 16 << 10
 MI_DECODE_PACKED_PV = 1
 MI_DECODE_FORCE_VALU = 2
 MI_DECODE_NONTEMPORAL = 4
@@ -90,6 +91,8 @@ SIGNATURES = {
                                              c_int, _P]),
     "mi_linear_silu_mul": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int, _P]),
     "mi_linear": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, _P, c_int64, c_int, _P]),
+    "mi_linear_fused_reduce": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, _P, c_int64, _P, c_int64,
+                                        c_int, _P]),
     "mi_linear_plan_set": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "mi_linear_plan_clear": (None, []),
     "mi_linear_plan_get": (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_int32)]),

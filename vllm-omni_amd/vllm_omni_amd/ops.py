@@ -562,6 +562,12 @@ def int8_dequant(acc: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor
 
 
 _LINEAR_WS: dict = {}
+_LINEAR_CNT: dict = {}   # device -> zeroed arrival counters of the in-launch split-K reduce (every launch leaves them zero)
+# "1": split-K linears reduce inside their launch (mi_linear_fused_reduce: the last-arriving slice sums the slabs, same
+# bits).  Built, tested, and measured SLOWER than the separate reduce launch at the shard shapes (down_proj at 128 rows
+# x TP 4: 19.5 against 18.7 us; o_proj 11.1 / 10.7 — the last arriver's write-through, counter round trip and slab
+# re-read cost more than the ~3.8 us launch they replace: profiles/r04i_fused_reduce.log), so it is opt-in.
+LINEAR_FUSED_REDUCE = os.environ.get("VLLM_OMNI_AMD_LINEAR_FUSED_REDUCE", "0") == "1"
 _LINEAR_WS_RETIRED: list = []   # outgrown workspaces stay allocated: a captured hipGraph may still write to them
 
 
@@ -585,6 +591,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     out = torch.empty(m, n, dtype=x.dtype, device=x.device)
     need = lib.mi_linear_workspace_bytes(m, n, k)
     ws = _linear_workspace(x.device, need) if need else None
+    if need and LINEAR_FUSED_REDUCE:   # split-K: the reduce rides in the launch (last-arriving slice), same bits
+        cnt = _LINEAR_CNT.get(x.device)
+        if cnt is None:
+            cnt = _LINEAR_CNT[x.device] = torch.zeros(_C.MI_LINEAR_COUNTER_BYTES // 4, dtype=torch.int32, device=x.device)
+        check("mi_linear_fused_reduce", lib.mi_linear_fused_reduce(
+            _p(out), _p(x2), _p(weight), _p(bias), m, n, k, x2.stride(0), out.stride(0), _p(ws), ws.numel(), _p(cnt),
+            cnt.numel() * 4, _dt(x.dtype), _stream()))
+        return out.view(*x.shape[:-1], n)
     check("mi_linear", lib.mi_linear(_p(out), _p(x2), _p(weight), _p(bias), m, n, k, x2.stride(0), out.stride(0),
                                      _p(ws) if need else None, ws.numel() if need else 0, _dt(x.dtype), _stream()))
     return out.view(*x.shape[:-1], n)
