@@ -301,3 +301,93 @@ def test_random_workload_keeps_the_pool_consistent():
     for r in list(s.requests.values()):
         s.finish_requests(r.request_id, RequestStatus.FINISHED_ABORTED)
     assert pool.get_num_free_blocks() == 23 and n_added == 60
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the prefix-cache hash fails closed on conditioning it does not understand
+def test_prefix_hash_fails_closed_on_unknown_per_request_conditioning():
+    """Equal placeholder ids + different ``additional_information`` under a key the hasher does not account for (a
+    custom model_cls hook's rows, Qwen3-style thinker_prefill_embeddings): 0 hit tokens — the blocks are salted with the
+    request id, never shared, yet the request re-hits its OWN blocks after a preemption.  Known keys keep sharing."""
+    from vllm_omni_amd.kv_cache import KVCacheManager
+
+    kv = KVCacheManager(32, BS, enable_caching=True)
+    ids = [7] * 9
+    a = Request("a", ids, SamplingParams(), additional_information={"my_rows": torch.randn(9, 8)})
+    assert kv.allocate_slots(a, 9) is not None
+    b = Request("b", ids, SamplingParams(), additional_information={"my_rows": torch.randn(9, 8)})
+    assert kv.get_computed_blocks(b) == (kv.empty_kv_cache_blocks, 0) or kv.get_computed_blocks(b)[1] == 0
+    c = Request("c", ids, SamplingParams(), additional_information={"thinker_prefill_embeddings": torch.randn(9, 8)})
+    assert kv.get_computed_blocks(c)[1] == 0
+    assert kv.get_computed_blocks(a)[1] == 8                      # the request itself (recompute after a preemption)
+    plain = Request("p", ids, SamplingParams())                   # no conditioning at all: ids ARE the content
+    assert kv.get_computed_blocks(plain)[1] == 0                  # ... and a's salted blocks are not served to it either
+    assert kv.allocate_slots(plain, 9) is not None
+    assert kv.get_computed_blocks(Request("q", ids, SamplingParams()))[1] == 8
+    # known keys still share: prompt rows by content
+    rows = torch.randn(9, 8)
+    k1 = Request("k1", ids, SamplingParams(), additional_information={"thinker_result": rows[8:], "prompt_embeds": rows[:7],
+                                                                       "prompt_token_ids": [1, 2], "voice_type": "Ethan"})
+    kv2 = KVCacheManager(32, BS, enable_caching=True)
+    assert kv2.allocate_slots(k1, 9) is not None
+    k2 = Request("k2", ids, SamplingParams(), additional_information={"thinker_result": rows[8:].clone(),
+                                                                       "prompt_embeds": rows[:7].clone(),
+                                                                       "prompt_token_ids": [1, 2], "voice_type": "Ethan"})
+    assert kv2.get_computed_blocks(k2)[1] == 8
+    k3 = Request("k3", ids, SamplingParams(), additional_information={"thinker_result": rows[8:], "prompt_embeds": rows[:7],
+                                                                       "voice_type": "Chelsie"})
+    assert kv2.get_computed_blocks(k3)[1] == 0                    # another voice: another speaker row
+
+
+def test_prefix_cache_extra_keys_hook_and_stats_shape():
+    from vllm_omni_amd.kv_cache import KVCacheManager, PrefixCacheStats
+
+    kv = KVCacheManager(32, BS, enable_caching=True)
+    kv.prefix_cache_extra_keys = lambda req, lo, hi: getattr(req, "lora", b"")     # a model class's statement
+    ids = list(range(9))
+    x = Request("x", ids, SamplingParams())
+    x.lora = b"A"
+    assert kv.allocate_slots(x, 9) is not None
+    y = Request("y", ids, SamplingParams())
+    y.lora = b"B"
+    z = Request("z", ids, SamplingParams())
+    z.lora = b"A"
+    w = Request("w", ids, SamplingParams())
+    w.lora = None                                                                   # None: never share
+    assert kv.get_computed_blocks(y)[1] == 0 and kv.get_computed_blocks(z)[1] == 8 and kv.get_computed_blocks(w)[1] == 0
+    st = kv.make_prefix_cache_stats()
+    assert isinstance(st, PrefixCacheStats) and (st.requests, st.queries, st.hits, st.reset) == (3, 27, 8, False)
+    assert st["hits"] == 8 and dict(st)["queries"] == 27                            # mapping access keeps working
+    assert kv.make_prefix_cache_stats().queries == 0
+    assert kv.create_kv_cache_blocks(([1, 2],)).get_block_ids() == ([1, 2],)
+    assert kv.create_kv_cache_blocks(([],)).get_block_ids() == ([],) == kv.empty_kv_cache_blocks.get_block_ids()
+
+
+def test_finished_requests_leave_no_hash_chain_and_evictions_do_not_pile_up():
+    """free() of a FINISHED request drops its hash chain and prompt-row copy (upstream never calls free_block_hashes; a
+    reused request id must not meet a stale chain); a preempted request keeps its chain.  With caching on and KV events
+    off the pool's eviction record is drained every step instead of growing for the life of the server."""
+    from vllm_omni_amd.kv_cache import KVCacheManager
+
+    kv = KVCacheManager(6, BS, enable_caching=True)          # 5 usable blocks
+    r = Request("same-id", [1] * 9, SamplingParams(), prompt_embeds=torch.randn(9, 4))
+    assert kv.allocate_slots(r, 9) is not None and "same-id" in kv._req_hashes
+    r.status = RequestStatus.PREEMPTED
+    kv.free(r)
+    assert "same-id" in kv._req_hashes                        # preempted: re-hits its own blocks
+    assert kv.get_computed_blocks(r)[1] == 8
+    got = kv.allocate_slots(r, 1, 8, kv.get_computed_blocks(r)[0])
+    assert got is not None
+    r.status = RequestStatus.FINISHED_STOPPED
+    kv.free(r)
+    assert "same-id" not in kv._req_hashes and "same-id" not in kv._req_src
+    again = Request("same-id", [2] * 9, SamplingParams(), prompt_embeds=torch.randn(9, 4))   # the id comes back
+    assert kv.get_computed_blocks(again)[1] == 0
+    # churn: every allocation evicts cached blocks; the record stays drained
+    for i in range(40):
+        q = Request(f"c{i}", [100 + i] * 17, SamplingParams())
+        kv.new_step_starts()
+        assert kv.allocate_slots(q, 17) is not None
+        q.status = RequestStatus.FINISHED_STOPPED
+        kv.free(q)
+    assert len(kv.block_pool.take_evicted()) <= 5

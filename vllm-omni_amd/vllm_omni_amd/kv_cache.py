@@ -142,6 +142,33 @@ class BlockRemoved:
     request_id: str
 
 
+@dataclass
+class PrefixCacheStats:
+    """upstream's ``vllm.v1.metrics.stats.PrefixCacheStats`` fields (what its stat loggers read from
+    ``SchedulerStats.prefix_cache_stats``), with mapping access for this package's own callers."""
+
+    requests: int = 0
+    queries: int = 0
+    hits: int = 0
+    reset: bool = False
+
+    def __getitem__(self, key: str):
+        return getattr(self, key)
+
+    def keys(self):
+        return ("requests", "queries", "hits", "reset")
+
+
+def _is_finished(request) -> bool:
+    st = getattr(request, "status", None)
+    if st is None:
+        return True          # a bare request object (tests, the reference's generation scheduler): free means gone
+    fin = getattr(request, "is_finished", None)
+    if callable(fin):
+        return bool(fin())
+    return "FINISHED" in getattr(st, "name", str(st))
+
+
 # ----------------------------------------------------------------------- hashing
 def _request_tokens(request) -> Sequence[int]:
     toks = getattr(request, "all_token_ids", None)
@@ -167,6 +194,43 @@ def _prompt_embed_source(request):
         rows = torch.cat([tp, tr.new_zeros(1, e).cpu(), tr[:1].reshape(1, e).cpu()], dim=0)
         return rows, b"voice:" + str(info.get("voice_type", "Chelsie")).encode()
     return None, b""
+
+
+# keys of ``additional_information`` whose effect on the KV contents the hasher accounts for: the thinker hand-over's
+# prompt rows and first reply row are hashed as bytes (``_prompt_embed_source``), the reply queue salts generated blocks
+# with the request id (``_has_reply_rows``), the id lists are the token ids themselves, the voice is hashed by name
+_HASHED_INFO_KEYS = frozenset({"prompt_embeds", "thinker_result", "thinker_reply_part", "prompt_token_ids",
+                               "thinker_output_token_ids", "voice_type"})
+
+
+def _unhashed_conditioning(request) -> bool:
+    """True when the request carries per-request conditioning the block hash does NOT cover: any other
+    ``additional_information`` key (Qwen3-style ``thinker_prefill_embeddings`` / ``thinker_hidden_states``, whatever a
+    custom ``model_cls`` preprocess hook consumes).  Talker prompts are placeholder ids, so two such requests would
+    collide on ids alone: their blocks are then salted with the request id — never shared, only re-hit by the request
+    itself after a preemption (fail closed; the reference ships enable_prefix_caching: false for every stage, so no
+    reference behaviour defines this case)."""
+    info = getattr(request, "additional_information", None)
+    if not info:
+        return False
+    if not isinstance(info, dict):
+        return True
+    return any(k not in _HASHED_INFO_KEYS for k in info)
+
+
+def _token_slice(request, lo: int, hi: int) -> Sequence[int]:
+    """Token ids [lo, hi) of prompt + output without materialising the concatenation."""
+    toks = getattr(request, "all_token_ids", None)
+    if toks is not None:
+        return toks[lo:hi]
+    prompt = request.prompt_token_ids
+    n = len(prompt)
+    if hi <= n:
+        return prompt[lo:hi]
+    out = getattr(request, "output_token_ids", None) or []
+    if lo >= n:
+        return out[lo - n:hi - n]
+    return list(prompt[lo:]) + list(out[:hi - n])
 
 
 def _prompt_rows(request) -> int:
@@ -246,8 +310,14 @@ class KVCacheManager:
         self.req_to_blocks: dict[str, list[int]] = {}
         self._req_hashes: dict[str, list[bytes]] = {}       # chained hashes of the request's full blocks so far
         self._num_cached_blocks: dict[str, int] = {}        # leading blocks of the request already indexed
+        self._req_src: dict[str, list] = {}                 # per request: [prompt rows on the host, voice tag, #rows, salted, private]
+        # optional hook ``f(request, lo, hi) -> bytes | None``: extra content of the tokens [lo, hi) beyond ids and
+        # prompt rows (a model class with its own preprocess hook); None = never share this block
+        self.prefix_cache_extra_keys = None
         self.prefix_cache_queries = 0                        # tokens looked up / found (upstream's PrefixCacheStats)
         self.prefix_cache_hits = 0
+        self.prefix_cache_requests = 0
+        self._prefix_reset = False
         self._events: list[Any] = []
         self._events_on = enable_kv_cache_events
         self._new_block_ids: Optional[list[int]] = [] if track_new_block_ids else None
@@ -259,7 +329,13 @@ class KVCacheManager:
     # -- step hooks -------------------------------------------------------------
     def new_step_starts(self) -> None:
         """Called once per scheduling step before any allocation (bookkeeping reset)."""
-        return None
+        self._drain_evictions()
+
+    def _drain_evictions(self) -> None:
+        # the pool records every eviction of a hashed block for KV events; with events off nobody consumes them, and
+        # the list would grow for the life of the server
+        if self.enable_caching and not self._events_on:
+            self.block_pool.take_evicted()
 
     @property
     def usage(self) -> float:
@@ -273,22 +349,33 @@ class KVCacheManager:
         hs = self._req_hashes.setdefault(rid, [])
         if len(hs) >= num_blocks:
             return hs[:num_blocks]
-        toks = _request_tokens(request)
         b = self.block_size
-        pe, voice = _prompt_embed_source(request)
-        rows = int(pe.shape[0]) if pe is not None else 0
-        salted = _has_reply_rows(request)
+        # the prompt-row source is built ONCE per request (the thinker hand-over's is a concatenation + a device->host
+        # copy of the whole prompt) and dropped when the last block that covers prompt rows has been hashed
+        src = self._req_src.get(rid)
+        if src is None:
+            pe, voice = _prompt_embed_source(request)
+            if pe is not None:
+                pe = pe.detach().contiguous().cpu()
+            src = self._req_src[rid] = [pe, voice, int(pe.shape[0]) if pe is not None else 0,
+                                        _has_reply_rows(request), _unhashed_conditioning(request)]
+        pe, voice, rows, salted, private = src
         plen = max(rows, len(request.prompt_token_ids))
         parent = hs[-1] if hs else b"\0" * 16
         for i in range(len(hs), num_blocks):
             lo, hi = i * b, (i + 1) * b
             extra = b""
             if lo < rows:   # the block covers prompt rows given as embeddings: their bytes ARE the content
-                extra = pe[lo:min(hi, rows)].detach().contiguous().cpu().view(torch.uint8).numpy().tobytes() + voice
-            if hi > plen and salted:
+                extra = pe[lo:min(hi, rows)].view(torch.uint8).numpy().tobytes() + voice
+            if private or (hi > plen and salted):
                 extra += b"|" + rid.encode()
-            parent = block_content_hash(parent, toks[lo:hi], extra)
+            if self.prefix_cache_extra_keys is not None:   # a model class's own statement of what else the KV depends on
+                more = self.prefix_cache_extra_keys(request, lo, hi)
+                extra += b"|" + (rid.encode() if more is None else bytes(more))
+            parent = block_content_hash(parent, _token_slice(request, lo, hi), extra)
             hs.append(parent)
+        if pe is not None and len(hs) * b >= rows:
+            src[0] = None   # every block with prompt rows is hashed: the host copy of the rows is no longer needed
         return hs
 
     def get_computed_blocks(self, request) -> tuple["KVCacheBlocks", int]:
@@ -303,6 +390,7 @@ class KVCacheManager:
             return KVCacheBlocks(([],)), 0
         hashes = self._block_hashes(request, n)
         ids = self.block_pool.cache_lookup(hashes)
+        self.prefix_cache_requests += 1
         self.prefix_cache_queries += int(request.num_tokens)
         self.prefix_cache_hits += len(ids) * self.block_size
         return KVCacheBlocks((ids,)), len(ids) * self.block_size
@@ -376,6 +464,8 @@ class KVCacheManager:
                     self._events.append(BlockRemoved([b], rid))
             elif new:                 # without the index: allocation / release of the blocks themselves
                 self._events.append(BlockStored(new[:], rid))
+        elif need > 0:
+            self._drain_evictions()   # (upstream's scheduler never calls new_step_starts: drain here too)
         if not delay_cache_blocks:
             self.cache_blocks(request, min(computed + num_new_tokens, int(request.num_tokens)))
         return KVCacheBlocks((new,))
@@ -425,6 +515,12 @@ class KVCacheManager:
         rid = request.request_id
         blocks = self.req_to_blocks.pop(rid, None)
         self._num_cached_blocks.pop(rid, None)
+        # a FINISHED request never comes back: its hash chain goes with it (upstream keeps hashes on the Request and
+        # never calls free_block_hashes — a reused request id must not meet a stale chain); a preempted request
+        # (status not finished) keeps its chain and re-hits its own blocks
+        if _is_finished(request):
+            self._req_hashes.pop(rid, None)
+            self._req_src.pop(rid, None)
         if blocks:
             self.block_pool.free_blocks(list(reversed(blocks)))
             if self._events_on and not self.enable_caching:
@@ -434,6 +530,7 @@ class KVCacheManager:
         """Forget the request's hash chain (upstream calls this when the request leaves the scheduler for good; a
         preempted request keeps it and re-hits its own blocks)."""
         self._req_hashes.pop(request.request_id, None)
+        self._req_src.pop(request.request_id, None)
 
     def get_num_common_prefix_blocks(self, running_request_id: str) -> list[int]:
         """Leading blocks of ``running_request_id`` shared by EVERY request that holds blocks (upstream: blocks whose
@@ -466,13 +563,27 @@ class KVCacheManager:
         if not self.block_pool.reset_cache():
             return False
         self._req_hashes.clear()
+        self._req_src.clear()
         self._num_cached_blocks.clear()
+        self._prefix_reset = True
         return True
 
-    def make_prefix_cache_stats(self) -> dict:
-        out = {"queries": self.prefix_cache_queries, "hits": self.prefix_cache_hits}
-        self.prefix_cache_queries = self.prefix_cache_hits = 0
+    def make_prefix_cache_stats(self) -> "PrefixCacheStats":
+        """Counters since the last call, in the shape upstream's ``SchedulerStats.prefix_cache_stats`` consumers read
+        (``.requests`` / ``.queries`` / ``.hits`` / ``.reset``; ``stats["queries"]`` keeps working)."""
+        out = PrefixCacheStats(requests=self.prefix_cache_requests, queries=self.prefix_cache_queries,
+                               hits=self.prefix_cache_hits, reset=self._prefix_reset)
+        self.prefix_cache_queries = self.prefix_cache_hits = self.prefix_cache_requests = 0
+        self._prefix_reset = False
         return out
+
+    # -- upstream's small helpers the scheduler calls on its manager ----------------
+    @property
+    def empty_kv_cache_blocks(self) -> KVCacheBlocks:
+        return KVCacheBlocks(([],))
+
+    def create_kv_cache_blocks(self, blocks: tuple[list[int], ...]) -> KVCacheBlocks:
+        return KVCacheBlocks(tuple(list(b) for b in blocks)) if any(blocks) else self.empty_kv_cache_blocks
 
 
 # ------------------------------------------------------------------- cache tensors
@@ -515,7 +626,8 @@ def get_process_gpu_memory(local_rank: int) -> Optional[int]:
     ``usedGpuMemory`` of the entry whose pid is ours), here through ``amdsmi``.  With several workers sharing one card
     (``gpu_memory_utilization`` split between stages) the allocator's own ``memory_reserved`` cannot see the neighbours;
     the driver's figure per pid can.  ``local_rank`` indexes the VISIBLE devices (``HIP_VISIBLE_DEVICES`` /
-    ``CUDA_VISIBLE_DEVICES`` integer lists are honoured).  Returns None when amdsmi is missing, not permitted or
+    ``CUDA_VISIBLE_DEVICES``, then ``ROCR_VISIBLE_DEVICES`` integer lists are honoured; the worker additionally never
+    takes a figure below the allocator's own ``memory_reserved``).  Returns None when amdsmi is missing, not permitted or
     reports nothing for this pid — the caller then takes the profiling branch (base.py:134-154)."""
     import os
 
@@ -530,11 +642,21 @@ def get_process_gpu_memory(local_rank: int) -> Optional[int]:
     try:
         handles = amdsmi.amdsmi_get_processor_handles()
         index = local_rank
-        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
-        if vis:
+        # HIP_/CUDA_VISIBLE_DEVICES index the devices ROCR_VISIBLE_DEVICES leaves visible, which index the physical ones
+        def through(idx: int, var: str) -> Optional[int]:
+            vis = os.environ.get(var)
+            if not vis:
+                return idx
             ids = [v.strip() for v in vis.split(",") if v.strip()]
-            if local_rank < len(ids) and ids[local_rank].lstrip("-").isdigit():
-                index = int(ids[local_rank])
+            if idx < len(ids) and ids[idx].isdigit():
+                return int(ids[idx])
+            return None   # UUID-style entries or an index past the list: no trustworthy mapping
+
+        index = through(index, "HIP_VISIBLE_DEVICES" if os.environ.get("HIP_VISIBLE_DEVICES") else "CUDA_VISIBLE_DEVICES")
+        if index is not None:
+            index = through(index, "ROCR_VISIBLE_DEVICES")
+        if index is None:
+            return None   # profiling branch
         if not 0 <= index < len(handles):
             raise RuntimeError(f"Invalid GPU device {index}. Only {len(handles)} GPU(s) available. "
                                "Check HIP_VISIBLE_DEVICES or stage config 'devices' setting.")

@@ -147,7 +147,11 @@ class GPUARWorker:
         profiled = max(torch.cuda.memory_reserved(self.device), self.init_free_bytes - free_now)
         by_pid = get_process_gpu_memory(self.local_rank)
         self.memory_accounting = {"amdsmi_process_bytes": by_pid, "profiled_bytes": int(profiled)}
-        used_by_process = by_pid if by_pid is not None and by_pid > 0 else profiled
+        # the allocator's reserved figure is a hard lower bound on what this process holds: a driver figure below it (a
+        # wrong handle under an unusual device enumeration, an under-report) would oversize the KV cache
+        reserved = int(torch.cuda.memory_reserved(self.device))
+        used_by_process = max(by_pid, reserved) if by_pid is not None and by_pid > 0 else profiled
+        self.memory_accounting["used_bytes"] = int(used_by_process)
         return determine_available_memory(total, self.config.gpu_memory_utilization, used_by_process,
                                           self.config.kv_cache_memory_bytes)
 
