@@ -186,7 +186,35 @@ def spawn_ranks(n: int) -> int:
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
+    # torch.distributed.run answers 1 for ANY failing rank: the ranks leave their own code (4 = a stage hung or raised
+    # after the line was printed) in a file, and this launcher passes that on
+    import tempfile
+
+    code_file = os.path.join(tempfile.gettempdir(), f"mi_bench_exit_{os.getpid()}_{port}")
+    rc = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MI_BENCH_EXIT_FILE=code_file)).returncode
+    try:
+        if rc != 0 and os.path.exists(code_file):
+            rc = int(open(code_file).read().strip() or rc)
+    except (OSError, ValueError):
+        pass
+    finally:
+        try:
+            os.remove(code_file)
+        except OSError:
+            pass
+    return rc
+
+
+def leave(code: int) -> None:
+    """os._exit with the code also left where a self-spawned launcher (``spawn_ranks``) can read it."""
+    f = os.environ.get("MI_BENCH_EXIT_FILE")
+    if f:
+        try:
+            with open(f, "w") as fh:
+                fh.write(str(code))
+        except OSError:
+            pass
+    os._exit(code)
 
 
 class SyntheticScheduler:
@@ -756,7 +784,7 @@ def main():
             line = compose(results, failures)
             line["exit_code"] = EXIT_STAGE_FAILED
             print(json.dumps(line), flush=True)
-        os._exit(EXIT_STAGE_FAILED if results else 3)
+        leave(EXIT_STAGE_FAILED if results else 3)
 
     t_bench0 = time.monotonic()
     budget = float(os.environ.get("MI_BENCH_BUDGET_S", "420"))   # no further stage is STARTED past this many seconds
@@ -795,7 +823,7 @@ def main():
                 line = compose(results, failures)
                 line["exit_code"] = EXIT_STAGE_FAILED
                 print(json.dumps(line), flush=True)
-            os._exit(EXIT_STAGE_FAILED)
+            leave(EXIT_STAGE_FAILED)
         finally:
             if guard is not None:
                 guard.cancel()
