@@ -66,6 +66,19 @@ constexpr int kColTile = 16;  // query tokens per MFMA column tile
 #ifndef MI_PREFILL_PRIO
 #define MI_PREFILL_PRIO 1
 #endif
+#ifndef MI_PREFILL_STAGGER
+// 32x32x16 kernel, eight waves: waves 4-7 run HALF A STEP behind waves 0-3 — the workgroup's one barrier per step sits
+// at the top of the step for waves 0-3 and between the S^T / softmax half and the PV half for waves 4-7, so that on
+// every SIMD one wave's PV MFMAs (matrix pipe busy, vector issue idle) run beside its partner's S^T MFMAs +
+// exponentials (vector issue busy, matrix pipe half idle) instead of both waves doing the same thing at the same
+// time (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  The DMA moves to waves 0-3 (their barrier is the one the
+// ring's refill rule is stated for).  0 = every wave at the top of the step (round 3's form).
+// Built, parity-green (tests/test_gpu_attention_prefill.py), and measured LEVEL with the unstaggered form on one box,
+// interleaved runs (8192-token prompt: 0.726-0.730 against 0.732-0.735 ms per layer in one chunk, 0.789 / 0.802 in chunks of
+// 4096, 0.737 / 0.721 in chunks of 2048: profiles/r04j_prefill_stagger_ab.log) — the two waves of a SIMD are not held back
+// by running in phase; the default stays the round-3 form.
+#define MI_PREFILL_STAGGER 0
+#endif
 #ifndef MI_PREFILL_SCHED
 #define MI_PREFILL_SCHED 1   // sched_group_barrier interleave of the exponentials with the QK^T MFMAs (A/B: -DMI_PREFILL_SCHED=0)
 #endif
@@ -650,7 +663,10 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 
   // ---- DMA issue (as in the 16x16x32 kernel; only the V swizzle differs)
   auto swz_v32 = [](int r) { return (r & 3) << 2; };
-  const int iw = wid - ((int)(blockDim.x >> 6) - NI);
+  // staggered: eight waves, the second half one half-step behind the first (see MI_PREFILL_STAGGER)
+  const bool stag = MI_PREFILL_STAGGER && NC == 1 && blockDim.x == 512;
+  const bool late = stag && wid >= 4;                                  // wave-uniform
+  const int iw = stag ? (wid < NI ? wid : -1) : wid - ((int)(blockDim.x >> 6) - NI);
   const uint64_t blk_bytes = (uint64_t)p.blk_stride * 2;
   const uint32_t tok_bytes = (uint32_t)p.tok_stride * 2;
   const uint32_t grp_bytes = RPI * tok_bytes;
@@ -833,9 +849,11 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     constexpr int ST = decltype(stc)::value;
     constexpr bool INT = decltype(interior)::value;
     using NEXT = std::integral_constant<int, (ST + 1) % NSTAGE>;
-    if (INT || t + 2 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (INT || t + 3 < t_end) issue(t + 3, (ST + 3) % NSTAGE, interior);
+    if (!late) {   // waves 4-7 of a staggered workgroup meet the others between the two halves of their step (below)
+      if (INT || t + 2 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (INT || t + 3 < t_end) issue(t + 3, (ST + 3) % NSTAGE, interior);
+    }
     if (active) {
       constexpr int SN = NEXT::value * STAGE, SB = ST * STAGE;
       // fragment reads run under the work that does not need them: K(t+1) under the branches of step t's softmax,
@@ -861,6 +879,9 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
         }
       }
       lds_wait_all();
+      // a late wave has K(t+1) and V(t) in registers and is done with the LDS stages of this step: it meets the early
+      // waves' NEXT top-of-step barrier here and runs its PV half beside their S^T / softmax half
+      if (late) __builtin_amdgcn_s_barrier();
       // the PV MFMAs need nothing but P: the row sum of step t and the lane maximum of step t+1's scores (ready since
       // the S MFMAs retired) fill their gaps instead of standing in front of the next step
       pv_mfma(o);
@@ -874,6 +895,8 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
           __builtin_amdgcn_sched_group_barrier(0x002, SPLIT ? 2 : 3, 1);
         }
       }
+    } else if (late) {
+      __builtin_amdgcn_s_barrier();   // a late wave without a real column still meets the others once per step
     }
   };
   if (MI_PREFILL_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
@@ -892,6 +915,11 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(sc[0][c]);
   }
   const int t_int = max(t_begin, min(t_end - 3, (ctx_off + tile0 + 1) / kStep)) & ~3;
+  // Barrier pairing of a staggered workgroup (n = t_end - t_begin steps): the early waves' top-of-step barrier of step
+  // j meets the late waves' mid-step barrier of step j - 1; the late waves therefore wait once more here (with the
+  // early waves' barrier of the first step: the stage of step t_begin + 1 has landed behind it), and the early waves
+  // once more after their last step (with the late waves' last mid-step barrier).
+  if (late) __builtin_amdgcn_s_barrier();
   int t = t_begin;
   for (; t < t_int; t += 4) {
     step(t, S0{}, std::true_type{});
@@ -905,6 +933,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     if (t + 2 < t_end) step(t + 2, S2{}, std::false_type{});
     if (t + 3 < t_end) step(t + 3, S3{}, std::false_type{});
   }
+  if (stag && !late) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: O^T -> out[token][head][dim]; lane: d = 32n + 8 * (i / 4) + 4h + i % 4
 #pragma unroll
