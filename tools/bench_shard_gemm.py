@@ -51,7 +51,10 @@ def talker_shapes(tp: int):
     """(name, weight rows n, k, gated, bias) of one rank's four projections of the headline talker (S-A)."""
     nq, nkv = 28 // tp, max(1, 4 // tp)
     return [("qkv", (nq + 2 * nkv) * 128, 3584, False, True), ("o", 3584, nq * 128, False, False),
-            ("gate_up", 2 * 18944 // tp, 3584, True, False), ("down", 3584, 18944 // tp, False, False)]
+            ("gate_up", 2 * 18944 // tp, 3584, True, False), ("down", 3584, 18944 // tp, False, False),
+            # once per step: the vocab-parallel lm_head (qwen2_old.py:409-418) and, un-sharded, thinker_to_talker_proj
+            # (qwen2_5_omni_talker.py:72-75: embedding_size 3584 -> hidden 3584, bias) — at TP 1 the o_proj shape with a bias
+            ("lm_head", 8448 // tp, 3584, False, False)] + ([("t2t_proj", 3584, 3584, False, True)] if tp > 1 else [])
 
 
 def candidates(m: int, n_cols: int, k: int, gated: bool):
@@ -128,7 +131,19 @@ def sweep(name, n, k, gated, bias, m, g, log=print, top=8):
              "builtin_us": round(t_def, 2)}
     if rows:
         t, mt, ns, sp, _, _ = rows[0]
-        entry["full"] = {"rows": 16 * mt, "wrows": 32 * ns, "split": sp, "us": round(t, 2)}
+        # the built-in plan stays unless a candidate is ahead by more than the run-to-run noise of these ~10-70 us timings
+        import ctypes
+
+        from vllm_omni_amd import _C
+        buf = (ctypes.c_int32 * 3)()
+        _C.lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_GATED if gated else _C.MI_LINEAR_PLAN_FULL, m, n // 2 if gated else n, k, buf)
+        purpose = _C.MI_LINEAR_PLAN_GATED if gated else _C.MI_LINEAR_PLAN_FULL
+        registrable = _C.lib.mi_linear_plan_set(purpose, 0, 1, 16, 64, buf[0], buf[1], buf[2]) == _C.MI_OK   # a throw-away entry
+        _C.lib.mi_linear_plan_clear()
+        if t_def <= 1.03 * t and registrable:
+            entry["full"] = {"rows": buf[0], "wrows": buf[1], "split": buf[2], "us": round(t_def, 2), "builtin": True}
+        else:
+            entry["full"] = {"rows": 16 * mt, "wrows": 32 * ns, "split": sp, "us": round(t, 2)}
         part = sorted((r[5], r[1], r[2], r[3]) for r in rows if r[5] is not None)
         if part:
             tp_, mt, ns, sp = part[0]

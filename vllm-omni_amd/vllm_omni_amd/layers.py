@@ -463,6 +463,24 @@ def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_re
     return F.linear(x, w, bias)
 
 
+class _Weights:
+    """a bare (weight, bias) pair in the shape ``_apply_linear`` reads a layer"""
+
+    __slots__ = ("weight", "bias", "qweight")
+
+    def __init__(self, weight, bias=None):
+        self.weight, self.bias, self.qweight = weight, bias, None
+
+
+def tuned_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear`` for the step's un-sharded extras (``thinker_to_talker_proj``, the vocab-parallel ``lm_head``), routed
+    like the decoder's projections: the streaming kernel where the tuned table (or the round-3 rule) has it ahead of
+    the library GEMM at this shape."""
+    if x.dim() > 2 or not x.is_cuda:
+        return F.linear(x, weight, bias)
+    return _apply_linear(_Weights(weight, bias), x, bias)
+
+
 def quantize_int8_(layer) -> None:
     """Online W8A8 quantisation of one linear layer after its weights are loaded — the reference's
     ``Int8OnlineLinearMethod.process_weights_after_loading`` (vllm_omni/quantization/int8_config.py:391-418:

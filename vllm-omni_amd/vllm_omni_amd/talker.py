@@ -21,7 +21,7 @@ from . import ops
 from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size
 from .layers import (Attention, MergedColumnParallelLinear, QKVParallelLinear, RMSNorm, RowParallelLinear,
                      SiluAndMul, _init_weight, fused_gate_up_silu, get_forward_context, get_rope, shard_column, shard_merged_column,
-                     shard_qkv, shard_row)
+                     shard_qkv, shard_row, tuned_linear)
 from .distributed import tensor_model_parallel_all_gather
 
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
@@ -256,7 +256,7 @@ class Qwen2ForCausalLM:
         self.lm_head = _init_weight(cfg.vocab_size // tp, cfg.hidden_size, dtype, device, generator)
 
     def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        logits = F.linear(hidden_states, self.lm_head)
+        logits = tuned_linear(hidden_states, self.lm_head)
         return tensor_model_parallel_all_gather(logits)
 
 
@@ -304,7 +304,7 @@ class Qwen2_5OmniTalkerForConditionalGeneration:
         if inputs_embeds is None:
             inputs_embeds = self.embed_input_ids(input_ids)  # profile run
         if self.config.input_projection:
-            inputs_embeds = F.linear(inputs_embeds, self.thinker_to_talker_proj_weight, self.thinker_to_talker_proj_bias)
+            inputs_embeds = tuned_linear(inputs_embeds, self.thinker_to_talker_proj_weight, self.thinker_to_talker_proj_bias)
         return self.language_model.model(None, positions, intermediate_tensors, inputs_embeds=inputs_embeds)
 
     __call__ = forward
