@@ -57,9 +57,18 @@ def talker_shapes(tp: int):
             ("lm_head", 8448 // tp, 3584, False, False)] + ([("t2t_proj", 3584, 3584, False, True)] if tp > 1 else [])
 
 
+def predictor_shapes():
+    """The Qwen3-Omni code predictor's four projections (models/common/qwen3_code_predictor.py:143-191: hidden 1024, 16 / 8
+    heads of 128, intermediate 3072, no biases): 157 MB of weights over its five layers, re-read at every one of the 31
+    steps of a call — they live in the 256 MB Infinity Cache, so they are timed warm (COPIES_MB=150)."""
+    return [("cp_qkv", 4096, 1024, False, False), ("cp_o", 1024, 2048, False, False),
+            ("cp_gate_up", 6144, 1024, True, False), ("cp_down", 1024, 3072, False, False)]
+
+
 def candidates(m: int, n_cols: int, k: int, gated: bool):
     """(rows per block / 16, weight rows per tile / 32, split) of every built tile shape that gives 96-640 workgroups."""
     mts = [4] if m <= 64 else [4, 8] if m <= 128 else [4, 8, 16]
+    lo_wgs = 32 if n_cols * k < (8 << 20) else 96      # small weights (the code predictor's): fewer workgroups may win
     out = []
     for mt in mts:
         for ns in (1, 2, 3, 4, 5, 6, 8):
@@ -74,14 +83,14 @@ def candidates(m: int, n_cols: int, k: int, gated: bool):
             for sp in splits:
                 rb = -(-m // (16 * mt))
                 tiles = -(-n_cols // ((16 if gated else 32) * ns))
-                if 96 <= tiles * sp * rb <= 640:
+                if lo_wgs <= tiles * sp * rb <= 640:
                     out.append((mt, ns, sp))
     return out
 
 
 def sweep(name, n, k, gated, bias, m, g, log=print, top=8):
     """Times the library, the kernel's built-in plan and every candidate plan.  Returns a dict for the tuned table."""
-    copies = max(2, int(600e6 // (n * k * 2)))
+    copies = max(2, int(float(os.environ.get("COPIES_MB", 600)) * 1e6 // (n * k * 2)))
     ws = [(torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16) for _ in range(copies)]
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
     b = (torch.randn(n, device="cuda", generator=g) * 0.1).to(torch.bfloat16) if bias else None
@@ -159,7 +168,7 @@ def main():
     tp = int(os.environ.get("TP", 4))
     only = os.environ.get("ONLY", "")
     g = torch.Generator(device="cuda").manual_seed(0)
-    for name, n, k, gated, bias in talker_shapes(tp):
+    for name, n, k, gated, bias in (predictor_shapes() if os.environ.get("PREDICTOR") == "1" else talker_shapes(tp)):
         if only and name not in only.split(","):
             continue
         sweep(name, n, k, gated, bias, m, g, log=lambda s: print(s, flush=True), top=14)
