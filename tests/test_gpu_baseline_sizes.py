@@ -234,6 +234,56 @@ def test_decode_full_size_properties_and_sampled_oracle(dev, B, ctx):
     assert e["atol_needed_at_rtol_1e-3"] <= _BOUNDS[("exact", dtype)], e
 
 
+@pytest.mark.parametrize("B,nq,nkv,ctx", [(256, 28, 4, 4096), (128, 7, 1, 4096), (64, 28, 4, 2048)],
+                         ids=["config3-tp1", "config3-dp2xtp4-rank", "config2"])
+def test_rope_fused_decode_full_size_equals_the_two_launches_and_the_oracle(dev, B, nq, nkv, ctx):
+    """Round 4: the launch bench.py times since RoPE + KV write moved inside it (`mi_rope_cache_paged_attn_decode`) at
+    the headline shape, at one rank's shape of the 8-GPU plan (7 / 1 heads, four partitions per sequence) and at config
+    #2's: output, K cache and V cache bit-identical to `mi_rope_neox_and_cache` + `mi_paged_attn_decode` on a twin cache;
+    sampled sequences against the oracle chain (rotate -> write -> attend) at the production bar."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.layers import build_cos_sin_cache
+
+    d, dtype = 128, torch.bfloat16
+    lens = [ctx] * B
+    bound = ctx + BS
+    table, nb = _table(B, lens, seed=13, max_blocks=(bound + BS - 1) // BS)
+    kv_a, kb_a, vb_a = _device_cache(dev, nb, nkv, d, dtype, seed=11)
+    kv_b = kv_a.clone()
+    kb_b, vb_b = kv_b[:, 0].permute(0, 2, 1, 3), kv_b[:, 1].permute(0, 2, 1, 3)
+    g = torch.Generator().manual_seed(14)
+    qkv = torch.randn(B, (nq + 2 * nkv) * d, generator=g).to(dtype).to(dev)
+    csc = build_cos_sin_cache(d, 8192, 1e6, device=dev)
+    pos = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
+    slots = (table[:, (ctx - 1) // BS].to(torch.int64) * BS + (ctx - 1) % BS).to(dev)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=dev)
+    tb = table.to(dev)
+    # the two launches
+    row = qkv.clone()
+    q, k, v = row.split([nq * d, nkv * d, nkv * d], dim=-1)
+    ops.rope_neox_and_cache(q, k, v, pos, csc, d, kb_a, vb_a, slots)
+    out_two = torch.empty(B, nq * d, dtype=dtype, device=dev)
+    ops.paged_attn_decode(out_two, q, kb_a, vb_a, tb, lens_d, bound, d ** -0.5)
+    # the one launch
+    q2, k2, v2 = qkv.split([nq * d, nkv * d, nkv * d], dim=-1)
+    assert ops.rope_decode_fusable(q2, kb_b, pos, d, 0, B, bound)
+    out_one = torch.empty_like(out_two)
+    ops.rope_cache_paged_attn_decode(out_one, q2, k2, v2, pos, csc, kb_b, vb_b, slots, tb, lens_d, bound, d ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(kv_a, kv_b), "cache contents differ"
+    assert torch.equal(out_one, out_two), "attention outputs differ"
+    # sampled sequences against the oracle chain
+    rows = [0, B // 3, B - 1]
+    table_cpu = ref_ops.build_cos_sin_cache(d, 8192, 1e6)
+    q0, k0, v0 = qkv[rows].cpu().split([nq * d, nkv * d, nkv * d], dim=-1)
+    p0 = pos[rows].cpu()
+    qr = ref_ops.rope_neox(p0, q0, d, table_cpu, round_to=dtype).view(len(rows), nq, d)
+    ref = _oracle_rows(kb_b, vb_b, table, lens, torch.zeros(B, nq, d).index_copy_(0, torch.tensor(rows), qr.float()), rows)
+    e = _errs(out_one.view(B, nq, d)[rows].float().cpu(), ref, out_ulp=2.0 ** -9)
+    _record(f"fused RoPE + decode B{B} {nq}/{nkv} ctx{ctx} bf16: 3 sampled sequences vs the oracle chain (16-bit output)", **e)
+    assert e["atol_needed_at_rtol_1e-3"] <= 2 * _BOUNDS[("fast", dtype)], e
+
+
 # ------------------------------------------------------------------ config #4: 8192-token chunked prefill
 def _prefill_chunks(dev, q, kb, vb, table, total, chunk):
     from vllm_omni_amd import ops

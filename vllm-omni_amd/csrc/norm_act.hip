@@ -65,12 +65,13 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ ou
   const uint16_t* xr = x + row * x_stride;
   uint16_t* rr = ADD ? residual + row * r_stride : nullptr;
   uint16_t* orow = out + row * out_stride;
-  uint4 z[MAXC];
+  uint4 z[MAXC], wreg[MAXC];   // the norm weights are loaded beside the row, not behind the reduction (one L2 round trip less)
   float ss = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     const int ch = threadIdx.x + k * 256;
     if (ch < nchunk) {
+      wreg[k] = *reinterpret_cast<const uint4*>(w + ch * 8);
       uint4 a = *reinterpret_cast<const uint4*>(xr + ch * 8);
       if constexpr (ADD) {
         const uint4 b = *reinterpret_cast<const uint4*>(rr + ch * 8);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* __restrict__ ou
   for (int k = 0; k < MAXC; ++k) {
     const int ch = threadIdx.x + k * 256;
     if (ch < nchunk) {
-      const uint4 wv = *reinterpret_cast<const uint4*>(w + ch * 8);
+      const uint4 wv = wreg[k];
       const uint32_t zs[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
       const uint32_t ws[4] = {wv.x, wv.y, wv.z, wv.w};
       uint32_t o[4];
@@ -194,12 +195,13 @@ __global__ __launch_bounds__(256) void rms_norm_splitk_kernel(uint16_t* __restri
   const int nchunk = hidden / 8;
   uint16_t* rr = residual + row * r_stride;
   uint16_t* orow = out + row * out_stride;
-  uint4 z[MAXC];
+  uint4 z[MAXC], wreg[MAXC];
   float ss = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     const int ch = threadIdx.x + k * 256;
     if (ch < nchunk) {
+      wreg[k] = *reinterpret_cast<const uint4*>(w + ch * 8);
       const float* p0 = part + (int64_t)row * hidden + ch * 8;
       // every slice's loads in flight at once (S <= 16), then summed in slice order
       float4 vl[16], vh[16];
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void rms_norm_splitk_kernel(uint16_t* __restri
   for (int k = 0; k < MAXC; ++k) {
     const int ch = threadIdx.x + k * 256;
     if (ch < nchunk) {
-      const uint4 wv = *reinterpret_cast<const uint4*>(w + ch * 8);
+      const uint4 wv = wreg[k];
       const uint32_t zs[4] = {z[k].x, z[k].y, z[k].z, z[k].w};
       const uint32_t ws[4] = {wv.x, wv.y, wv.z, wv.w};
       uint32_t o[4];

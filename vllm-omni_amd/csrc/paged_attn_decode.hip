@@ -352,6 +352,46 @@ __global__ __launch_bounds__(64) void decode_reduce_kernel(const DecodeParams p)
   // Eight partitions per trip, every load of a trip issued before the first use (a loop that loads, uses and loops is
   // `np` dependent round trips: 7.5 us for 16 partitions at batch 8); the sums run in partition order as before.
   constexpr int CH = 8;
+  if (p.num_parts <= CH) {
+    // The common case (the auto rule gives <= 8 partitions up to 64k tokens): every load of the merge — the (m, l) pairs
+    // and the partial rows of ALL the launch's partitions — is issued at once, beside the seq_lens load instead of
+    // behind it (three dependent round trips become one); partitions the sequence does not reach hold stale bytes and
+    // are dropped by a select AFTER the load.  Same sums in the same order as the loops below.
+    float2 x[CH];
+    float po[CH][DPL];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const bool have = j < p.num_parts;   // launch parameter: no dependence on seq_lens
+      x[j] = have ? ml[j] : make_float2(kNegBig, 0.f);
+      const float* src = p.part_o + (slot0 + (have ? j : 0)) * HD + lane * DPL;
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) po[j][d] = have ? src[d] : 0.f;
+    }
+    float mm1 = kNegBig;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) mm1 = fmaxf(mm1, j < np ? x[j].x : kNegBig);
+    float L1 = 0.f, a1[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) a1[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      if (j < np) {
+        const float w = fast_exp2(x[j].x - mm1);
+        L1 += w * x[j].y;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) a1[d] += w * po[j][d];
+      }
+    }
+    const float inv1 = np > 0 ? 1.f / L1 : 0.f;
+    const int64_t o1 = (int64_t)seq * p.out_stride + (int64_t)qh * HD + lane * DPL;
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) {
+      const float r = a1[d] * inv1;
+      if (p.out_f32) reinterpret_cast<float*>(p.out)[o1 + d] = r;
+      else reinterpret_cast<uint16_t*>(p.out)[o1 + d] = E::to_bits(r);
+    }
+    return;
+  }
   float mm = kNegBig;
   for (int i0 = 0; i0 < np; i0 += CH) {
     float2 x[CH];
