@@ -142,6 +142,67 @@ def test_linear_sweep(dev, seed):
 
 
 @pytest.mark.parametrize("seed", SEEDS)
+def test_linear_registered_plan_sweep(dev, seed):
+    """Round 4: random shapes on a random BUILT tile plan (row block 64 / 128 / 256, 32-256 weight rows per tile, split-K
+    1-8) registered through mi_linear_plan_set — plain (with its reduce launch, its partials-only half, and the
+    in-launch reduce: all three the same bits) and gated — against float64 references."""
+    import ctypes
+
+    from vllm_omni_amd import _C, ops
+    from vllm_omni_amd.tuned import linear_plans
+
+    rng = np.random.default_rng(9100 + seed)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    linear_plans.reset()
+    try:
+        for _ in range(6):
+            dtype = _dtype(rng)
+            m = int(rng.choice([1, 31, 64, 65, 100, 128, 129, 200, 256, 300, 512]))
+            k = 128 * int(rng.choice([1, 2, 7, 8, 28, 37]))
+            n = 32 * int(rng.choice([1, 3, 9, 36, 100, 112, 148]))
+            rows = int(rng.choice([64, 128, 256]))
+            gated = rng.random() < 0.4
+            if gated:
+                wrows = 32 * int(rng.choice([1, 2, 3, 4, 5, 6] if rows == 64 else [1, 2, 3, 4, 5] if rows == 128 else [1, 2, 4, 5]))
+                split = 1
+            else:
+                wrows = 32 * int(rng.choice([1, 2, 3, 4, 5, 6, 8] if rows == 64 else [1, 2, 3, 4, 5] if rows == 128 else [4, 5]))
+                split = int(rng.choice([1, 2, 3, 4, 6, 8]))
+            x = torch.randn(m, k, device="cuda", generator=g).to(dtype)
+            if gated:
+                inter = n // 2
+                assert _C.lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_GATED, 0, 512, inter, k, rows, wrows, 1) == _C.MI_OK
+                w = (torch.randn(2 * inter, k, device="cuda", generator=g) * k ** -0.5).to(dtype)
+                z = ops.linear_silu_mul(x, w)
+                gu = (x.double() @ w.double().t()).to(dtype).float()
+                gate, up = gu[:, :inter], gu[:, inter:]
+                sil = gate / (1.0 + torch.exp(-gate))
+                slack = (up.abs() * 1.1 * gate.abs() + sil.abs() * up.abs()) * ULP[dtype]
+                assert ((z.float() - sil * up).abs() <= (sil * up).abs() * ULP[dtype] + slack + 1e-3).all(), (m, inter, k, rows, wrows)
+                continue
+            assert _C.lib.mi_linear_plan_set(_C.MI_LINEAR_PLAN_FULL, 0, 512, n, k, rows, wrows, split) == _C.MI_OK
+            buf = (ctypes.c_int32 * 3)()
+            assert _C.lib.mi_linear_plan_get(_C.MI_LINEAR_PLAN_FULL, m, n, k, buf) == _C.MI_OK and list(buf)[:2] == [rows, wrows]
+            w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(dtype)
+            b = torch.randn(n, device="cuda", generator=g).to(dtype) if rng.random() < 0.5 else None
+            ops.LINEAR_FUSED_REDUCE = False
+            y = ops.linear(x, w, b)
+            ref = x.double() @ w.double().t() + (b.double() if b is not None else 0.0)
+            err = (y.double() - ref).abs()
+            tol = ref.abs() * ULP[dtype] + 4e-3 * (1 + (k / 1024) ** 0.5) * ULP[dtype] / ULP[torch.bfloat16] + 1e-3
+            assert (err <= tol).all(), (m, n, k, rows, wrows, split, dtype, float(err.max()))
+            if buf[2] > 1:
+                part = ops.linear_partials(x, w, b)
+                assert part is not None and torch.equal(part.materialize(), y)
+                ops.LINEAR_FUSED_REDUCE = True
+                assert torch.equal(ops.linear(x, w, b), y), (m, n, k, rows, wrows, split)
+                ops.LINEAR_FUSED_REDUCE = False
+    finally:
+        ops.LINEAR_FUSED_REDUCE = os.environ.get("VLLM_OMNI_AMD_LINEAR_FUSED_REDUCE", "0") == "1"
+        linear_plans.reset()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_fused_moe_sweep(dev, seed):
     """The sparse-MoE layer at random token counts (one row block to several tiles per expert, the 1024-thread route
     launch with 1, 2 and 4 tokens per wave), expert counts 64 / 128 / 256 and top-k 1..8, against the oracle evaluated
