@@ -172,38 +172,46 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
     for (int s = 0; s < KS; ++s)
       qf[s] = head_ok ? *reinterpret_cast<const uint4*>(qb + 32 * s) : make_uint4(0, 0, 0, 0);
   }
+  // ---- RoPE + KV write of this step's token (A4 + A7 inside the attention launch) ---------------------------------
+  // q: rotated in registers AFTER the first DMA steps have been issued (below): the q, position and table-row loads then
+  // ride under the DMA flight instead of standing in front of it.  k, v: the wave whose partition ends at the sequence's
+  // last token, once per KV head, rotates the token's k and writes it and v to the cache row.  Its own DMA is the only
+  // reader of that row in this launch: when the partition is longer than the ring (the row's step is issued from inside
+  // the loop) the token's k / v loads also ride under the first DMA steps and only the stores' acknowledgement is waited
+  // for; a partition of <= NS steps fetches the row in its prologue, so it writes first and waits before any DMA.
+  const float* rope_row = nullptr;
+  bool kv_owner = false;
   if constexpr (ROPE) {
-    // ---- RoPE + KV write of this step's token (A4 + A7 inside the attention launch) ---------------------------
     int64_t pos = p.positions[seq];
     pos = pos < 0 ? 0 : (pos >= p.max_position ? (int64_t)p.max_position - 1 : pos);
-    const float* const row = p.cos_sin + pos * HD;   // rot_dim == head_dim
-    // q: dims 32 s + 8 g .. of head h pair with dims + HD / 2 = fragment s + KS / 2 of the same lane
-#pragma unroll
-    for (int s = 0; s < KS / 2; ++s) rope_rotate8<Tag>(qf[s], qf[s + KS / 2], row, 32 * s + 8 * g, HD / 2);
-    // k, v: the wave whose partition ends at the sequence's last token, once per KV head
-    if (t_end == steps_total && qh0 % p.kv_group == 0) {   // wave-uniform
-      const int64_t slot = p.slot_mapping[seq];
-      if (slot >= 0) {
-        const int64_t crow = (slot >> p.bs_log2) * p.blk_stride + (slot & bs_mask_of(p.bs_log2)) * p.tok_stride +
-                             (int64_t)kvh * p.head_stride;
-        constexpr int RI = HD / 16;   // rotate-items of one k head: lane j < RI = dims [8 j, 8 j + 8) and their partners
-        if (lane < RI) {
-          const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new) + (int64_t)seq * p.kn_stride + kvh * HD;
-          uint4 x = *reinterpret_cast<const uint4*>(kn + 8 * lane), y = *reinterpret_cast<const uint4*>(kn + HD / 2 + 8 * lane);
-          rope_rotate8<Tag>(x, y, row, 8 * lane, HD / 2);
-          uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k_cache)) + crow;
-          *reinterpret_cast<uint4*>(kc + 8 * lane) = x;
-          *reinterpret_cast<uint4*>(kc + HD / 2 + 8 * lane) = y;
-        } else if (lane < RI + HD / 8) {
-          const int j = lane - RI;
-          const uint16_t* vn = reinterpret_cast<const uint16_t*>(p.v_new) + (int64_t)seq * p.vn_stride + kvh * HD;
-          uint16_t* vc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.v_cache)) + crow;
-          *reinterpret_cast<uint4*>(vc + 8 * j) = *reinterpret_cast<const uint4*>(vn + 8 * j);
-        }
-      }
-      // the row's stores have been acknowledged before this wave's DMA (the only reader of that row in this launch,
-      // on this CU) can fetch it
-      wait_vmcnt<0>();
+    rope_row = p.cos_sin + pos * HD;   // rot_dim == head_dim
+    kv_owner = t_end == steps_total && qh0 % p.kv_group == 0;   // wave-uniform
+  }
+  auto kv_write = [&]() {
+    const int64_t slot = p.slot_mapping[seq];
+    if (slot < 0) return;
+    const int64_t crow = (slot >> p.bs_log2) * p.blk_stride + (slot & bs_mask_of(p.bs_log2)) * p.tok_stride +
+                         (int64_t)kvh * p.head_stride;
+    constexpr int RI = HD / 16;   // rotate-items of one k head: lane j < RI = dims [8 j, 8 j + 8) and their partners
+    if (lane < RI) {
+      const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new) + (int64_t)seq * p.kn_stride + kvh * HD;
+      uint4 x = *reinterpret_cast<const uint4*>(kn + 8 * lane), y = *reinterpret_cast<const uint4*>(kn + HD / 2 + 8 * lane);
+      rope_rotate8<Tag>(x, y, rope_row, 8 * lane, HD / 2);
+      uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k_cache)) + crow;
+      *reinterpret_cast<uint4*>(kc + 8 * lane) = x;
+      *reinterpret_cast<uint4*>(kc + HD / 2 + 8 * lane) = y;
+    } else if (lane < RI + HD / 8) {
+      const int j = lane - RI;
+      const uint16_t* vn = reinterpret_cast<const uint16_t*>(p.v_new) + (int64_t)seq * p.vn_stride + kvh * HD;
+      uint16_t* vc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.v_cache)) + crow;
+      *reinterpret_cast<uint4*>(vc + 8 * j) = *reinterpret_cast<const uint4*>(vn + 8 * j);
+    }
+  };
+  const bool kv_early = kv_owner && t_end - t_begin <= NS;
+  if constexpr (ROPE) {
+    if (kv_early) {
+      kv_write();
+      wait_vmcnt<0>();   // acknowledged before the prologue DMA below can fetch the row
     }
   }
 
@@ -424,6 +432,19 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
     if (t_begin + i < t_end) {
       issue_k(t_begin + i, i);
       issue_v(t_begin + i, i);
+    }
+  }
+  if constexpr (ROPE) {
+    // q: dims 32 s + 8 g .. of head h pair with dims + HD / 2 = fragment s + KS / 2 of the same lane
+#pragma unroll
+    for (int s = 0; s < KS / 2; ++s) rope_rotate8<Tag>(qf[s], qf[s + KS / 2], rope_row, 32 * s + 8 * g, HD / 2);
+    if (kv_owner && !kv_early) {
+      kv_write();
+      // Acknowledged before the loop can issue the DMA of the row's step (it may do so in its very first step: a
+      // counted wait only bounds the operations outstanding, it does not order three young stores).  The prologue's
+      // DMA steps have landed by now (the q rotation waited for its loads behind them), so this waits for the
+      // stores alone and drains nothing.
+      wait_vmcnt<0>();
     }
   }
   // A partition longer than 64 blocks (MI_DECODE_LONG_PARTITIONS) is walked window by window: steps_per_win is even for
