@@ -47,7 +47,7 @@ def main():
     buf = (ctypes.c_ulonglong * 256)()
     assert lib.mi_debug_prefill_ticks(buf) == 0
     print(f"kernel {e0.elapsed_time(e1) * 1e3:.1f} us")
-    names = ["vmcnt", "barrier", "dma issue", "masks/max", "K read", "QK+exp", "V read", "PV"]
+    names = ["vmcnt", "barrier", "dma issue", "Kissue+pre", "Kwait+Vissue", "QK+exp", "Vwait", "PV"]
     for w in range(8):
         row = [buf[w * 16 + i] for i in range(16)]
         steps = row[10]

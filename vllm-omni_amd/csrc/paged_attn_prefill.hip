@@ -79,6 +79,24 @@ constexpr int kColTile = 16;  // query tokens per MFMA column tile
 // by running in phase; the default stays the round-3 form.
 #define MI_PREFILL_STAGGER 0
 #endif
+#ifndef MI_PREFILL_LO_LATE
+// 32x32x16 kernel, SPLIT form: the lo operand (p - hi, packed) is computed beside the eight hi PV MFMAs — a half of the
+// step whose vector issue is nearly idle — instead of beside the S^T MFMAs, whose half is already bound by the vector
+// issue port (16 exponentials + their fmas + the hi packs); the lo PV MFMAs follow in a second pass over the same V
+// fragments.  0 = round 3's order (hi and lo back to back per (d-block, key half), both packs in the S^T half).
+#define MI_PREFILL_LO_LATE 1
+#endif
+#ifndef MI_PREFILL_ROTATE
+// 32x32x16 kernel, with MI_PREFILL_LO_LATE: the loop is rotated by half a step — iteration t runs [barrier] K(t+1) fragment
+// reads -> PV(t-1) (16 MFMAs from registers: V(t-1) fragments, P(t-1)) -> wait K -> masks / maximum of step t -> V(t)
+// fragment reads -> S^T(t+1) MFMAs beside the exponentials of step t -> wait V.  The K fragments' LDS latency — exposed in
+// front of the S^T MFMAs in round 3's order (phase timing: profiles/r04r_prefill_phase_timing.log) — now runs under the
+// PV MFMAs; V(t) and P(t) stay in registers across the barrier (+16 registers for the fp32 P of the lo operand).
+// Built, parity-green, and SLOWER as compiled (0.805-0.809 against 0.731-0.733 ms per layer at the 8192-token prompt,
+// profiles/r04t_prefill_rotate_ab.log): the extra live ranges push the wave past its 256 registers and hipcc spills
+// fragments to scratch inside the loop (tools/check_prefill_isa.py flags the scratch_load).  Off.
+#define MI_PREFILL_ROTATE 0
+#endif
 #ifndef MI_PREFILL_SCHED
 #define MI_PREFILL_SCHED 1   // sched_group_barrier interleave of the exponentials with the QK^T MFMAs (A/B: -DMI_PREFILL_SCHED=0)
 #endif
@@ -749,7 +767,10 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
       for (int c = 0; c < NC; ++c) s[c] = mfma32<Tag>(__builtin_bit_cast(uint4, k[ks]), qf[c][ks], s[c]);
   };
-  auto pv_mfma = [&](const u32x2_t (&o)[16]) {
+  constexpr bool LO_LATE = SPLIT && MI_PREFILL_LO_LATE && NC == 1;
+  // which: 0 = hi and lo back to back (round 3), 1 = the hi operands only, 2 = the lo operands only
+  auto pv_mfma = [&](const u32x2_t (&o)[16], auto which) {
+    constexpr int W = decltype(which)::value;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -757,9 +778,23 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
         const uint4 a = make_uint4(o[4 * n + 2 * m][0], o[4 * n + 2 * m][1], o[4 * n + 2 * m + 1][0], o[4 * n + 2 * m + 1][1]);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          acc[c][n] = mfma32<Tag>(a, pb[c][m], acc[c][n]);
-          if constexpr (SPLIT) acc[c][n] = mfma32<Tag>(a, pl_[c][m], acc[c][n]);
+          if constexpr (W != 2) acc[c][n] = mfma32<Tag>(a, pb[c][m], acc[c][n]);
+          if constexpr (SPLIT && W != 1) acc[c][n] = mfma32<Tag>(a, pl_[c][m], acc[c][n]);
         }
+      }
+  };
+  // lo = rnd16(p - hi): the subtraction is exact in fp32
+  auto lo_pack = [&](const float (&v)[NC][16]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const uint32_t w[4] = {pb[c][m].x, pb[c][m].y, pb[c][m].z, pb[c][m].w};
+        uint32_t lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          lo[i] = E::pack(v[c][8 * m + 2 * i] - E::lo(w[i]), v[c][8 * m + 2 * i + 1] - E::hi(w[i]));
+        pl_[c][m] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
       }
   };
   auto row_max = [&](const f32x16_t& s) {
@@ -821,7 +856,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
       for (int m = 0; m < 2; ++m) {
         pb[c][m] = make_uint4(E::pack(v[c][8 * m], v[c][8 * m + 1]), E::pack(v[c][8 * m + 2], v[c][8 * m + 3]),
                               E::pack(v[c][8 * m + 4], v[c][8 * m + 5]), E::pack(v[c][8 * m + 6], v[c][8 * m + 7]));
-        if constexpr (SPLIT) {   // lo = rnd16(p - hi): the subtraction is exact in fp32
+        if constexpr (SPLIT && !LO_LATE) {   // lo = rnd16(p - hi): the subtraction is exact in fp32
           const uint32_t w[4] = {pb[c][m].x, pb[c][m].y, pb[c][m].z, pb[c][m].w};
           uint32_t lo[4];
 #pragma unroll
@@ -839,6 +874,13 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
               (((v[c][8] + v[c][9]) + (v[c][10] + v[c][11])) + ((v[c][12] + v[c][13]) + (v[c][14] + v[c][15])));
   };
 
+#ifdef MI_PREFILL_TIMING
+  // phases of tools/debug_prefill_timing.py: 0 vmcnt wait, 1 barrier, 2 DMA issue, 3 K read issue + masks / maximum,
+  // 4 wait for the K fragments + V read issue, 5 S^T MFMAs + exponentials (issue), 6 wait for the V fragments, 7 PV passes
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = tprev;
+#endif
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
@@ -851,8 +893,11 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     using NEXT = std::integral_constant<int, (ST + 1) % NSTAGE>;
     if (!late) {   // waves 4-7 of a staggered workgroup meet the others between the two halves of their step (below)
       if (INT || t + 2 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
+      MI_TICK(0);
       __builtin_amdgcn_s_barrier();
+      MI_TICK(1);
       if (INT || t + 3 < t_end) issue(t + 3, (ST + 3) % NSTAGE, interior);
+      MI_TICK(2);
     }
     if (active) {
       constexpr int SN = NEXT::value * STAGE, SB = ST * STAGE;
@@ -862,10 +907,12 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
       lds_issue_b128x8<SN>(k_rd, k);
       __builtin_amdgcn_sched_barrier(0);   // the reads stay in FRONT of the work that covers their latency
       pre(t, sc[ST & 1], interior);
+      MI_TICK(3);
       lds_wait_all();
       u32x2_t o[16];
       lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
       __builtin_amdgcn_sched_barrier(0);
+      MI_TICK(4);
       qk_mfma(k, sc[(ST + 1) & 1]);
       float v[NC][16];
       expo(sc[ST & 1], v);
@@ -878,13 +925,40 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
           __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // a pack once its pair exists
         }
       }
+      MI_TICK(5);
       lds_wait_all();
+      MI_TICK(6);
       // a late wave has K(t+1) and V(t) in registers and is done with the LDS stages of this step: it meets the early
       // waves' NEXT top-of-step barrier here and runs its PV half beside their S^T / softmax half
       if (late) __builtin_amdgcn_s_barrier();
       // the PV MFMAs need nothing but P: the row sum of step t and the lane maximum of step t+1's scores (ready since
       // the S MFMAs retired) fill their gaps instead of standing in front of the next step
-      pv_mfma(o);
+      if constexpr (LO_LATE) {
+        // pass 1: the eight hi MFMAs with the lo operand's arithmetic in their gaps (8 expansions + 16 subtractions + 8
+        // packs = 40 vector instructions: five per MFMA); pass 2: the eight lo MFMAs with the row sum and the next
+        // step's lane maximum (30: four per MFMA)
+        pv_mfma(o, std::integral_constant<int, 1>{});
+        lo_pack(v);
+        if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+          for (int i = 0; i < 2 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
+          }
+        }
+        pv_mfma(o, std::integral_constant<int, 2>{});
+        row_sum(v);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(sc[(ST + 1) & 1][c]);
+        if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+          for (int i = 0; i < 2 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 2);
+          }
+        }
+      } else {
+      pv_mfma(o, std::integral_constant<int, 0>{});
       row_sum(v);
 #pragma unroll
       for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(sc[(ST + 1) & 1][c]);
@@ -895,8 +969,78 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
           __builtin_amdgcn_sched_group_barrier(0x002, SPLIT ? 2 : 3, 1);
         }
       }
+      }
+      MI_TICK(7);
     } else if (late) {
       __builtin_amdgcn_s_barrier();   // a late wave without a real column still meets the others once per step
+    }
+  };
+  // ---- rotated loop (MI_PREFILL_ROTATE): state that crosses the barrier
+  constexpr bool ROT = LO_LATE && MI_PREFILL_ROTATE;
+  u32x2_t o_keep[16];
+  float v_keep[NC][16];
+  // PV of the step whose V fragments and fp32 P are in o_keep / v_keep (hi operands in pb); `smax`: the scores whose
+  // lane maximum the next `pre` wants (nullptr in the drain behind the loop)
+  auto pv_block = [&](const f32x16_t* smax) {
+    pv_mfma(o_keep, std::integral_constant<int, 1>{});
+    lo_pack(v_keep);
+    if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+      for (int i = 0; i < 2 * NB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
+      }
+    }
+    pv_mfma(o_keep, std::integral_constant<int, 2>{});
+    row_sum(v_keep);
+    if (smax) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) mx_pre[c] = row_max(smax[c]);
+    }
+    if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+      for (int i = 0; i < 2 * NB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 2);
+      }
+    }
+  };
+  auto step_rot = [&](int t, auto stc, auto interior) {
+    constexpr int ST = decltype(stc)::value;
+    constexpr bool INT = decltype(interior)::value;
+    using NEXT = std::integral_constant<int, (ST + 1) % NSTAGE>;
+    if (INT || t + 2 < t_end) wait_vmcnt<SHARE>(); else wait_vmcnt<0>();
+    MI_TICK(0);
+    __builtin_amdgcn_s_barrier();
+    MI_TICK(1);
+    if (INT || t + 3 < t_end) issue(t + 3, (ST + 3) % NSTAGE, interior);
+    MI_TICK(2);
+    if (active) {
+      constexpr int SN = NEXT::value * STAGE, SB = ST * STAGE;
+      u32x4_t k[KS];
+      lds_issue_b128x8<SN>(k_rd, k);          // K(t+1): its latency runs under the PV MFMAs below
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > t_begin) pv_block(sc[ST & 1]);  // PV(t-1) from registers; lane maxima of step t's scores for `pre`
+      MI_TICK(3);
+      lds_wait_all();
+      MI_TICK(4);
+      pre(t, sc[ST & 1], interior);
+      lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o_keep);   // V(t): under the S^T MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      qk_mfma(k, sc[(ST + 1) & 1]);
+      expo(sc[ST & 1], v_keep);
+      if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+        for (int i = 0; i < NC * KS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+      }
+      MI_TICK(5);
+      lds_wait_all();
+      MI_TICK(6);
     }
   };
   if (MI_PREFILL_PRIO && wid >= 4) __builtin_amdgcn_s_setprio(1);
@@ -921,6 +1065,21 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   // once more after their last step (with the late waves' last mid-step barrier).
   if (late) __builtin_amdgcn_s_barrier();
   int t = t_begin;
+  if (ROT && !stag) {
+    for (; t < t_int; t += 4) {
+      step_rot(t, S0{}, std::true_type{});
+      step_rot(t + 1, S1{}, std::true_type{});
+      step_rot(t + 2, S2{}, std::true_type{});
+      step_rot(t + 3, S3{}, std::true_type{});
+    }
+    for (; t < t_end; t += 4) {
+      step_rot(t, S0{}, std::false_type{});
+      if (t + 1 < t_end) step_rot(t + 1, S1{}, std::false_type{});
+      if (t + 2 < t_end) step_rot(t + 2, S2{}, std::false_type{});
+      if (t + 3 < t_end) step_rot(t + 3, S3{}, std::false_type{});
+    }
+    if (active) pv_block(nullptr);   // the last step's PV
+  } else {
   for (; t < t_int; t += 4) {
     step(t, S0{}, std::true_type{});
     step(t + 1, S1{}, std::true_type{});
@@ -933,7 +1092,17 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     if (t + 2 < t_end) step(t + 2, S2{}, std::false_type{});
     if (t + 3 < t_end) step(t + 3, S3{}, std::false_type{});
   }
+  }
   if (stag && !late) __builtin_amdgcn_s_barrier();
+#ifdef MI_PREFILL_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mi_prefill_ticks[wid][i] = tacc[i];
+    mi_prefill_ticks[wid][8] = __builtin_amdgcn_s_memtime() - clk0;
+    mi_prefill_ticks[wid][9] = __builtin_amdgcn_s_memrealtime() - rt0;
+    mi_prefill_ticks[wid][10] = (unsigned long long)(t_end - t_begin);
+  }
+#endif
 
   // ---- epilogue: O^T -> out[token][head][dim]; lane: d = 32n + 8 * (i / 4) + 4h + i % 4
 #pragma unroll
