@@ -324,6 +324,10 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
 #endif
   f32x4_t sc0[2][NC], sc1[2][NC];
   uint4 pb[NC], pl_[NC];  // P^T operand (hi, lo) per column tile: k index 8g + j <-> key 4g + j (j < 4), 16 + 4g + j - 4
+  // MI_PREFILL_LO_LATE (as in the 32x32x16 kernel): the fp32 exponentials stay in registers until the PV half, where the
+  // row sum and the lo operand are computed in the gaps of the hi MFMAs; the lo MFMAs follow in a second pass
+  constexpr bool LO_LATE = SPLIT && MI_PREFILL_LO_LATE && (MI_PREFILL_ABLATE == 0);
+  float vk[NC][8];
   auto kread = [&](auto stc, u32x4_t (&k0)[KS], u32x4_t (&k1)[KS]) {
     constexpr int SB = decltype(stc)::value * STAGE;
     if constexpr (MI_PREFILL_ABLATE & 4) {
@@ -382,10 +386,40 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
             acc[c][4 * nb + n][0] += __builtin_bit_cast(float, a.x ^ pb[c].x) * 1e-30f;
           } else {
             acc[c][4 * nb + n] = mfma16<Tag>(a, pb[c], acc[c][4 * nb + n]);
-            if constexpr (SPLIT) acc[c][4 * nb + n] = mfma16<Tag>(a, pl_[c], acc[c][4 * nb + n]);
+            if constexpr (SPLIT && !LO_LATE) acc[c][4 * nb + n] = mfma16<Tag>(a, pl_[c], acc[c][4 * nb + n]);
           }
         }
       }
+    }
+    if constexpr (LO_LATE) {
+      // row sums and lo = rnd16(p - hi) (exact subtraction) beside the hi MFMAs above ...
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float(&v)[8] = vk[c];
+        l[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        const uint32_t w[4] = {pb[c].x, pb[c].y, pb[c].z, pb[c].w};
+        uint32_t lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lo[i] = E::pack(v[2 * i] - E::lo(w[i]), v[2 * i + 1] - E::hi(w[i]));
+        pl_[c] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      }
+      if constexpr (MI_PREFILL_SCHED) {
+#pragma unroll
+        for (int i = 0; i < NT * NC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
+          __builtin_amdgcn_sched_group_barrier(0x002, (27 * NC + NT * NC - 1) / (NT * NC), 3);
+        }
+      }
+      // ... then the lo MFMAs over the same V fragments
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int nb = 0; nb < NT / 4; ++nb)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const uint4 a = make_uint4(a0[nb][n][0], a0[nb][n][1], a1[nb][n][0], a1[nb][n][1]);
+            acc[c][4 * nb + n] = mfma16<Tag>(a, pl_[c], acc[c][4 * nb + n]);
+          }
     }
   };
   // masks, lane-local maximum, the rare raise: everything of step t's softmax that branches
@@ -444,9 +478,14 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
           v[r] = fast_exp2(__builtin_fmaf(s0[c][r], p.scale_log2e, nms[c]));
           v[4 + r] = fast_exp2(__builtin_fmaf(s1[c][r], p.scale_log2e, nms[c]));
         }
-        l[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        if constexpr (LO_LATE) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) vk[c][r] = v[r];
+        } else {
+          l[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
         pb[c] = make_uint4(E::pack(v[0], v[1]), E::pack(v[2], v[3]), E::pack(v[4], v[5]), E::pack(v[6], v[7]));
-        if constexpr (SPLIT) {   // lo = rnd16(p - hi): the subtraction is exact in fp32
+        if constexpr (SPLIT && !LO_LATE) {   // lo = rnd16(p - hi): the subtraction is exact in fp32
           const uint32_t w[4] = {pb[c].x, pb[c].y, pb[c].z, pb[c].w};
           uint32_t lo[4];
 #pragma unroll
