@@ -284,6 +284,53 @@ def test_rope_fused_decode_full_size_equals_the_two_launches_and_the_oracle(dev,
     assert e["atol_needed_at_rtol_1e-3"] <= 2 * _BOUNDS[("fast", dtype)], e
 
 
+@pytest.mark.parametrize("nq,nkv,d,part", [(28, 4, 128, 0), (7, 1, 128, 512), (16, 2, 64, 0)], ids=["S-A", "S-A-tp4-rank", "S-B"])
+def test_rope_fused_decode_ragged_batch_equals_the_two_launches(dev, nq, nkv, d, part):
+    """The fused RoPE + KV-write + decode launch on a RAGGED full-size batch (256 sequences of 1 .. 4096 tokens, some
+    inert rows, every residue of the last token's position mod the KV block and mod the 32-token step, several
+    partitions per sequence in the TP-4 geometry): the wave that owns each sequence's last partition differs per row —
+    output and both caches bit-identical to the two launches, three times over on the same caches (the step appends)."""
+    from vllm_omni_amd import ops
+    from vllm_omni_amd.layers import build_cos_sin_cache
+
+    B, dtype = 256, torch.bfloat16
+    rng = np.random.default_rng(5)
+    lens = [int(x) for x in rng.integers(1, 4094, size=B)]
+    for i in range(0, B, 37):
+        lens[i] = 0                                     # inert rows of a bucketed graph replay
+    for i, n in enumerate([1, 2, 15, 16, 17, 31, 32, 33, 511, 512, 513, 1024, 1025, 2047, 2048, 2049, 4093]):
+        lens[3 + 5 * i] = n
+    bound = 4112
+    table, nb = _table(B, [bound] * B, seed=23, max_blocks=(bound + BS - 1) // BS)
+    g = torch.Generator(device=dev).manual_seed(31)
+    kv_a = torch.empty(nb, 2, nkv, BS, d, dtype=dtype, device=dev).normal_(0.0, 1.0, generator=g)
+    kv_b = kv_a.clone()
+    views = lambda kv: (kv[:, 0].permute(0, 2, 1, 3), kv[:, 1].permute(0, 2, 1, 3))   # noqa: E731
+    (kb_a, vb_a), (kb_b, vb_b) = views(kv_a), views(kv_b)
+    csc = build_cos_sin_cache(d, 8192, 1e6, device=dev)
+    tb = table.to(dev)
+    for step in range(3):
+        cur = [n + step if n > 0 else 0 for n in lens]
+        pos = torch.tensor([max(n - 1, 0) for n in cur], dtype=torch.int64, device=dev)
+        slots = torch.tensor([int(table[i, (n - 1) // BS]) * BS + (n - 1) % BS if n > 0 else -1 for i, n in enumerate(cur)],
+                             dtype=torch.int64, device=dev)
+        lens_d = torch.tensor(cur, dtype=torch.int32, device=dev)
+        qkv = torch.randn(B, (nq + 2 * nkv) * d, device=dev, generator=g).to(dtype)
+        row = qkv.clone()
+        q, k, v = row.split([nq * d, nkv * d, nkv * d], dim=-1)
+        ops.rope_neox_and_cache(q, k, v, pos, csc, d, kb_a, vb_a, slots)
+        out_two = torch.empty(B, nq * d, dtype=dtype, device=dev)
+        ops.paged_attn_decode(out_two, q, kb_a, vb_a, tb, lens_d, bound, d ** -0.5, partition_size=part)
+        q2, k2, v2 = qkv.split([nq * d, nkv * d, nkv * d], dim=-1)
+        out_one = torch.empty_like(out_two)
+        ops.rope_cache_paged_attn_decode(out_one, q2, k2, v2, pos, csc, kb_b, vb_b, slots, tb, lens_d, bound, d ** -0.5,
+                                         partition_size=part)
+        torch.cuda.synchronize()
+        assert torch.equal(kv_a, kv_b), f"step {step}: cache contents differ"
+        assert torch.equal(out_one, out_two), f"step {step}: attention outputs differ"
+    assert torch.isfinite(out_one.float()).all()
+
+
 # ------------------------------------------------------------------ config #4: 8192-token chunked prefill
 def _prefill_chunks(dev, q, kb, vb, table, total, chunk):
     from vllm_omni_amd import ops
