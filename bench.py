@@ -332,14 +332,17 @@ def time_decode_kernel(runner, reps: int = 4):
     q, k, v = qkv.split([nq * d, attn0.attn.num_kv_heads * d, attn0.attn.num_kv_heads * d], dim=-1)
     out = torch.empty(n, nq * d, dtype=torch.bfloat16, device=runner.device)
     rope = attn0.rotary_pos_emb
-    fused = ops.rope_decode_fusable(q, attn0.attn._kb, pos, rope.cos_sin_cache.shape[1], 0, n, bound) and attn0.q_norm is None
+    fused = ops.rope_decode_fusable(q, attn0.attn._kb, pos, rope.cos_sin_cache.shape[1], 0, n, bound)
 
     def one_pass():
         for ly in layers:
             at = ly.self_attn.attn
             if fused:
+                sa = ly.self_attn
                 ops.rope_cache_paged_attn_decode(out, q, k, v, pos, rope.cos_sin_cache, at._kb, at._vb, slots, table, lens,
-                                                 bound, at.scale, workspace=runner._decode_ws, _skip_merge=True)
+                                                 bound, at.scale, workspace=runner._decode_ws, _skip_merge=True,
+                                                 q_norm_weight=sa.q_norm.weight if sa.q_norm else None,
+                                                 k_norm_weight=sa.k_norm.weight if sa.k_norm else None, norm_eps=sa.norm_eps)
             else:
                 ops.paged_attn_decode(out, q, at._kb, at._vb, table, lens, bound, at.scale, workspace=runner._decode_ws,
                                       _skip_merge=True)

@@ -213,11 +213,14 @@ int mi_paged_attn_decode(void* out, const void* q, const void* k_cache, const vo
  * stores before it starts streaming — no other wave of the launch reads that row.  Result and cache contents equal
  * mi_rope_neox_and_cache followed by mi_paged_attn_decode bit for bit; q is left un-rotated in memory.  Matrix-core
  * kernel only (flags: PACKED_PV | NONTEMPORAL, no ROUNDED_P / FORCE_VALU; block_size >= 16; partition % 32 == 0),
- * rot_dim == head_dim, 1-D positions, no q/k-norm: MI_ERR_UNSUPPORTED otherwise (callers run the two launches).
+ * rot_dim == head_dim, 1-D positions: MI_ERR_UNSUPPORTED otherwise (callers run the two launches).  q_norm_weight /
+ * k_norm_weight (both or neither, [head_dim]): the Qwen3 family's per-head RMSNorm in front of the rotation, as in
+ * mi_rope_neox_and_cache.
  * Replaces the rotary_pos_emb + attn pair of qwen2_old.py:153-154 on decode steps. */
 int mi_rope_cache_paged_attn_decode(void* out, const void* q, const void* k, const void* v,
                                     const int64_t* positions, const float* cos_sin_cache,
-                                    int32_t max_position, int32_t rot_dim, void* k_cache, void* v_cache,
+                                    int32_t max_position, int32_t rot_dim, const void* q_norm_weight,
+                                    const void* k_norm_weight, float norm_eps, void* k_cache, void* v_cache,
                                     const int64_t* slot_mapping, const int32_t* block_table,
                                     const int32_t* seq_lens, int32_t num_seqs, int32_t num_q_heads,
                                     int32_t num_kv_heads, int32_t head_dim, int32_t block_size,

@@ -379,10 +379,11 @@ ROPE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("qk_norm", [False, True], ids=["plain", "qk-norm"])
 @pytest.mark.parametrize("layout", ["nb2", "head_major"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", ROPE_CASES)
-def test_rope_fused_decode_equals_the_two_launches_bit_for_bit(dev, case, dtype, layout):
+def test_rope_fused_decode_equals_the_two_launches_bit_for_bit(dev, case, dtype, layout, qk_norm):
     """q rotated in registers + the token's k / v written by the owning wave + attention == rope_neox_and_cache followed
     by paged_attn_decode: output, K cache and V cache bit for bit (and therefore inside the oracle tolerance the two
     launches are tested at), un-rotated q left alone, rows with slot -1 write nothing."""
@@ -398,6 +399,9 @@ def test_rope_fused_decode_equals_the_two_launches_bit_for_bit(dev, case, dtype,
     slots = torch.tensor([int(table[i, (n - 1) // bs]) * bs + (n - 1) % bs if n > 0 else -1 for i, n in enumerate(lens)],
                          dtype=torch.int64)
     msl = max(max(lens), 1)
+    # the Qwen3 family's per-head q / k RMSNorm in front of the rotation (modeling_qwen3_omni_moe.py:1451-1456)
+    qn = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(dev) if qk_norm else None
+    kn = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype).to(dev) if qk_norm else None
 
     def caches():
         kvg = kv.to(dev).clone()
@@ -414,16 +418,20 @@ def test_rope_fused_decode_equals_the_two_launches_bit_for_bit(dev, case, dtype,
         if fused:
             assert ops.rope_decode_fusable(q, kc, pos, d, ps, S, msl)
             ops.rope_cache_paged_attn_decode(out, q, k, v, pos.to(dev), csc, kc, vc, slots.to(dev), table.to(dev),
-                                             seq_lens.to(dev), msl, d ** -0.5, partition_size=ps)
+                                             seq_lens.to(dev), msl, d ** -0.5, partition_size=ps, q_norm_weight=qn,
+                                             k_norm_weight=kn, norm_eps=1e-6)
             assert torch.equal(row, qkv)                      # q / k / v rows are inputs only
         else:
-            ops.rope_neox_and_cache(q, k, v, pos.to(dev), csc, d, kc, vc, slots.to(dev))
+            ops.rope_neox_and_cache(q, k, v, pos.to(dev), csc, d, kc, vc, slots.to(dev), q_norm_weight=qn, k_norm_weight=kn,
+                                    norm_eps=1e-6)
             ops.paged_attn_decode(out, q, kc, vc, table.to(dev), seq_lens.to(dev), msl, d ** -0.5, partition_size=ps)
         torch.cuda.synchronize()
         outs.append((out.cpu(), store.cpu()))
     assert torch.equal(outs[0][1], outs[1][1]), "cache contents differ"
     assert not torch.equal(outs[1][1], kv), "nothing was written"
     assert torch.equal(outs[0][0], outs[1][0]), "attention outputs differ"
+    if qk_norm:
+        return   # the two launches with q/k-norm have their own oracle test (test_gpu_layer_ops.py); equality is the claim here
     # and against the oracle chain on the same inputs
     q0, k0, v0 = qkv.cpu().split([nq * d, nkv * d, nkv * d], dim=-1)
     live = [i for i, n in enumerate(lens) if n > 0]

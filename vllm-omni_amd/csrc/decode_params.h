@@ -34,6 +34,10 @@ struct DecodeParams {
   const float* cos_sin = nullptr;          // [max_position, head_dim] = cos | sin
   int32_t max_position = 0;
   int64_t kn_stride = 0, vn_stride = 0;
+  // ... with the per-head q / k RMSNorm of the Qwen3 family in front of the rotation (both or neither; weights [head_dim])
+  const void* q_norm_w = nullptr;
+  const void* k_norm_w = nullptr;
+  float norm_eps = 0.f;
 };
 
 // paged_attn_decode_mfma.hip

@@ -541,6 +541,9 @@ struct RopeFusion {
   const float* cos_sin;
   int32_t max_position;
   int64_t k_stride, v_stride;
+  const void* q_norm_w;
+  const void* k_norm_w;
+  float norm_eps;
 };
 
 int decode_call(void* out, const void* q, const void* k_cache, const void* v_cache, const int32_t* block_table,
@@ -629,6 +632,7 @@ int decode_call(void* out, const void* q, const void* k_cache, const void* v_cac
     p.positions = rope->positions; p.slot_mapping = rope->slot_mapping;
     p.cos_sin = rope->cos_sin; p.max_position = rope->max_position;
     p.kn_stride = rope->k_stride; p.vn_stride = rope->v_stride;
+    p.q_norm_w = rope->q_norm_w; p.k_norm_w = rope->k_norm_w; p.norm_eps = rope->norm_eps;
     rc = launch_decode_mfma_rope(p, G, head_dim, dtype, s);
   } else if (use_mfma) {
     rc = launch_decode_mfma(p, G, head_dim, dtype, (flags & MI_DECODE_NONTEMPORAL) != 0,
@@ -668,7 +672,8 @@ extern "C" int mi_paged_attn_decode(void* out, const void* q, const void* k_cach
 
 extern "C" int mi_rope_cache_paged_attn_decode(void* out, const void* q, const void* k, const void* v,
                                                const int64_t* positions, const float* cos_sin_cache,
-                                               int32_t max_position, int32_t rot_dim, void* k_cache, void* v_cache,
+                                               int32_t max_position, int32_t rot_dim, const void* q_norm_weight,
+                                               const void* k_norm_weight, float norm_eps, void* k_cache, void* v_cache,
                                                const int64_t* slot_mapping, const int32_t* block_table,
                                                const int32_t* seq_lens, int32_t num_seqs, int32_t num_q_heads,
                                                int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
@@ -681,9 +686,12 @@ extern "C" int mi_rope_cache_paged_attn_decode(void* out, const void* q, const v
   if (num_seqs == 0) return MI_OK;
   if (!k || !v || !positions || !cos_sin_cache || !slot_mapping || max_position <= 0) return MI_ERR_INVALID_ARG;
   if (rot_dim != head_dim) return MI_ERR_UNSUPPORTED;   // partial rotary: use the two launches
+  if ((q_norm_weight == nullptr) != (k_norm_weight == nullptr)) return MI_ERR_INVALID_ARG;
+  if (((uintptr_t)q_norm_weight | (uintptr_t)k_norm_weight) & 15) return MI_ERR_INVALID_ARG;
   if (k_token_stride % 8 || v_token_stride % 8 || (((uintptr_t)k | (uintptr_t)v | (uintptr_t)cos_sin_cache) & 15))
     return MI_ERR_INVALID_ARG;
-  const RopeFusion rf{k, v, positions, slot_mapping, cos_sin_cache, max_position, k_token_stride, v_token_stride};
+  const RopeFusion rf{k, v, positions, slot_mapping, cos_sin_cache, max_position, k_token_stride, v_token_stride,
+                      q_norm_weight, k_norm_weight, norm_eps};
   return decode_call(out, q, k_cache, v_cache, block_table, seq_lens, num_seqs, num_q_heads, num_kv_heads, head_dim,
                      block_size, block_table_stride, max_seq_len, scale, q_token_stride, out_token_stride,
                      cache_block_stride, cache_token_stride, cache_head_stride, partition_size, workspace,

@@ -97,7 +97,37 @@ __device__ __forceinline__ void rope_rotate8(uint4& xr, uint4& yr, const float* 
   yr = pack8<Tag>(oy);
 }
 
-template <typename Tag, int HD, int AUX, bool SPLIT, int NS, bool ROPE = false>
+// Per-head RMSNorm of one rotate-item (x = dims [8 j, 8 j + 8), y = their rotate-half partners) given the head's
+// 1 / rms: fp32 normalise -> round to the dtype -> x weight in the dtype (HF order) — rope_cache_kernel's NORM arithmetic
+template <typename Tag>
+__device__ __forceinline__ void head_norm8(uint4& xr, uint4& yr, float inv, const uint16_t* w, int j0, int half) {
+  using E = Elem<Tag>;
+  float x[8], y[8], wx[8], wy[8];
+  unpack8<Tag>(xr, x);
+  unpack8<Tag>(yr, y);
+  unpack8<Tag>(*reinterpret_cast<const uint4*>(w + j0), wx);
+  unpack8<Tag>(*reinterpret_cast<const uint4*>(w + half + j0), wy);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    x[e] = E::from_bits(E::to_bits(E::from_bits(E::to_bits(x[e] * inv)) * wx[e]));
+    y[e] = E::from_bits(E::to_bits(E::from_bits(E::to_bits(y[e] * inv)) * wy[e]));
+  }
+  xr = pack8<Tag>(x);
+  yr = pack8<Tag>(y);
+}
+// sum of squares of one rotate-item, in rope_cache_kernel's order
+template <typename Tag>
+__device__ __forceinline__ float item_sumsq(const uint4& xr, const uint4& yr) {
+  float x[8], y[8];
+  unpack8<Tag>(xr, x);
+  unpack8<Tag>(yr, y);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ss += x[e] * x[e] + y[e] * y[e];
+  return ss;
+}
+
+template <typename Tag, int HD, int AUX, bool SPLIT, int NS, bool ROPE = false, bool NORM = false>
 __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p, const int gh) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
@@ -196,6 +226,14 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
     if (lane < RI) {
       const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new) + (int64_t)seq * p.kn_stride + kvh * HD;
       uint4 x = *reinterpret_cast<const uint4*>(kn + 8 * lane), y = *reinterpret_cast<const uint4*>(kn + HD / 2 + 8 * lane);
+      if constexpr (NORM) {   // the RI lanes of the head: rope_cache_kernel's reduction, lane for lane
+        float ss = item_sumsq<Tag>(x, y);
+        ss += dpp_f32<kDppQuadXor1>(ss);
+        ss += dpp_f32<kDppQuadXor2>(ss);
+        if constexpr (RI == 8) ss += dpp_f32<kDppRowHalfMirror>(ss);
+        const float inv = __builtin_amdgcn_rsqf(ss / (float)HD + p.norm_eps);
+        head_norm8<Tag>(x, y, inv, reinterpret_cast<const uint16_t*>(p.k_norm_w), 8 * lane, HD / 2);
+      }
       rope_rotate8<Tag>(x, y, rope_row, 8 * lane, HD / 2);
       uint16_t* kc = reinterpret_cast<uint16_t*>(const_cast<void*>(p.k_cache)) + crow;
       *reinterpret_cast<uint4*>(kc + 8 * lane) = x;
@@ -436,6 +474,25 @@ __global__ __launch_bounds__(64, 2) void decode_mfma_kernel(const DecodeParams p
   }
   if constexpr (ROPE) {
     // q: dims 32 s + 8 g .. of head h pair with dims + HD / 2 = fragment s + KS / 2 of the same lane
+    if constexpr (NORM) {
+      // the head's 64 / 128 dims sit in the lanes g = 0..3 of column h (lanes 16 apart): item j = 4 s + g of the rope
+      // kernel is fragments (s, s + KS / 2) of lane g.  Its reduction — quad xor 1, xor 2 over j (, then the two halves
+      // of eight) — is reproduced with the same pairing: g ^ 1 (lane ^ 16), g ^ 2 (lane ^ 32), then s = 0 + s = 1.
+      float tot = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS / 2; ++s) {
+        float ss = head_ok ? item_sumsq<Tag>(qf[s], qf[s + KS / 2]) : 0.f;
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        tot = s == 0 ? ss : tot + ss;
+      }
+      const float inv = __builtin_amdgcn_rsqf(tot / (float)HD + p.norm_eps);
+      if (head_ok) {
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s)
+          head_norm8<Tag>(qf[s], qf[s + KS / 2], inv, reinterpret_cast<const uint16_t*>(p.q_norm_w), 32 * s + 8 * g, HD / 2);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < KS / 2; ++s) rope_rotate8<Tag>(qf[s], qf[s + KS / 2], rope_row, 32 * s + 8 * g, HD / 2);
     if (kv_owner && !kv_early) {
@@ -592,6 +649,16 @@ int launch_decode_mfma_rope(const DecodeParams& p, int gh, int head_dim, int dty
   const int64_t waves = (int64_t)p.num_seqs * (p.num_q_heads / gh) * p.num_parts;
   if (waves > INT32_MAX) return MI_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)waves), block(64);
+  if (p.q_norm_w) {   // per-head q / k RMSNorm in front of the rotation (Qwen3 family)
+    if (dtype == MI_DTYPE_BF16) {
+      if (head_dim == 128) hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 128, 2, true, 2, true, true>), grid, block, 0, stream, p, gh);
+      else hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 64, 2, true, MI_DECODE_NS64, true, true>), grid, block, 0, stream, p, gh);
+    } else {
+      if (head_dim == 128) hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 128, 2, true, 2, true, true>), grid, block, 0, stream, p, gh);
+      else hipLaunchKernelGGL((decode_mfma_kernel<f16_tag, 64, 2, true, MI_DECODE_NS64, true, true>), grid, block, 0, stream, p, gh);
+    }
+    return launch_status();
+  }
   if (dtype == MI_DTYPE_BF16) {
     if (head_dim == 128) hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 128, 2, true, 2, true>), grid, block, 0, stream, p, gh);
     else hipLaunchKernelGGL((decode_mfma_kernel<bf16_tag, 64, 2, true, MI_DECODE_NS64, true>), grid, block, 0, stream, p, gh);

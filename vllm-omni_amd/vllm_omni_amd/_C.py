@@ -57,7 +57,7 @@ SIGNATURES = {
                                       c_int32, c_int32, c_int32, c_float, c_int64, c_int64,
                                       c_int64, c_int64, c_int64, c_int32, _P, c_int64, c_int,
                                       c_int, c_int32, _P]),
-    "mi_rope_cache_paged_attn_decode": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32,
+    "mi_rope_cache_paged_attn_decode": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, c_float, _P, _P, _P, _P, _P, c_int32, c_int32,
                                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int64, c_int64,
                                                  c_int64, c_int64, c_int64, c_int64, c_int64, c_int32, _P, c_int64, c_int,
                                                  c_int, c_int32, _P]),

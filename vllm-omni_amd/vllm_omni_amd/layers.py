@@ -248,10 +248,10 @@ class Attention:
 
     def rope_decode_fusable(self, rope: RotaryEmbedding, positions: torch.Tensor, q_norm_weight=None) -> bool:
         """Whether this step's RoPE + KV write run inside the paged-attention launch (``ops.rope_cache_paged_attn_decode``):
-        a pure-decode step on the production decode kernel, plain positions, no q/k-norm, not a single-block sequence
+        a pure-decode step on the production decode kernel, plain positions (q/k-norm rides along), not a single-block sequence
         (those have their own fused launch).  qkv_proj then hands over a 16-bit row, not split-K partials."""
         md = get_forward_context().attn_metadata
-        if md is None or md.single_block or q_norm_weight is not None or positions.dim() != 1:
+        if md is None or md.single_block or positions.dim() != 1:
             return False
         nd = md.num_decodes
         return (nd > 0 and nd == md.num_reqs and md.num_actual_tokens == nd
@@ -284,7 +284,8 @@ class Attention:
             ops.rope_cache_paged_attn_decode(out[:nd], q[:nd], k[:nd], v[:nd], positions[:nd], rope.cos_sin_cache, self._kb,
                                              self._vb, md.slot_mapping[:nd], md.block_table[:nd], md.seq_lens[:nd],
                                              md.max_seq_len, self.scale, partition_size=md.decode_partition_size,
-                                             workspace=md.decode_workspace)
+                                             workspace=md.decode_workspace, q_norm_weight=q_norm_weight,
+                                             k_norm_weight=k_norm_weight, norm_eps=norm_eps)
             return out
         ops.rope_neox_and_cache(q, k, v, positions, rope.cos_sin_cache, self.head_size, self._kb, self._vb,
                                 md.slot_mapping, mrope_section=sec, q_norm_weight=q_norm_weight,

@@ -336,11 +336,16 @@ def rope_cache_paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k: torch.Te
                                  positions: torch.Tensor, cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
                                  v_cache: torch.Tensor, slot_mapping: torch.Tensor, block_table: torch.Tensor,
                                  seq_lens: torch.Tensor, max_seq_len: int, scale: float, partition_size: int = 0,
-                                 workspace: Optional[torch.Tensor] = None, _skip_merge: bool = False) -> torch.Tensor:
+                                 workspace: Optional[torch.Tensor] = None, _skip_merge: bool = False,
+                                 q_norm_weight: Optional[torch.Tensor] = None, k_norm_weight: Optional[torch.Tensor] = None,
+                                 norm_eps: float = 1e-6) -> torch.Tensor:
     """``rope_neox_and_cache`` + ``paged_attn_decode`` of a pure-decode step in ONE launch (same bits): q is rotated in
     registers (the tensor keeps its un-rotated values), the token's rotated k and its v are written to the cache by the
     wave that owns the sequence's last context partition.  q [S, nq*d], k / v [S, nkv*d]: views of the qkv row."""
-    _gpu(out, q, k, v, positions, cos_sin_cache, k_cache, v_cache, slot_mapping, block_table, seq_lens, workspace)
+    _gpu(out, q, k, v, positions, cos_sin_cache, k_cache, v_cache, slot_mapping, block_table, seq_lens, workspace,
+         q_norm_weight, k_norm_weight)
+    if (q_norm_weight is None) != (k_norm_weight is None):
+        raise ValueError("q_norm_weight and k_norm_weight come together")
     nb, bs, hkv, d = k_cache.shape
     s = q.shape[0]
     if s == 0:
@@ -360,7 +365,8 @@ def rope_cache_paged_attn_decode(out: torch.Tensor, q: torch.Tensor, k: torch.Te
         workspace = new_decode_workspace(need, q.device)
     fused_merge = DECODE_FUSED_MERGE and _decode_ws_ready(workspace)
     check("mi_rope_cache_paged_attn_decode", lib.mi_rope_cache_paged_attn_decode(
-        _p(out), _p(q), _p(k), _p(v), _p(positions), _p(cos_sin_cache), max_pos, rot_dim, _p(k_cache), _p(v_cache),
+        _p(out), _p(q), _p(k), _p(v), _p(positions), _p(cos_sin_cache), max_pos, rot_dim, _p(q_norm_weight),
+        _p(k_norm_weight), float(norm_eps), _p(k_cache), _p(v_cache),
         _p(slot_mapping), _p(block_table), _p(seq_lens), s, nq, hkv, d, bs, block_table.stride(0), int(max_seq_len),
         float(scale), q.stride(0), k.stride(0), v.stride(0), out.stride(0), cb, ct, ch, int(partition_size), _p(workspace),
         workspace.numel() * workspace.element_size() if workspace is not None else 0, _dt(q.dtype), _dt(out.dtype),
