@@ -101,11 +101,13 @@ def test_prefill_flattened_columns_many_sequences(dev, dtype):
     torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("d", [128, 64])
 @pytest.mark.parametrize("nq,nkv", [(10, 2), (12, 2), (6, 2), (5, 1), (3, 1)])
-def test_prefill_gqa_groups_that_are_not_powers_of_two(dev, nq, nkv):
+def test_prefill_gqa_groups_that_are_not_powers_of_two(dev, nq, nkv, d):
     """G = 5, 6, 3 on a small grid: the group is split over two workgroups (3 + 2, 3 + 3 heads) or kept (3), and 3
-    heads run as 4 waves x 32 columns = 3 x 42 tokens; 80-token chunks leave a 38-token last tile."""
-    got, ref = _case(dev, nq, nkv, 16, [0, 25, 90], [80, 43, 7], torch.bfloat16, seed=13)
+    heads run as 4 waves x 32 columns = 3 x 42 tokens; 80-token chunks leave a 38-token last tile.  Both head sizes of
+    the 32x32x16 kernel (128-B rows at head_dim 64: its own K / V images and fragment reads)."""
+    got, ref = _case(dev, nq, nkv, 16, [0, 25, 90], [80, 43, 7], torch.bfloat16, seed=13, d=d)
     assert torch.isfinite(got).all()
     torch.testing.assert_close(got, ref, rtol=_tol(torch.bfloat16)[0], atol=_tol(torch.bfloat16)[1])
 
@@ -116,7 +118,7 @@ SPLIT_CASES = [
     (28, 4, 128, [300, 0, 2100], [40, 130, 5], 3),   # sequences of very different lengths: some tiles fit one segment
     (7, 1, 128, [513], [129], 5),                  # one KV head (a TP=4 rank); a segment boundary inside a tile's diagonal
     (8, 8, 128, [250], [20], 2),                   # MHA: one-wave workgroups
-    (16, 2, 64, [900], [64], 4),                   # head_dim 64: the 16x16x32 kernel
+    (16, 2, 64, [900], [64], 4),                   # head_dim 64: the 32x32x16 kernel on 128-B rows
     (16, 2, 64, [700, 64], [9, 16], 3),            # chunks <= 16 tokens: 16-token tiles
     (28, 4, 128, [2000], [8], 6),                  # a speculative-verify-sized chunk on a long context (16-token tiles)
 ]

@@ -225,6 +225,45 @@ __device__ __forceinline__ void lds_issue_tr4x4(const uint32_t (&addr)[4], u32x2
       : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(I0), "i"(I1), "i"(I2), "i"(I3)
       : "memory");
 }
+// head_dim 64 forms of the three above: 4 k-steps of a 32-row K tile; 2 d-blocks x 4 row offsets of the V tile.
+template <int IMM>
+__device__ __forceinline__ void lds_read_b128x4(const uint32_t (&addr)[4], u32x4_t (&r)[4]) {
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%8\n\t"
+      "ds_read_b128 %1, %5 offset:%8\n\t"
+      "ds_read_b128 %2, %6 offset:%8\n\t"
+      "ds_read_b128 %3, %7 offset:%8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(IMM)
+      : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void lds_issue_b128x4(const uint32_t (&addr)[4], u32x4_t (&r)[4]) {
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%8\n\t"
+      "ds_read_b128 %1, %5 offset:%8\n\t"
+      "ds_read_b128 %2, %6 offset:%8\n\t"
+      "ds_read_b128 %3, %7 offset:%8"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+      : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "i"(IMM)
+      : "memory");
+}
+template <int I0, int I1, int I2, int I3>
+__device__ __forceinline__ void lds_issue_tr2x4(const uint32_t (&addr)[2], u32x2_t (&o)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %9 offset:%10\n\t"
+      "ds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %9 offset:%13"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(addr[0]), "v"(addr[1]), "i"(I0), "i"(I1), "i"(I2), "i"(I3)
+      : "memory");
+}
 __device__ __forceinline__ void lds_wait_all() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);

@@ -24,8 +24,8 @@
 //   * the causal mask is per lane (column = query token); only steps that touch a column tile's
 //     diagonal evaluate it; the context loop stops at the last position any column may see; tiles
 //     are dispatched longest first over all kv heads;
-//   * head_dim 128 with chunks longer than 16 tokens runs the 32x32x16 formulation further down
-//     (`prefill_mfma32_kernel`): same ring, same DMA, one 32-column tile per wave;
+//   * chunks longer than 16 tokens run the 32x32x16 formulation further down (`prefill_mfma32_kernel`, both head
+//     sizes): same ring, same DMA, one 32-column tile per wave;
 //   * a launch too small to fill the chip (the ragged last chunk of a long prompt, a TP shard with one KV head) cuts
 //     every tile's keys into segments — separate workgroups of the same kernels over a key range, normalised fp32
 //     partials + log-sum-exp in a workspace — and `prefill_merge_kernel` combines them (`prefill_plan` decides).
@@ -607,9 +607,11 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The 32x32x16 formulation: head_dim 128, chunks longer than one 16-token tile.  Same ring, same DMA, same K image;
+// The 32x32x16 formulation: chunks longer than one 16-token tile.  Same ring, same DMA, same K image;
 // what changes is the shape of the matrix instruction — a wave's 32 query tokens are ONE 32-column tile:
-//   S^T (32 keys x 32 queries) = 8 MFMAs 32x32x16 over d;  O^T (128 d x 32 queries) += 4 d-blocks x 2 key halves.
+//   S^T (32 keys x 32 queries) = 8 MFMAs 32x32x16 over d;  O^T (128 d x 32 queries) += 4 d-blocks x 2 key halves
+// (head_dim 64: 4 MFMAs and 2 d-blocks — measured 0.296 -> 0.278 ms per layer against the 16x16x32 kernel at the 8192-token
+// prompt of 16 / 2 heads, 0.564 -> 0.519 at 32 / 4: profiles/r04_prefill_d64_mfma32.log).
 // Why: the step is bound by the SIMD's vector issue port, which an MFMA holds for 8 cycles whether it computes 16 or 32
 // cycles (MI355X_MICROARCH.md, constants table).  16 MFMAs of 32 cycles leave 16 x 24 = 384 issue cycles per wave and
 // step for the ~320 the softmax needs; 32 MFMAs of 16 cycles left 256.
@@ -627,11 +629,10 @@ __global__ __launch_bounds__(512) void prefill_mfma_kernel(const PrefillParams p
 // significant bits instead of 8 / 11), one extra MFMA per (d-block, key half) against the same V operand — what brings the
 // kernel inside rtol 1e-3 / atol 1e-4 of the fp32 oracle, as the decode kernel's split does.  SPLIT = false is the
 // single-rounding P of flash kernels (`dot(P.to(V.dtype), V)`), kept for A/B (MI_PREFILL_ROUNDED_P=1).
-template <typename Tag, int NI, int NC, bool SPLIT>
+template <typename Tag, int HD, int NI, int NC, bool SPLIT>
 __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(const PrefillParams p) {
   scalar_cache_acquire();
   using E = Elem<Tag>;
-  constexpr int HD = 128;
   const int QT = p.qt;               // query tokens per workgroup
   constexpr int ROWB = HD * 2;
   constexpr int KS = HD / 16;        // k-steps of S^T
@@ -711,15 +712,18 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   // ---- per-lane LDS read addresses
   uint32_t k_rd[KS];   // K row `col`, chunk 2s + h (dims 16s + 8h ..), swizzled by row & 15: a b128 lane group = 16 rows x 16 chunks
 #pragma unroll
-  for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(col * ROWB + (((2 * s + h) ^ (col & 15)) * 16));
+  for (int s = 0; s < KS; ++s) k_rd[s] = (uint32_t)(col * ROWB + (((2 * s + h) ^ swz_k<HD>(col)) * 16));
   const int j16 = lane & 15, db = (lane >> 4) & 1, rho = j16 >> 2;
   uint32_t v_rd[NB];   // V row 4h + rho (+ 16m + 8r as an immediate), dims 32n + 16db + 4 * (j16 & 3) ..
 #pragma unroll
   for (int n = 0; n < NB; ++n)
-    v_rd[n] = (uint32_t)(IMG + (4 * h + rho) * ROWB + ((((n ^ rho) << 2) + 2 * db + ((j16 & 3) >> 1)) * 16) + 8 * (j16 & 1));
+    v_rd[n] = (uint32_t)(IMG + (4 * h + rho) * ROWB + ((((n ^ (HD == 128 ? rho : rho >> 1)) << 2) + 2 * db + ((j16 & 3) >> 1)) * 16) +
+                         8 * (j16 & 1));
 
-  // ---- DMA issue (as in the 16x16x32 kernel; only the V swizzle differs)
-  auto swz_v32 = [](int r) { return (r & 3) << 2; };
+  // ---- DMA issue (as in the 16x16x32 kernel; only the V swizzle differs).  head_dim 64: a row is two 64-B segments and
+  // two rows share a 256-B bank row, so the segment is XORed with bit 1 of the row — the 32 lanes of an LDS cycle (rows
+  // r .. r+3, one segment each) then cover (row & 1) x (segment ^ (row >> 1)) = all four 64-B quarters of two bank rows.
+  auto swz_v32 = [](int r) { return HD == 128 ? (r & 3) << 2 : ((r >> 1) & 1) << 2; };
   // staggered: eight waves, the second half one half-step behind the first (see MI_PREFILL_STAGGER)
   const bool stag = MI_PREFILL_STAGGER && NC == 1 && blockDim.x == 512;
   const bool late = stag && wid >= 4;                                  // wave-uniform
@@ -795,7 +799,22 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   f32x16_t sc[2][NC];
   uint4 pb[NC][2], pl_[NC][2];
 
-  auto kread = [&](auto stc, u32x4_t (&k)[KS]) { lds_read_b128x8<decltype(stc)::value * STAGE>(k_rd, k); };
+  auto kread = [&](auto stc, u32x4_t (&k)[KS]) {
+    if constexpr (KS == 8) lds_read_b128x8<decltype(stc)::value * STAGE>(k_rd, k);
+    else lds_read_b128x4<decltype(stc)::value * STAGE>(k_rd, k);
+  };
+  auto k_issue = [&](auto off, u32x4_t (&k)[KS]) {
+    if constexpr (KS == 8) lds_issue_b128x8<decltype(off)::value>(k_rd, k);
+    else lds_issue_b128x4<decltype(off)::value>(k_rd, k);
+  };
+  auto v_issue = [&](auto off, u32x2_t (&o)[4 * NB]) {
+    constexpr int SB = decltype(off)::value;
+    if constexpr (NB == 4) lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
+    else lds_issue_tr2x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
+  };
+  // vector instructions the scheduler places behind each MFMA (the same totals per step whatever the head size)
+  constexpr int kExpPerMfma = 16 / KS, kPackPerMfma = 8 / KS;
+  constexpr int kLoPerMfma = 40 / (2 * NB), kSumPerMfma = (30 + 2 * NB - 1) / (2 * NB);
   auto qk_mfma = [&](const u32x4_t (&k)[KS], f32x16_t (&s)[NC]) {
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -808,7 +827,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   };
   constexpr bool LO_LATE = SPLIT && MI_PREFILL_LO_LATE && NC == 1;
   // which: 0 = hi and lo back to back (round 3), 1 = the hi operands only, 2 = the lo operands only
-  auto pv_mfma = [&](const u32x2_t (&o)[16], auto which) {
+  auto pv_mfma = [&](const u32x2_t (&o)[4 * NB], auto which) {
     constexpr int W = decltype(which)::value;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -943,13 +962,13 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
       // fragment reads run under the work that does not need them: K(t+1) under the branches of step t's softmax,
       // V(t) under the S(t+1) MFMAs and the exponentials
       u32x4_t k[KS];
-      lds_issue_b128x8<SN>(k_rd, k);
+      k_issue(std::integral_constant<int, SN>{}, k);
       __builtin_amdgcn_sched_barrier(0);   // the reads stay in FRONT of the work that covers their latency
       pre(t, sc[ST & 1], interior);
       MI_TICK(3);
       lds_wait_all();
-      u32x2_t o[16];
-      lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o);
+      u32x2_t o[4 * NB];
+      v_issue(std::integral_constant<int, SB>{}, o);
       __builtin_amdgcn_sched_barrier(0);
       MI_TICK(4);
       qk_mfma(k, sc[(ST + 1) & 1]);
@@ -958,10 +977,10 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
       if constexpr (MI_PREFILL_SCHED) {
 #pragma unroll
         for (int i = 0; i < NC * KS; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA (32 cycles of pipe, 8 of issue)
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two exponents' fma
-          __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   // two exponentials
-          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // a pack once its pair exists
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA (32 cycles of pipe, 8 of issue)
+          __builtin_amdgcn_sched_group_barrier(0x002, kExpPerMfma, 0);    // two exponents' fma (four at head_dim 64)
+          __builtin_amdgcn_sched_group_barrier(0x400, kExpPerMfma, 0);    // as many exponentials
+          __builtin_amdgcn_sched_group_barrier(0x002, kPackPerMfma, 0);   // a pack once its pair exists
         }
       }
       MI_TICK(5);
@@ -982,7 +1001,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
           for (int i = 0; i < 2 * NB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
+            __builtin_amdgcn_sched_group_barrier(0x002, kLoPerMfma, 1);
           }
         }
         pv_mfma(o, std::integral_constant<int, 2>{});
@@ -993,7 +1012,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
           for (int i = 0; i < 2 * NB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 2);
+            __builtin_amdgcn_sched_group_barrier(0x002, kSumPerMfma, 2);
           }
         }
       } else {
@@ -1005,7 +1024,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
         for (int i = 0; i < NC * 2 * NB * (SPLIT ? 2 : 1); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-          __builtin_amdgcn_sched_group_barrier(0x002, SPLIT ? 2 : 3, 1);
+          __builtin_amdgcn_sched_group_barrier(0x002, (SPLIT ? 2 : 3) * 4 / NB, 1);
         }
       }
       }
@@ -1016,7 +1035,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
   };
   // ---- rotated loop (MI_PREFILL_ROTATE): state that crosses the barrier
   constexpr bool ROT = LO_LATE && MI_PREFILL_ROTATE;
-  u32x2_t o_keep[16];
+  u32x2_t o_keep[4 * NB];
   float v_keep[NC][16];
   // PV of the step whose V fragments and fp32 P are in o_keep / v_keep (hi operands in pb); `smax`: the scores whose
   // lane maximum the next `pre` wants (nullptr in the drain behind the loop)
@@ -1027,7 +1046,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
       for (int i = 0; i < 2 * NB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 1);
+        __builtin_amdgcn_sched_group_barrier(0x002, kLoPerMfma, 1);
       }
     }
     pv_mfma(o_keep, std::integral_constant<int, 2>{});
@@ -1040,7 +1059,7 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
       for (int i = 0; i < 2 * NB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 2);
+        __builtin_amdgcn_sched_group_barrier(0x002, kSumPerMfma, 2);
       }
     }
   };
@@ -1057,14 +1076,14 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
     if (active) {
       constexpr int SN = NEXT::value * STAGE, SB = ST * STAGE;
       u32x4_t k[KS];
-      lds_issue_b128x8<SN>(k_rd, k);          // K(t+1): its latency runs under the PV MFMAs below
+      k_issue(std::integral_constant<int, SN>{}, k);   // K(t+1): its latency runs under the PV MFMAs below
       __builtin_amdgcn_sched_barrier(0);
       if (t > t_begin) pv_block(sc[ST & 1]);  // PV(t-1) from registers; lane maxima of step t's scores for `pre`
       MI_TICK(3);
       lds_wait_all();
       MI_TICK(4);
       pre(t, sc[ST & 1], interior);
-      lds_issue_tr4x4<SB, SB + 8 * ROWB, SB + 16 * ROWB, SB + 24 * ROWB>(v_rd, o_keep);   // V(t): under the S^T MFMAs
+      v_issue(std::integral_constant<int, SB>{}, o_keep);   // V(t): under the S^T MFMAs
       __builtin_amdgcn_sched_barrier(0);
       qk_mfma(k, sc[(ST + 1) & 1]);
       expo(sc[ST & 1], v_keep);
@@ -1072,9 +1091,9 @@ __global__ __launch_bounds__(NC == 2 ? 256 : 512) void prefill_mfma32_kernel(con
 #pragma unroll
         for (int i = 0; i < NC * KS; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, kExpPerMfma, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, kExpPerMfma, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, kPackPerMfma, 0);
         }
       }
       MI_TICK(5);
@@ -1270,7 +1289,11 @@ PrefillPlan prefill_plan(int max_query_len, int num_seqs, int num_q_heads, int n
   // Column tiles per wave of the 16x16x32 kernel: 2 (32 query tokens per workgroup) once the chunk is long enough to use
   // them; a short chunk (decode-like mixed batches, tails) keeps 16-token tiles so that rows are not wasted.
   pl.nc = forced_nc ? forced_nc : (max_query_len > kColTile ? 2 : 1);
-  pl.kernel32 = head_dim == 128 && pl.nc >= 2 && !mm16;
+  static const bool mm16_d64 = [] {   // MI_PREFILL_MM64=16: head_dim 64 keeps the 16x16x32 kernel (A/B)
+    const char* e = getenv("MI_PREFILL_MM64");
+    return e && atoi(e) == 16;
+  }();
+  pl.kernel32 = pl.nc >= 2 && !mm16 && !(head_dim == 64 && mm16_d64);
   pl.w4 = pl.kernel32 && w4 && hpw >= 4;
   if (pl.w4) {
     // (experiment, off) 4..8 heads as FOUR waves x 2 tiles x 32 columns, one wave per SIMD with the 512-register file.
@@ -1335,25 +1358,20 @@ int launch_prefill(PrefillParams p, const PrefillPlan& pl, int num_kv_heads, int
   }();
 #define MI_LAUNCH32(NI_, NC_)                                                                              \
   do {                                                                                                     \
-    if (rounded_p) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, NI_, NC_, false>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, NI_, NC_, true>), grid, block, 0, s, p);            \
+    if (rounded_p) hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, HD, NI_, NC_, false>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((prefill_mfma32_kernel<Tag, HD, NI_, NC_, true>), grid, block, 0, s, p);            \
   } while (0)
 #define MI_LAUNCH16(NI_, NC_)                                                                                \
   do {                                                                                                       \
     if (rounded_p) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, NI_, NC_, false>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, HD, NI_, NC_, true>), grid, block, 0, s, p);            \
   } while (0)
-  bool launched = false;
-  if constexpr (HD == 128) {
-    if (pl.kernel32) {
-      if (pl.w4) MI_LAUNCH32(4, 2);
-      else if (pl.waves >= 4) MI_LAUNCH32(4, 1);
-      else if (pl.waves >= 2) MI_LAUNCH32(2, 1);
-      else MI_LAUNCH32(1, 1);
-      launched = true;
-    }
-  }
-  if (!launched) {
+  if (pl.kernel32) {
+    if (pl.w4) MI_LAUNCH32(4, 2);
+    else if (pl.waves >= 4) MI_LAUNCH32(4, 1);
+    else if (pl.waves >= 2) MI_LAUNCH32(2, 1);
+    else MI_LAUNCH32(1, 1);
+  } else {
     if (pl.nc >= 2) {
       if (pl.waves >= 4) MI_LAUNCH16(4, 2);
       else if (pl.waves >= 2) MI_LAUNCH16(2, 2);
