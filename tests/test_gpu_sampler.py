@@ -103,6 +103,39 @@ def test_sampler_random_sweep(dev, seed):
     assert flips <= 2, flips
 
 
+def test_sampler_top_k_with_masked_logits_and_crowded_buckets(dev):
+    """What the bucketed top-k select (csrc/sampler.hip) must get right besides the sweep above: rows that are mostly -inf
+    (a grammar / codec mask: -inf sits in bucket 0 with the smallest finite values, and k may reach into it), rows whose
+    k-th value lies in a crowded bucket (> 64 members: the radix select takes over), rows of one repeated finite value."""
+    rng = np.random.default_rng(77)
+    vocab, n = 2048, 40
+    x = rng.standard_normal((n, vocab)).astype(np.float32) * 2
+    for r in range(n):
+        frac = (0.5, 0.9, 0.97, 0.999)[r % 4]
+        x[r, rng.random(vocab) < frac] = -np.inf
+    x[5, :] = -np.inf
+    x[5, 7] = 1.0                                      # a single finite logit
+    x[6, :] = 0.25                                     # every logit the same
+    x[7, :1500] = 3.0                                  # a crowded top bucket: k falls among 1500 equal values
+    x[8, 100:400] = np.linspace(2.0, 2.001, 300, dtype=np.float32)   # 300 distinct values inside one bucket
+    x[8, 0] = 40.0                                     # ... of a wide range
+    logits = torch.from_numpy(x)
+    temperature = np.full(n, 0.9, np.float32)
+    top_k = rng.choice([1, 5, 50, 300, 2047], size=n).astype(np.int32)
+    top_k[7], top_k[8] = 50, 150
+    top_p = rng.choice([1.0, 0.8], size=n).astype(np.float32)
+    seed = np.arange(n, dtype=np.int64) + 5
+    offset = np.arange(n, dtype=np.int64) * 3
+    got, _ = _run(dev, logits, temperature, top_k, top_p, None, None, None, seed, offset)
+    ref, margins = ref_sampler.sample(x, temperature, top_k, top_p, None, None, None, seed, offset)
+    for r in range(n):
+        if got[r] != ref[r]:
+            m = margins[r]
+            assert m["topp_gap"] < 1e-5 or m["race_ratio"] < 1 + 1e-4, (r, int(got[r]), int(ref[r]), m)
+    assert np.isfinite(x[np.arange(n), got]).all()     # a masked token is never drawn
+    assert got[5] == 7
+
+
 def test_sampler_signed_zeros_tie_and_the_race_tail(dev):
     """Two things the sweep above found.  (1) -0.0 and +0.0 are one value: a top-k whose k-th value is a zero keeps the
     zeros of either sign (they used to get different sort keys).  (2) The exponential race is decided by the draws next

@@ -180,9 +180,86 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
     // 2. top-k: key of the k-th largest value, built bit by bit (largest tau with count(key >= tau) >= k)
     const int k = p.top_k ? p.top_k[row] : 0;
     if (k > 0 && k < V) {
+      // The k-th largest key `tau` (values with a smaller key are dropped; ties with it stay, as `logit < kth` upstream).
+      // Fast path — one pass instead of eight: bucket the values by a MONOTONE map of the value itself, 256 equal steps
+      // between the row's smallest and largest finite logit (monotone: a value in a higher bucket is a larger value, so the
+      // k-th largest lies in the bucket where the suffix count crosses k), then select exactly among that bucket's few
+      // members by rank (<= 64 of them: one wave, every member against every other).  Rows the map cannot order — a NaN
+      // or +inf logit, all finite logits equal — or a boundary bucket with more than 64 members take the radix select below:
+      // the same tau either way.  Measured, 2048 logits, k = 50: 13.4 -> 5.4 us of the launch (profiles/r04y_sampler_bucket_select.log).
+      uint32_t tau = 0, kk = (uint32_t)k;
+      bool have_tau = false;
+      {
+        float hi_v = -INFINITY, lo_v = INFINITY;
+        for (int i = tid; i < V; i += 256) {
+          const float v = vals[i];
+          if (!(v < INFINITY)) hi_v = INFINITY;          // +inf or NaN: no bucket map
+          else if (v > -INFINITY) { hi_v = fmaxf(hi_v, v); lo_v = fminf(lo_v, v); }
+        }
+        hi_v = red.max(hi_v);
+        lo_v = -red.max(-lo_v);
+        const float range = hi_v - lo_v;
+        if (range > 0.f && range < INFINITY) {           // block-uniform (reduced values)
+          const float sc = 255.f / range;
+          auto bucket = [&](float v) -> int {
+            if (!(v > -INFINITY)) return 0;
+            const int b = (int)((v - lo_v) * sc);
+            return b > 255 ? 255 : b;
+          };
+          uint32_t* hist256 = reinterpret_cast<uint32_t*>(mbuf + 64);   // the survivor lists' space: not in use yet
+          uint32_t* cand = hist256 + 256;                                // [64] keys of the boundary bucket
+          uint32_t* misc = cand + 64;                                    // [0..3] wave totals, [4] bucket, [5] above, [6] count, [7] tau
+          hist256[tid] = 0u;
+          if (tid == 0) misc[6] = 0u;
+          __syncthreads();
+          for (int i = tid; i < V; i += 256) atomicAdd(&hist256[bucket(vals[i])], 1u);
+          __syncthreads();
+          // suffix counts: s = members of buckets tid .. 255
+          const uint32_t c = hist256[tid];
+          uint32_t sfx = c;
+          const int ln = tid & 63;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_down(sfx, o, 64);
+            if (ln + o < 64) sfx += up;
+          }
+          if (ln == 0) misc[tid >> 6] = sfx;
+          __syncthreads();
+          for (int w2 = (tid >> 6) + 1; w2 < 4; ++w2) sfx += misc[w2];
+          if (sfx >= kk && sfx - c < kk) {   // exactly one bucket: the suffix count is non-increasing and reaches V >= k
+            misc[4] = (uint32_t)tid;
+            misc[5] = sfx - c;
+          }
+          __syncthreads();
+          const int bsel = (int)misc[4];
+          const uint32_t need = kk - misc[5];                   // the need-th largest of the bucket's members
+          const uint32_t nb = hist256[bsel];
+          if (nb <= 64u) {                                        // block-uniform
+            for (int i = tid; i < V; i += 256) {
+              const float v = vals[i];
+              if (bucket(v) == bsel) cand[atomicAdd(&misc[6], 1u)] = fkey(v);
+            }
+            __syncthreads();
+            if (tid < 64) {
+              const uint32_t key = (uint32_t)tid < nb ? cand[tid] : 0u;
+              uint32_t gt = 0, ge = 0;
+              for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t kj = cand[j];                      // same address in every lane: a broadcast read
+                gt += kj > key ? 1u : 0u;
+                ge += kj >= key ? 1u : 0u;
+              }
+              if ((uint32_t)tid < nb && gt < need && need <= ge) misc[7] = key;   // equal keys write the same value
+            }
+            __syncthreads();
+            tau = misc[7];
+            have_tau = true;
+            __syncthreads();   // misc / cand are the top-p stage's lists next
+          }
+        }
+      }
+      if (!have_tau) {
       // radix select, four key bits per step: a 16-bin histogram (one per wave: LDS atomics) of the keys that share the
       // digits found so far; the digit is the largest d whose bins d..15 hold the kk-th largest of them
-      uint32_t tau = 0, kk = (uint32_t)k;
       uint32_t* hist = reinterpret_cast<uint32_t*>(mbuf);   // [4][16]
       for (int sh = 28; sh >= 0; sh -= 4) {
         if (tid < 64) hist[tid] = 0u;
@@ -205,6 +282,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
         kk -= above;
         tau |= dig << sh;
         __syncthreads();   // every thread has read the bins before they are zeroed again
+      }
       }
       for (int i = tid; i < V; i += 256)
         if (fkey(vals[i]) < tau) vals[i] = -INFINITY;
