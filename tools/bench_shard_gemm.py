@@ -62,7 +62,9 @@ def predictor_shapes():
     heads of 128, intermediate 3072, no biases): 157 MB of weights over its five layers, re-read at every one of the 31
     steps of a call — they live in the 256 MB Infinity Cache, so they are timed warm (COPIES_MB=150)."""
     return [("cp_qkv", 4096, 1024, False, False), ("cp_o", 1024, 2048, False, False),
-            ("cp_gate_up", 6144, 1024, True, False), ("cp_down", 1024, 3072, False, False)]
+            ("cp_gate_up", 6144, 1024, True, False), ("cp_down", 1024, 3072, False, False),
+            # one of the G - 1 heads after every stack pass (qwen3_code_predictor.py:556-560: vocab 2048)
+            ("cp_lm_head", 2048, 1024, False, False)]
 
 
 def candidates(m: int, n_cols: int, k: int, gated: bool):

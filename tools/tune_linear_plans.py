@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--predictor", action="store_true",
                     help="the Qwen3-Omni code predictor's four projections at 32..512 rows instead (weights warm in the "
                          "Infinity Cache, as they are across the 31 steps of a call); entries are tagged tp 0")
+    ap.add_argument("--only", default="", help="comma-separated projection names: measure just these")
     ap.add_argument("--merge", default=None, help="an existing table whose entries of OTHER shapes are kept")
     a = ap.parse_args()
     from vllm_omni_amd.tuned import enable_tuned_gemms
@@ -38,6 +39,8 @@ def main():
         os.environ["COPIES_MB"] = "150"
         for m in (32, 64, 128, 256, 512):
             for name, n, k, gated, bias in predictor_shapes():
+                if a.only and name not in a.only.split(","):
+                    continue
                 e = sweep(name, n, k, gated, bias, m, g, log=lambda s: print(s, flush=True), top=3)
                 e["tp"] = 0
                 entries.append(e)
@@ -45,6 +48,8 @@ def main():
         for tp in (int(t) for t in a.tp.split(",")):
             for m in (int(r) for r in a.rows.split(",")):
                 for name, n, k, gated, bias in talker_shapes(tp):
+                    if a.only and name not in a.only.split(","):
+                        continue
                     e = sweep(name, n, k, gated, bias, m, g, log=lambda s: print(s, flush=True), top=3)
                     e["tp"] = tp
                     entries.append(e)

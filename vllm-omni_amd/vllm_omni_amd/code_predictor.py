@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .layers import AttentionMetadata, RMSNorm, _init_weight, set_forward_context
+from .layers import AttentionMetadata, RMSNorm, _init_weight, set_forward_context, tuned_linear
 from .talker import Qwen2DecoderLayer, TalkerConfig
 
 
@@ -206,7 +206,7 @@ class MI355XCodePredictor:
         draws = base.view(1, b) + self._steps          # [G - 1, B] Philox counters of the call's draws: one launch, not G - 1
         fused = self.proj_weight is None and torch.device(dev).type == "cuda"
         for step in range(1, g):
-            logits = F.linear(hid, self.lm_head[step - 1])
+            logits = tuned_linear(hid, self.lm_head[step - 1])
             if return_logits:
                 all_logits.append(logits.float())
             code = ops.sample_tokens(logits, temp, seed, draws[step - 1], top_k=topk, top_p=topp)
