@@ -137,6 +137,40 @@ int mi_rope_cache_attend_block(void* out, const void* q, const void* k, const vo
                                int64_t cache_token_stride, int64_t cache_head_stride, float scale,
                                int dtype, void* stream);
 
+/* One decode pass of the code predictor's WHOLE layer stack in one launch
+ * (csrc/cp_stack.hip; replaces, per pass, the 7 launches x num_layers of
+ * Qwen3OmniMoeTalkerCodePredictor's decoder layers + the final norm:
+ * vllm_omni/model_executor/models/common/qwen3_code_predictor.py:143-191,318-420).
+ * Every row's new token sits at `position` of its own KV block (block_ids[row *
+ * block_ids_stride]); x [rows, hidden] are the step's input rows, out [rows, hidden]
+ * the final-norm output.  Weights per layer as arrays of `num_layers` HOST pointers to
+ * device tensors: qkv [(nq + 2 nkv) * 128, hidden], o [hidden, nq * 128], gate_up
+ * [2 * intermediate, hidden], down [hidden, intermediate], the four norm weights; no
+ * biases; q heads = 2 x kv heads of 128 (the predictor's geometry), hidden <= 1024.
+ * `workspace` (mi_cp_stack_workspace_bytes) holds the activations between phases and
+ * the grid barrier's state: pass workspace_fresh = 1 on the first call with a
+ * workspace (zeroes that state), 0 afterwards.  The launch is a persistent grid of one
+ * workgroup per CU: it needs the whole device to itself while it runs; a barrier that
+ * cannot complete gives up after a bounded wait and the launch reports through
+ * mi_cp_stack_status. */
+int64_t mi_cp_stack_workspace_bytes(int32_t rows, int32_t hidden, int32_t num_q_heads,
+                                    int32_t num_kv_heads, int32_t intermediate);
+int mi_cp_stack_decode(void* out, const void* x, const void* const* w_qkv, const void* const* w_o,
+                       const void* const* w_gate_up, const void* const* w_down,
+                       const void* const* input_norm, const void* const* post_attn_norm,
+                       const void* const* q_norm, const void* const* k_norm, const void* final_norm,
+                       void* const* k_cache, void* const* v_cache, const int32_t* block_ids,
+                       int64_t block_ids_stride, const float* cos_sin_cache, int32_t max_position,
+                       int32_t position, int32_t rows, int32_t hidden, int32_t num_q_heads,
+                       int32_t num_kv_heads, int32_t head_dim, int32_t intermediate,
+                       int32_t num_layers, int32_t block_size, int64_t cache_block_stride,
+                       int64_t cache_token_stride, int64_t cache_head_stride, float norm_eps,
+                       float scale, void* workspace, int64_t workspace_bytes,
+                       int32_t workspace_fresh, int dtype, void* stream);
+/* Device address of the workspace's error word (uint32, 0 = every barrier completed). */
+void* mi_cp_stack_status(void* workspace, int32_t rows, int32_t hidden, int32_t num_q_heads,
+                         int32_t num_kv_heads, int32_t intermediate);
+
 /* The same op fed by the fp32 split-K partials [split][T][(nq + 2 nkv) * 128] of
  * qkv_proj (mi_linear_partials), as mi_rope_neox_and_cache_splitk is: a value is
  * rnd(sum over slices in order (+ qkv_bias)), so results equal mi_linear +

@@ -46,6 +46,11 @@ SIGNATURES = {
     "mi_rope_cache_attend_block_splitk": (c_int, [_P, _P, c_int32, _P, _P, c_int32, _P, c_int32, c_int32, _P, _P, c_float,
                                                    _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64,
                                                    c_int64, c_int64, c_int64, c_float, c_int, _P]),
+    "mi_cp_stack_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mi_cp_stack_status": (_P, [_P, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mi_cp_stack_decode": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int32, c_int32, c_int32,
+                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
+                                    c_float, c_float, _P, c_int64, c_int32, c_int, _P]),
     "mi_embed_codes": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, _P]),
     "mi_rope_cache_attend_block": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P, _P, c_float, _P, _P, _P, c_int64,
                                             c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,

@@ -205,6 +205,82 @@ def rope_cache_attend_block_splitk(part: "SplitKPartials", num_q_heads: int, num
     return out
 
 
+class CpStack:
+    """Host handle of the code predictor's one-launch layer stack (``mi_cp_stack_decode``, csrc/cp_stack.hip): the
+    pointer tables of the layers' weights and private KV caches (the tensors are kept alive here) and the workspace
+    that carries the activations between the launch's phases and its grid-barrier state.
+
+    ``layers``: per layer a dict with ``qkv, o, gate_up, down, input_norm, post_norm, q_norm, k_norm`` (device tensors of
+    the compute dtype) and ``k_cache, v_cache`` ([num_blocks, block_size, kv_heads, 128] views); ``max_rows``: the largest
+    batch a call may bring."""
+
+    _KEYS = ("qkv", "o", "gate_up", "down", "input_norm", "post_norm", "q_norm", "k_norm", "k_cache", "v_cache")
+
+    def __init__(self, layers: Sequence[dict], final_norm: torch.Tensor, cos_sin_cache: torch.Tensor, num_q_heads: int,
+                 num_kv_heads: int, head_dim: int, norm_eps: float, scale: float, max_rows: int):
+        import ctypes
+
+        first = layers[0]
+        _gpu(final_norm, cos_sin_cache, *[t for layer in layers for t in (layer[k] for k in self._KEYS)])
+        self.dtype = first["qkv"].dtype
+        self.hidden = int(first["qkv"].shape[1])
+        self.inter = int(first["down"].shape[1])
+        self.nq, self.nkv, self.head_dim = int(num_q_heads), int(num_kv_heads), int(head_dim)
+        self.eps, self.scale = float(norm_eps), float(scale)
+        self.max_rows = int(max_rows)
+        for layer in layers:
+            if (tuple(layer["qkv"].shape) != ((self.nq + 2 * self.nkv) * self.head_dim, self.hidden)
+                    or tuple(layer["o"].shape) != (self.hidden, self.nq * self.head_dim)
+                    or tuple(layer["gate_up"].shape) != (2 * self.inter, self.hidden)
+                    or tuple(layer["down"].shape) != (self.hidden, self.inter)):
+                raise ValueError("layer weights do not have the stack's shapes")
+            for k in self._KEYS[:8]:
+                if layer[k].dtype != self.dtype or not layer[k].is_contiguous():
+                    raise TypeError(f"{k}: contiguous {self.dtype} expected")
+            if layer["k_cache"].stride() != first["k_cache"].stride() or layer["k_cache"].shape != first["k_cache"].shape:
+                raise ValueError("the layers' KV caches must share one layout")
+        self._cb, self._ct, self._ch = _cache_strides(first["k_cache"], first["v_cache"])
+        self.block_size = int(first["k_cache"].shape[1])
+        self._keep = (list(layers), final_norm, cos_sin_cache)
+        n = len(layers)
+        arr = ctypes.c_void_p * n
+        self._tables = {k: arr(*[layer[k].data_ptr() for layer in layers]) for k in self._KEYS}
+        self.num_layers = n
+        self.final_norm, self.cos_sin = final_norm, cos_sin_cache
+        nbytes = int(lib.mi_cp_stack_workspace_bytes(self.max_rows, self.hidden, self.nq, self.nkv, self.inter))
+        if nbytes <= 0:
+            raise ValueError("unsupported code-predictor stack geometry")
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=final_norm.device)
+        self._ws_bytes = nbytes
+        self._fresh = True
+
+    def decode(self, out: torch.Tensor, x: torch.Tensor, block_ids: torch.Tensor, position: int) -> torch.Tensor:
+        """One pass: x [rows, hidden] -> out [rows, hidden] (final-norm output), every row's new token at ``position`` of
+        the KV block ``block_ids[row]``."""
+        _gpu(out, x, block_ids)
+        rows = int(x.shape[0])
+        if rows > self.max_rows:
+            raise ValueError(f"{rows} rows exceed the workspace's {self.max_rows}")
+        if x.dtype != self.dtype or out.dtype != self.dtype or not x.is_contiguous() or not out.is_contiguous():
+            raise TypeError("x / out must be contiguous tensors of the stack's dtype")
+        if tuple(x.shape) != (rows, self.hidden) or tuple(out.shape) != (rows, self.hidden):
+            raise ValueError("x / out must be [rows, hidden]")
+        if block_ids.dtype != torch.int32 or block_ids.dim() != 1 or block_ids.shape[0] < rows:
+            raise TypeError("block_ids must be int32 [rows]")
+        t = self._tables
+        check("mi_cp_stack_decode", lib.mi_cp_stack_decode(
+            _p(out), _p(x), t["qkv"], t["o"], t["gate_up"], t["down"], t["input_norm"], t["post_norm"], t["q_norm"], t["k_norm"],
+            _p(self.final_norm), t["k_cache"], t["v_cache"], _p(block_ids), block_ids.stride(0), _p(self.cos_sin),
+            self.cos_sin.shape[0], int(position), rows, self.hidden, self.nq, self.nkv, self.head_dim, self.inter,
+            self.num_layers, self.block_size, self._cb, self._ct, self._ch, self.eps, self.scale, _p(self.workspace),
+            self._ws_bytes, 0, _dt(self.dtype), _stream()))   # the workspace was zeroed at allocation
+        return out
+
+    def status(self) -> int:
+        """0 = every grid barrier of every launch so far completed (synchronises)."""
+        return int(self.workspace[self._ws_bytes - 256:self._ws_bytes - 252].view(torch.int32).item())
+
+
 # --------------------------------------------------------------------------- A5
 # Default decode mode (see include/vllm_omni_amd.h, flags): True = P may be rounded to the cache dtype
 # before P.V, as the reference's TRITON_ATTN kernel does -> matrix-core kernel where built (head_dim 128,
