@@ -12,6 +12,14 @@ from oracle import ref_sampler
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[False, True], ids=["launch_chain", "one_launch_stack"])
+def stack_mode(request, monkeypatch):
+    """Both forms of the single-token passes: the per-layer launches (default) and the whole stack as one persistent
+    launch per pass (csrc/cp_stack.hip; VLLM_OMNI_AMD_CP_ONE_LAUNCH=1)."""
+    monkeypatch.setenv("VLLM_OMNI_AMD_CP_ONE_LAUNCH", "1" if request.param else "0")
+    return request.param
+
+
 def _mk(dev, cfg, b, seed=0):
     from vllm_omni_amd.code_predictor import MI355XCodePredictor
 
@@ -27,7 +35,7 @@ def _mk(dev, cfg, b, seed=0):
 
 
 @pytest.mark.parametrize("groups", [4, 32])
-def test_code_predictor_matches_oracle(dev, groups):
+def test_code_predictor_matches_oracle(dev, groups, stack_mode):
     from vllm_omni_amd.code_predictor import CodePredictorConfig
 
     cfg = CodePredictorConfig(hidden_size=256, num_hidden_layers=5, num_attention_heads=4, num_key_value_heads=2,
@@ -39,6 +47,7 @@ def test_code_predictor_matches_oracle(dev, groups):
     codes, buf, logits = cp(code0.to(dev), emb0.to(dev), hidden.to(dev), seed=seed.to(dev), offset=offset.to(dev),
                             return_logits=True)
     torch.cuda.synchronize()
+    assert (cp._cp_stack is not None) == stack_mode and (not stack_mode or cp._cp_stack.status() == 0)
     codes_c, buf_c = codes.cpu(), buf.cpu().float()
     assert codes_c.shape == (b, groups, 1) and buf_c.shape == (b, groups + 1, cfg.hidden_size)
     assert torch.equal(codes_c[:, 0], code0)
@@ -70,7 +79,7 @@ def test_code_predictor_matches_oracle(dev, groups):
         assert torch.equal(gcodes[:, step, 0].cpu(), glogits[step - 1].argmax(-1).cpu())
 
 
-def test_code_predictor_incremental_equals_reprefill_on_device(dev):
+def test_code_predictor_incremental_equals_reprefill_on_device(dev, stack_mode):
     """Size-independent property at the real shape (H 1024, 16/8 heads, G 32, batch 8): the hidden state the
     incremental path produces at the last position equals a from-scratch varlen prefill of the whole buffer."""
     from vllm_omni_amd.code_predictor import CodePredictorConfig, MI355XCodePredictor
@@ -99,7 +108,7 @@ def test_code_predictor_incremental_equals_reprefill_on_device(dev):
     assert int(codes.min()) >= 0 and int(codes.max()) < cfg.vocab_size
 
 
-def test_code_predictor_graph_replay_equals_eager(dev):
+def test_code_predictor_graph_replay_equals_eager(dev, stack_mode):
     from vllm_omni_amd.code_predictor import CodePredictorConfig, MI355XCodePredictor
 
     cfg = CodePredictorConfig(hidden_size=256, num_hidden_layers=5, num_attention_heads=4, num_key_value_heads=2,

@@ -387,8 +387,23 @@ constexpr int cp_ring_stages(int nslab) {
   return n < 3 ? 3 : (n > 8 ? 8 : n);
 }
 
+#ifdef MI_CP_TIMING
+// debug build (make dbg-style, tools/debug_cp_stack_timing.py): 10 ns timestamps of workgroup MI_CP_TIMING_WG around every
+// phase and barrier of the first layer-steps
+__device__ unsigned long long mi_cp_ticks[128];
+#define CP_TICK()                                                                                    \
+  do {                                                                                               \
+    if (blockIdx.x == (MI_CP_TIMING_WG) && threadIdx.x == 0 && tick < 128) mi_cp_ticks[tick++] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define CP_TICK() do {} while (0)
+#endif
+
 template <typename Tag, int NSLAB, int NL, int G, int TILES>
 __global__ __launch_bounds__(64 * (NSLAB + NL)) void cp_stack_kernel(const CpStackParams p) {
+#ifdef MI_CP_TIMING
+  int tick = 0;
+#endif
   scalar_cache_acquire();
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int NW = NSLAB + NL;
@@ -399,30 +414,52 @@ __global__ __launch_bounds__(64 * (NSLAB + NL)) void cp_stack_kernel(const CpSta
   uint16_t* lq = reinterpret_cast<uint16_t*>(smem) + wid * (G * kCpHD);
   uint32_t gen = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left by the previous launch
   const int QKV = (p.NQ + 2 * p.NKV) * kCpHD;
+  CP_TICK();
   for (int l = 0; l < p.L; ++l) {
     if (l == 0) cp_norm_phase<Tag>(p, p.x_in, nullptr, 0, p.ln1[0], p.xn, nwaves, wave_id);
     else cp_norm_phase<Tag>(p, nullptr, p.down_part, p.S4, p.ln1[l], p.xn, nwaves, wave_id);
+    CP_TICK();
     cp_grid_barrier(p.sync, ++gen, p.err);
+    CP_TICK();
     cp_linear_phase<Tag, NSLAB, NL, NST, false>(p.xn, p.w_qkv[l], p.qkv_part, nullptr, p.B, QKV, p.H, p.S1, smem);
+    CP_TICK();
     cp_grid_barrier(p.sync, ++gen, p.err);
+    CP_TICK();
     cp_attn_phase<Tag, G, TILES>(p, l, lq, nwaves, wave_id);
+    CP_TICK();
     cp_grid_barrier(p.sync, ++gen, p.err);
+    CP_TICK();
     cp_linear_phase<Tag, NSLAB, NL, NST, false>(p.attn, p.w_o[l], p.o_part, nullptr, p.B, p.H, p.NQ * kCpHD, p.S2, smem);
+    CP_TICK();
     cp_grid_barrier(p.sync, ++gen, p.err);
+    CP_TICK();
     cp_norm_phase<Tag>(p, nullptr, p.o_part, p.S2, p.ln2[l], p.xn, nwaves, wave_id);
+    CP_TICK();
     cp_grid_barrier(p.sync, ++gen, p.err);
+    CP_TICK();
     cp_linear_phase<Tag, NSLAB, NL, NST, true>(p.xn, p.w_gu[l], nullptr, p.act, p.B, p.I, p.H, 1, smem);
+    CP_TICK();
     cp_grid_barrier(p.sync, ++gen, p.err);
+    CP_TICK();
     cp_linear_phase<Tag, NSLAB, NL, NST, false>(p.act, p.w_down[l], p.down_part, nullptr, p.B, p.H, p.I, p.S4, smem);
+    CP_TICK();
     cp_grid_barrier(p.sync, ++gen, p.err);
+    CP_TICK();
   }
   cp_norm_phase<Tag>(p, nullptr, p.down_part, p.S4, p.final_norm, p.out, nwaves, wave_id);
+  CP_TICK();
   // every workgroup read word 0 before its first barrier, and none passes the last one before all have arrived there
   if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(p.sync, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
 }  // namespace mi
+
+#ifdef MI_CP_TIMING
+extern "C" int mi_debug_cp_ticks(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mi::mi_cp_ticks), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int64_t mi_cp_stack_workspace_bytes(int32_t rows, int32_t hidden, int32_t num_q_heads, int32_t num_kv_heads,
                                                int32_t intermediate) {

@@ -18,6 +18,7 @@ no host synchronisation.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Iterable, Optional
 
@@ -115,6 +116,13 @@ class MI355XCodePredictor:
         self._step_in = torch.zeros(mb, cfg.hidden_size, dtype=dtype, device=device)   # the stack's input row of a step
         self._steps = torch.arange(1, g, dtype=torch.int64, device=device).view(g - 1, 1)
         self._graphs: dict = {}
+        # The single-token passes as ONE persistent launch each (ops.CpStack, csrc/cp_stack.hip); built at first use.  Opt-in:
+        # bit-identical to the chain of launches with the same tile plans, but not faster — measured per call 8.09 ms against
+        # 7.43 at batch 32, 14.07 against 12.55 at 512: every phase is still a chain of device-scope round trips (slabs in,
+        # rows out, ~1-2 us each), which is what a kernel boundary costs too (profiles/r04za_cp_stack_phase_timing.log).
+        self._one_launch = os.environ.get("VLLM_OMNI_AMD_CP_ONE_LAUNCH", "0") == "1"
+        self._cp_stack: Optional[ops.CpStack] = None
+        self._hid = torch.zeros(mb, cfg.hidden_size, dtype=dtype, device=device)
 
     # ---- reference-named surface ------------------------------------------------------------------------
     def get_input_embeddings(self) -> list[torch.Tensor]:
@@ -125,6 +133,34 @@ class MI355XCodePredictor:
 
     def _project(self, x: torch.Tensor) -> torch.Tensor:
         return x if self.proj_weight is None else F.linear(x, self.proj_weight, self.proj_bias)
+
+    def _one_launch_stack(self) -> Optional["ops.CpStack"]:
+        """The layers' weights and private caches behind one persistent launch per single-token pass — when the stack is
+        what that kernel was built for: 16-bit un-quantised dense layers, q/k-norm, heads of 128 with two q heads per KV
+        head, hidden <= 1024, one rank.  Otherwise (and with VLLM_OMNI_AMD_CP_ONE_LAUNCH=0) the per-layer launches run."""
+        if self._cp_stack is not None or not self._one_launch or torch.device(self.device).type != "cuda":
+            return self._cp_stack
+        self._one_launch = False        # decided once
+        cfg = self.config
+        a0 = self.layers[0].self_attn
+        if (self.dtype not in (torch.bfloat16, torch.float16) or cfg.head_dim != 128 or cfg.hidden_size > 1024
+                or cfg.hidden_size % 64 or cfg.intermediate_size % 64 or a0.q_norm is None
+                or a0.num_heads != cfg.num_attention_heads or a0.num_heads != 2 * a0.num_kv_heads
+                or cfg.num_hidden_layers > 8 or self.num_code_groups > 32):
+            return None
+        layers = []
+        for layer, kv in zip(self.layers, self.kv):
+            at, mlp = layer.self_attn, layer.mlp
+            lins = (at.qkv_proj, at.o_proj, getattr(mlp, "gate_up_proj", None), getattr(mlp, "down_proj", None))
+            if any(x is None or x.weight is None or getattr(x, "qweight", None) is not None or x.bias is not None for x in lins):
+                return None
+            layers.append(dict(qkv=at.qkv_proj.weight, o=at.o_proj.weight, gate_up=mlp.gate_up_proj.weight,
+                               down=mlp.down_proj.weight, input_norm=layer.input_layernorm.weight,
+                               post_norm=layer.post_attention_layernorm.weight, q_norm=at.q_norm.weight,
+                               k_norm=at.k_norm.weight, k_cache=kv[:, 0].permute(0, 2, 1, 3), v_cache=kv[:, 1].permute(0, 2, 1, 3)))
+        self._cp_stack = ops.CpStack(layers, self.norm.weight, a0.rotary_pos_emb.cos_sin_cache, a0.num_heads, a0.num_kv_heads,
+                                     cfg.head_dim, cfg.rms_norm_eps, a0.scaling, self.max_batch)
+        return self._cp_stack
 
     def _stack(self, x: torch.Tensor, positions: torch.Tensor, md: AttentionMetadata) -> torch.Tensor:
         residual = None
@@ -226,7 +262,11 @@ class MI355XCodePredictor:
                                        seq_lens=self._seq[p][:b], max_seq_len=p + 1, block_table=self.block_table[:b],
                                        slot_mapping=self._slots[p][:b], num_reqs=b, num_decodes=b, single_block=True,
                                        uniform_position=p)
-                hid = self._stack(x, self._pos[p][:b], md)
+                one = self._one_launch_stack()
+                if one is not None:   # the five layers + final norm of this pass in one launch
+                    hid = one.decode(self._hid[:b], x, self.block_table[:b, 0], p)
+                else:
+                    hid = self._stack(x, self._pos[p][:b], md)
         out = (codes[:b].unsqueeze(-1).clone(), buf[:b].clone())
         return out + (all_logits,) if return_logits else out
 
