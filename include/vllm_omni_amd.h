@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 /* dtype enum shared by every entry point */
 enum {

@@ -29,3 +29,16 @@ def dev():
     import torch
 
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def plan_registry():
+    """An empty tile-plan registry (and an unloaded tuned table) for tests that compare entry points of the decode-batch
+    linear kernel bit for bit: the tuned table may give ``linear`` and ``linear_partials`` different split-K factors for one
+    shape, and the whole table is registered the first time any test routes a layer through ``layers.py``."""
+    from vllm_omni_amd import _C
+    from vllm_omni_amd.tuned import linear_plans
+
+    linear_plans.reset()
+    yield _C
+    linear_plans.reset()

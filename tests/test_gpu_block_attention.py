@@ -144,7 +144,7 @@ def test_block_attention_uniform_position_equals_the_per_row_form(dev, p):
 
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("p", [0, 9, 16, 33])
-def test_block_attention_from_qkv_partials_is_bit_identical(dev, p, bias):
+def test_block_attention_from_qkv_partials_is_bit_identical(dev, plan_registry, p, bias):
     """qkv_proj's split-K partials straight into the attention launch == ``linear`` then ``rope_cache_attend_block``:
     same output bits, same cache bits (the code predictor's route at <= 32 rows)."""
     from vllm_omni_amd import ops

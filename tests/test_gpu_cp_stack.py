@@ -49,11 +49,12 @@ def _cos_sin(dev, max_pos=64):
 def _chain(x, layers, final_norm, views, block_ids, cos_sin, pos, plan):
     """The same pass as separate launches, tile plans pinned to the stack's."""
     from vllm_omni_amd import _C, ops
+    from vllm_omni_amd.tuned import linear_plans
 
     rows = x.shape[0]
     wrows, s1, s2, s4 = plan
     lib = _C.lib
-    lib.mi_linear_plan_clear()
+    linear_plans.reset()
     qkv_n = (NQ + 2 * NKV) * D
     for n, k, sp in ((qkv_n, H, s1), (H, NQ * D, s2), (H, INTER, s4)):
         purpose = _C.MI_LINEAR_PLAN_PARTIALS if sp > 1 else _C.MI_LINEAR_PLAN_FULL   # one slice: the 16-bit output itself
@@ -98,7 +99,7 @@ def _chain(x, layers, final_norm, views, block_ids, cos_sin, pos, plan):
         ops.fused_add_rms_norm(down, residual, final_norm, EPS)
         return down
     finally:
-        lib.mi_linear_plan_clear()
+        linear_plans.reset()
 
 
 def _plan(rows, cus):

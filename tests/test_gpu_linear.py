@@ -277,16 +277,6 @@ def _talker_shard_shapes(tp):
     return {"qkv": ((nq + 2 * nkv) * 128, 3584), "o": (3584, nq * 128), "down": (3584, 18944 // tp)}
 
 
-@pytest.fixture
-def plan_registry():
-    from vllm_omni_amd import _C
-    from vllm_omni_amd.tuned import linear_plans
-
-    linear_plans.reset()
-    yield _C
-    linear_plans.reset()
-
-
 _PLAIN_PLANS = [(64, w, s) for w in (32, 64, 96, 128, 160, 192, 256) for s in (1, 3)] + \
                [(128, w, s) for w in (32, 64, 96, 128, 160) for s in (1, 4)] + [(256, 128, 2), (256, 160, 1)]
 

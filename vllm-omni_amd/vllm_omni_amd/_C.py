@@ -17,7 +17,7 @@ MI_DTYPE_F16, MI_DTYPE_BF16, MI_DTYPE_F32 = 0, 1, 2
 MI_OK = 0
 MI_ERR_INVALID_ARG, MI_ERR_UNSUPPORTED, MI_ERR_WORKSPACE = -1, -2, -3
 MI_ERR_LAUNCH, MI_ERR_EXHAUSTED, MI_ERR_STATE = -4, -5, -6
-ABI_VERSION = 2
+ABI_VERSION = 3
 MI_LINEAR_PLAN_FULL, MI_LINEAR_PLAN_PARTIALS, MI_LINEAR_PLAN_GATED = 0, 1, 2
 MI_LINEAR_COUNTER_BYTES = 16 << 10
 MI_DECODE_PACKED_PV = 1
