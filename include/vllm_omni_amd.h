@@ -447,6 +447,19 @@ int mi_sample_tokens(int64_t* ids, const void* logits, int32_t num_rows, int32_t
                      const int32_t* top_k, const float* top_p, const float* rep_penalty,
                      uint32_t* seen_bitmap, const int32_t* seen_row, int32_t bitmap_words_per_row,
                      int32_t update_seen, const uint64_t* seed, const uint64_t* offset, void* stream);
+/* The same draw with mi_embed_codes behind it in ONE launch (the code predictor's step,
+ * qwen3_code_predictor.py:556-600: sample, store the code, embed it with that
+ * codebook's table, append the row): out_a[r] (and out_b[r], may be NULL) =
+ * embed_table[ids[r]] (16-bit rows of embed_dim, embed_dim % 8 == 0), ids_out[r *
+ * ids_out_stride] = ids[r] (may be NULL).  The table has `vocab` rows (the drawn id is
+ * always inside).  No repetition penalty / seen set in this form. */
+int mi_sample_tokens_embed(int64_t* ids, const void* logits, int32_t num_rows, int32_t vocab,
+                           int64_t row_stride, int logits_dtype, const float* temperature,
+                           const int32_t* top_k, const float* top_p, const uint64_t* seed,
+                           const uint64_t* offset, const void* embed_table, int32_t embed_dim,
+                           void* out_a, int64_t out_a_token_stride, void* out_b,
+                           int64_t out_b_token_stride, int64_t* ids_out, int64_t ids_out_stride,
+                           void* stream);
 
 /* ------------------------------------------------------------------------
  * A11 — talker per-step input embedding, batched:

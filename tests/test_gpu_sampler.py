@@ -195,6 +195,37 @@ def test_sampler_draw_frequencies_follow_the_kept_distribution(dev):
     assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_sample_tokens_embed_equals_the_two_launches(dev, dtype):
+    """The code predictor's per-step draw (``mi_sample_tokens_embed``): ids, both embedding copies and the strided id store
+    are what ``sample_tokens`` followed by ``embed_codes`` produce, bit for bit — sampled rows and greedy rows (T = 0)."""
+    from vllm_omni_amd import ops
+
+    rows, vocab, dim, g = 37, 2048, 1024, 5
+    gen = torch.Generator(device=dev).manual_seed(17)
+    logits = (torch.randn(rows, vocab, device=dev, generator=gen) * 3).to(dtype)
+    table = torch.randn(vocab, dim, device=dev, generator=gen).to(dtype)
+    temp = torch.ones(rows, device=dev)
+    temp[::4] = 0.0
+    topk = torch.full((rows,), 50, dtype=torch.int32, device=dev)
+    topp = torch.full((rows,), 0.8, device=dev)
+    seed = torch.arange(rows, dtype=torch.int64, device=dev) + 3
+    off = torch.arange(rows, dtype=torch.int64, device=dev) * 7
+    want = ops.sample_tokens(logits, temp, seed, off, top_k=topk, top_p=topp)
+    buf_a = torch.zeros(rows, g, dim, dtype=dtype, device=dev)
+    buf_b = torch.zeros(rows, dim, dtype=dtype, device=dev)
+    codes = torch.full((rows, g), -1, dtype=torch.int64, device=dev)
+    ops.embed_codes(want, table, buf_a[:, 2], buf_b, codes[:, 3])
+    got_a, got_b, got_codes = torch.zeros_like(buf_a), torch.zeros_like(buf_b), torch.full_like(codes, -1)
+    got = ops.sample_tokens_embed(logits, temp, seed, off, topk, topp, table, got_a[:, 2], got_b, got_codes[:, 3])
+    assert torch.equal(got, want) and torch.equal(got_a, buf_a) and torch.equal(got_b, buf_b) and torch.equal(got_codes, codes)
+    assert torch.equal(got_a[:, 2], table[want])
+    # without the second copy and the id store
+    only_a = torch.zeros_like(buf_b)
+    assert torch.equal(ops.sample_tokens_embed(logits, temp, seed, off, topk, topp, table, only_a), want)
+    assert torch.equal(only_a, table[want])
+
+
 def test_sampler_reproducible_and_edge_cases(dev):
     from vllm_omni_amd import _C, ops
 

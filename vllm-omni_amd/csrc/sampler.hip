@@ -38,6 +38,13 @@ struct SamplerParams {
   int32_t update_seen;
   const uint64_t* seed;       // [rows]
   const uint64_t* offset;     // [rows] draw counter of the request
+  // mi_sample_tokens_embed: the drawn id's row of `emb_table` [vocab, emb_dim] goes to emb_a[row] (and emb_b[row]), the id
+  // itself also to ids2[row * ids2_stride] — mi_embed_codes behind the draw, in the draw's launch
+  const uint16_t* emb_table = nullptr;
+  uint16_t *emb_a = nullptr, *emb_b = nullptr;
+  int64_t* ids2 = nullptr;
+  int64_t a_stride = 0, b_stride = 0, ids2_stride = 0;
+  int32_t emb_dim = 0;
 };
 
 // order-preserving map fp32 -> uint32 (larger float <=> larger key; -0 and +0 share a key: they compare equal, and a
@@ -415,11 +422,40 @@ __global__ __launch_bounds__(256) void sample_kernel(const SamplerParams p) {
     if (best_i == 0x7fffffff) best_i = 0;  // a row of NaNs
     p.ids[row] = best_i;
     if (seen && p.update_seen) atomicOr(&seen[best_i >> 5], 1u << (best_i & 31));
+    if (p.emb_table) {
+      if (p.ids2) p.ids2[row * p.ids2_stride] = best_i;
+      ibuf[0] = best_i;
+    }
+  }
+  if (p.emb_table) {   // block-uniform
+    __syncthreads();
+    const uint16_t* src = p.emb_table + (int64_t)ibuf[0] * p.emb_dim;
+    for (int ch = tid; ch < p.emb_dim / 8; ch += 256) {
+      const uint4 a = *reinterpret_cast<const uint4*>(src + ch * 8);
+      *reinterpret_cast<uint4*>(p.emb_a + row * p.a_stride + ch * 8) = a;
+      if (p.emb_b) *reinterpret_cast<uint4*>(p.emb_b + row * p.b_stride + ch * 8) = a;
+    }
   }
 }
 
 }  // namespace
 }  // namespace mi
+
+namespace {
+int sample_launch(mi::SamplerParams p, int32_t num_rows, int logits_dtype, void* stream) {
+  using namespace mi;
+  const size_t lds = (size_t)p.vocab * 4 + 64 + 256 + 2048 + 16;   // row, scalars, [4][16] words, survivor lists + counts
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(num_rows), block(256);
+  switch (logits_dtype) {
+    case MI_DTYPE_F32: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_F32>), grid, block, lds, s, p); break;
+    case MI_DTYPE_BF16: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_BF16>), grid, block, lds, s, p); break;
+    case MI_DTYPE_F16: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_F16>), grid, block, lds, s, p); break;
+    default: return MI_ERR_UNSUPPORTED;
+  }
+  return launch_status();
+}
+}  // namespace
 
 extern "C" int mi_sample_tokens(int64_t* ids, const void* logits, int32_t num_rows, int32_t vocab,
                                 int64_t row_stride, int logits_dtype, const float* temperature,
@@ -434,14 +470,29 @@ extern "C" int mi_sample_tokens(int64_t* ids, const void* logits, int32_t num_ro
   if (seen_bitmap && bitmap_words_per_row * 32 < vocab) return MI_ERR_INVALID_ARG;
   SamplerParams p{ids, logits, row_stride, vocab, temperature, top_k, top_p, rep_penalty, seen_bitmap, seen_row,
                   bitmap_words_per_row, update_seen, seed, offset};
-  const size_t lds = (size_t)vocab * 4 + 64 + 256 + 2048 + 16;   // row, scalars, [4][16] words, survivor lists + counts
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid(num_rows), block(256);
-  switch (logits_dtype) {
-    case MI_DTYPE_F32: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_F32>), grid, block, lds, s, p); break;
-    case MI_DTYPE_BF16: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_BF16>), grid, block, lds, s, p); break;
-    case MI_DTYPE_F16: hipLaunchKernelGGL((sample_kernel<MI_DTYPE_F16>), grid, block, lds, s, p); break;
-    default: return MI_ERR_UNSUPPORTED;
-  }
-  return launch_status();
+  return sample_launch(p, num_rows, logits_dtype, stream);
+}
+
+extern "C" int mi_sample_tokens_embed(int64_t* ids, const void* logits, int32_t num_rows, int32_t vocab, int64_t row_stride,
+                                      int logits_dtype, const float* temperature, const int32_t* top_k, const float* top_p,
+                                      const uint64_t* seed, const uint64_t* offset, const void* embed_table,
+                                      int32_t embed_dim, void* out_a, int64_t out_a_token_stride, void* out_b,
+                                      int64_t out_b_token_stride, int64_t* ids_out, int64_t ids_out_stride, void* stream) {
+  using namespace mi;
+  if (num_rows == 0) return MI_OK;
+  if (!ids || !logits || !temperature || !seed || !offset || num_rows < 0 || vocab <= 0 || row_stride < vocab || !embed_table ||
+      !out_a || embed_dim <= 0)
+    return MI_ERR_INVALID_ARG;
+  if (vocab > 15744 || embed_dim % 8 || out_a_token_stride % 8 || (out_b && out_b_token_stride % 8)) return MI_ERR_UNSUPPORTED;
+  if (((uintptr_t)out_a | (uintptr_t)out_b | (uintptr_t)embed_table) & 15) return MI_ERR_INVALID_ARG;
+  SamplerParams p{ids, logits, row_stride, vocab, temperature, top_k, top_p, nullptr, nullptr, nullptr, 0, 0, seed, offset};
+  p.emb_table = reinterpret_cast<const uint16_t*>(embed_table);
+  p.emb_a = reinterpret_cast<uint16_t*>(out_a);
+  p.emb_b = reinterpret_cast<uint16_t*>(out_b);
+  p.ids2 = ids_out;
+  p.a_stride = out_a_token_stride;
+  p.b_stride = out_b_token_stride;
+  p.ids2_stride = ids_out_stride;
+  p.emb_dim = embed_dim;
+  return sample_launch(p, num_rows, logits_dtype, stream);
 }

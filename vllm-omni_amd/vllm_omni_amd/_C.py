@@ -51,6 +51,8 @@ SIGNATURES = {
     "mi_cp_stack_decode": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int32, c_int32, c_int32,
                                     c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
                                     c_float, c_float, _P, c_int64, c_int32, c_int, _P]),
+    "mi_sample_tokens_embed": (c_int, [_P, _P, c_int32, c_int32, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, _P,
+                                        c_int64, _P, c_int64, _P]),
     "mi_embed_codes": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, _P]),
     "mi_rope_cache_attend_block": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P, _P, c_float, _P, _P, _P, c_int64,
                                             c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,

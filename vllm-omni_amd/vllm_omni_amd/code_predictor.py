@@ -167,7 +167,7 @@ class MI355XCodePredictor:
         h = x
         with set_forward_context(md):
             for layer in self.layers:
-                h, residual = layer(positions, h, residual)
+                h, residual = layer(positions, h, residual, True)   # every output meets a fused-add norm: down_proj may defer its reduce
         h, _ = self.norm(h, residual)
         return h
 
@@ -245,14 +245,14 @@ class MI355XCodePredictor:
             logits = tuned_linear(hid, self.lm_head[step - 1])
             if return_logits:
                 all_logits.append(logits.float())
-            code = ops.sample_tokens(logits, temp, seed, draws[step - 1], top_k=topk, top_p=topp)
-            # store the code, embed it -> next buffer position (the last one is only returned, never forwarded) and the
-            # next step's input row (the stack works in place on its input): one launch (ops.embed_codes)
+            # draw, store the code, embed it -> next buffer position (the last one is only returned, never forwarded) and the
+            # next step's input row (the stack works in place on its input): ONE launch (ops.sample_tokens_embed)
             x = self._step_in[:b]
             if fused:
-                ops.embed_codes(code, self.codec_embedding[step - 1], buf[:b, step + 1], x if step < g - 1 else None,
-                                codes[:b, step])
+                ops.sample_tokens_embed(logits, temp, seed, draws[step - 1], topk, topp, self.codec_embedding[step - 1],
+                                        buf[:b, step + 1], x if step < g - 1 else None, codes[:b, step])
             else:
+                code = ops.sample_tokens(logits, temp, seed, draws[step - 1], top_k=topk, top_p=topp)
                 codes[:b, step] = code
                 buf[:b, step + 1] = self._project(F.embedding(code, self.codec_embedding[step - 1]))
                 x = buf[:b, step + 1].clone()

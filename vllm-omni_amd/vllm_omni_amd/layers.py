@@ -349,6 +349,7 @@ def _tuned(m: int, n: int, k: int, gated: bool = False):
 
 # what folding a split-K reduce into the consumer (fused-add RMSNorm, RoPE + KV write) adds to that launch, in us
 _DEFERRED_REDUCE_US = 1.0
+_DEFER_TRAFFIC = os.environ.get("VLLM_OMNI_AMD_DEFER_TRAFFIC", "1") != "0"   # A/B: price the slabs' traffic too (predictor shapes)
 
 
 def _streaming_kernel_wins(m: int, n: int, k: int) -> bool:
@@ -444,7 +445,13 @@ def _apply_linear(layer, x: torch.Tensor, bias: Optional[torch.Tensor], defer_re
             # measured at this shape: the cheapest of {library, kernel + its reduce launch, partials reduced downstream}
             best_direct = min(e["library_us"], e["full"]["us"])
             part = e.get("partials")
-            if defer_reduce and _DEFER_REDUCE and part and part["us"] + _DEFERRED_REDUCE_US < best_direct and (
+            # what the consumer pays for reducing the slabs: a constant for the shard shapes (as measured in situ there); for
+            # the code predictor's small layers (tp 0 entries) also the slabs' traffic — at 128 rows x 8 slices they are 4 MB
+            # against a 4 MB weight, and the table's own 1 us margin chose the slower route (8.01 -> 8.25 ms per call)
+            defer_us = _DEFERRED_REDUCE_US
+            if part and e.get("tp") == 0 and _DEFER_TRAFFIC:
+                defer_us += int(part["split"]) * m * n * 4 / 3.0e6
+            if defer_reduce and _DEFER_REDUCE and part and part["us"] + defer_us < best_direct and (
                     defer_reduce != "rope" or _DEFER_QKV_TUNED):
                 pr = ops.linear_partials(x, w, bias)
                 if pr is not None:

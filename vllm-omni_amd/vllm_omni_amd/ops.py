@@ -568,6 +568,35 @@ def sample_tokens(logits: torch.Tensor, temperature: torch.Tensor, seed: torch.T
     return ids
 
 
+def sample_tokens_embed(logits: torch.Tensor, temperature: torch.Tensor, seed: torch.Tensor, offset: torch.Tensor,
+                        top_k: Optional[torch.Tensor], top_p: Optional[torch.Tensor], table: torch.Tensor,
+                        out_a: torch.Tensor, out_b: Optional[torch.Tensor] = None, ids_out: Optional[torch.Tensor] = None,
+                        ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``sample_tokens`` (no repetition penalty) + ``embed_codes`` in one launch: the drawn id's row of ``table`` goes to
+    ``out_a[r]`` (and ``out_b[r]``), the id also to ``ids_out[r]`` (any stride).  The code predictor's per-step draw."""
+    _gpu(logits, temperature, seed, offset, top_k, top_p, table, out_a, out_b, ids_out, ids)
+    t, v = logits.shape
+    if temperature.dtype != torch.float32 or seed.dtype != torch.int64 or offset.dtype != torch.int64:
+        raise TypeError("temperature must be float32, seed/offset int64")
+    if (top_k is not None and top_k.dtype != torch.int32) or (top_p is not None and top_p.dtype != torch.float32):
+        raise TypeError("top_k must be int32, top_p float32")
+    if table.dim() != 2 or table.shape[0] < v or not table.is_contiguous() or table.element_size() != 2:
+        raise ValueError("table must be a contiguous 16-bit [>= vocab, dim] tensor")
+    dim = table.shape[1]
+    for o in (out_a, out_b):
+        if o is not None and (tuple(o.shape) != (t, dim) or o.dtype != table.dtype or o.stride(1) != 1):
+            raise ValueError("out_a / out_b must be [rows, dim] of the table's dtype with contiguous rows")
+    if ids_out is not None and (ids_out.dtype != torch.int64 or ids_out.dim() != 1 or ids_out.shape[0] != t):
+        raise TypeError("ids_out must be int64 [rows]")
+    if ids is None:
+        ids = torch.empty(t, dtype=torch.int64, device=logits.device)
+    check("mi_sample_tokens_embed", lib.mi_sample_tokens_embed(
+        _p(ids), _p(logits), t, v, logits.stride(0), _dt(logits.dtype), _p(temperature), _p(top_k), _p(top_p), _p(seed),
+        _p(offset), _p(table), dim, _p(out_a), out_a.stride(0), _p(out_b), out_b.stride(0) if out_b is not None else 0,
+        _p(ids_out), ids_out.stride(0) if ids_out is not None else 0, _stream()))
+    return ids
+
+
 def talker_decode_embeds(out: torch.Tensor, embed_table: torch.Tensor, token_ids: torch.Tensor,
                          reply_rows: Optional[torch.Tensor] = None, reply_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[t] = embed_table[token_ids[t]] (+ reply_rows[reply_idx[t]] where reply_idx[t] >= 0)."""
