@@ -978,7 +978,25 @@ int launch_grouped_skinny(const GroupedGemmArgs& a, hipStream_t s) {
   p.dbg = 0;
   p.ldx = a.a_row_stride;
   p.ldo = a.out_row_stride;
-  const dim3 grid(a.gated ? a.n_out / 64 : a.n_out / 128, a.max_tiles);
+  // Weight tiles of one row tile chained into one workgroup (one ring through all of them: SkinnyParams::chain): as many as
+  // still leave about two workgroups per CU.  MI_MOE_CHAIN_GATED / MI_MOE_CHAIN_DOWN = <tiles per workgroup> override (A/B).
+  const int n_tiles = a.gated ? a.n_out / 64 : a.n_out / 128;
+  int chain = 1;
+  {
+    const char* e = getenv(a.gated ? "MI_MOE_CHAIN_GATED" : "MI_MOE_CHAIN_DOWN");
+    if (e && atoi(e) > 0) {
+      chain = atoi(e);
+    } else {
+      for (int c = n_tiles; c >= 1; --c)
+        if (n_tiles % c == 0 && (int64_t)(n_tiles / c) * a.max_tiles >= 512) {
+          chain = c;
+          break;
+        }
+    }
+    if (chain > n_tiles || n_tiles % chain) chain = 1;
+  }
+  p.chain = chain;
+  const dim3 grid(n_tiles / chain, a.max_tiles);
   const int rpt = a.rows_per_tile;
   if (a.dtype == MI_DTYPE_BF16)
     return a.gated ? launch_grouped_rows<bf16_tag, true>(p, grid, rpt, s) : launch_grouped_rows<bf16_tag, false>(p, grid, rpt, s);

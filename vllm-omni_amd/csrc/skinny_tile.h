@@ -60,6 +60,10 @@ struct SkinnyParams {
   const int32_t* tile_expert;  // [max_tiles]
   const int32_t* num_tiles;    // [1]
   int32_t rpt, gather_div;     // rows per tile (32 / 64); gather_div > 0: source row = row_map[r] / gather_div, else r
+  // GROUPED: a workgroup runs `chain` consecutive weight tiles of its row tile back to back through ONE ring — the loaders
+  // go on to the next tile's stages while the consumers store the last one (a K of 384 is six steps: a workgroup per tile
+  // spent more time filling and draining its ring than streaming)
+  int32_t chain = 1;
   int64_t w_expert_stride;     // elements
   int32_t dbg;            // MI_LINEAR_DBG (timing experiments only): 1 = no DMA, 2 = no fragment reads / MFMAs, 4 = no reduce launch, 8 = no output stores
   int64_t ldx, ldo;
@@ -217,7 +221,9 @@ __device__ __forceinline__ void skinny_tile(const SkinnyParams& p, const int wg_
   }
   // XCD-aware order: slice = item % S puts every k slice of x on the XCDs congruent to it (S = 8: one slice per XCD) —
   // its rows are then re-read from ONE L2 by all the tiles
-  const int s = wg % p.S, tile = wg / p.S;
+  const int s = wg % p.S;
+  const int chain = GROUPED ? p.chain : 1;
+  const int tile0 = (wg / p.S) * chain;     // first of the workgroup's `chain` tiles
   const int nb = p.K >> 6;
   const int b_lo = (int)((int64_t)s * nb / p.S), b_hi = (int)((int64_t)(s + 1) * nb / p.S);
   const int n_it = b_hi - b_lo;
@@ -249,37 +255,47 @@ __device__ __forceinline__ void skinny_tile(const SkinnyParams& p, const int wg_
         const int r = row - 16 * MT;               // row of the weight image
         int n;
         if constexpr (GATED) {
-          int col = tile * (16 * NSLAB) + 16 * (r >> 5) + (r & 15);
+          int col = tile0 * (16 * NSLAB) + 16 * (r >> 5) + (r & 15);
           col = col < p.N ? col : p.N - 1;
           n = ((r >> 4) & 1) * p.N + col;          // rows 16-31 of a slab: the up rows of the same columns
         } else {
-          n = tile * TR + r;
+          n = tile0 * TR + r;
           n = n < p.N ? n : p.N - 1;               // a tile may hang over N: those row groups are never stored
         }
         src[i] = reinterpret_cast<const char*>(wbase + (int64_t)n * p.K + 64 * (int64_t)b_lo + 8 * lc);
       }
     }
-    auto issue = [&](int it, int stage) {
+    // step `it` of the workgroup = k block it % n_it of its tile it / n_it: the x pieces start over with every tile, the
+    // weight pieces move on by one tile's rows (a chained launch has whole tiles only: the host checks)
+    const int64_t w_tile_bytes = (int64_t)(GATED ? 16 * NSLAB : TR) * p.K * 2;
+    int kk_next = 0;                 // k block of the next step to issue
+    int64_t w_next = 0;              // byte offset of its tile's weight rows
+    auto issue = [&](int stage) {
       char* st = smem + stage * kStage;
 #pragma unroll
       for (int i = 0; i < PPL; ++i) {
         if (l + NL * i < XI)
-          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it),
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)kk_next),
                                            (lds_void*)(st + (l + NL * i) * 1024), 16, 0, COH ? kAuxAgent : 0);
         else
-          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)it),
+          __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + 128 * (int64_t)kk_next + w_next),
                                            (lds_void*)(st + (l + NL * i) * 1024), 16, 0, MI_SKINNY_W_AUX);
       }
+      if (++kk_next == n_it) {
+        kk_next = 0;
+        w_next += w_tile_bytes;
+      }
     };
+    const int total = n_it * chain;
 #pragma unroll
     for (int j = 0; j < AHEAD; ++j)
-      if (j < n_it && !(p.dbg & 1)) issue(j, j);
+      if (j < total && !(p.dbg & 1)) issue(j);
     int stage = AHEAD;   // stage of step it + AHEAD (= the stage step it - 1 was read from)
-    for (int it = 0; it < n_it; ++it) {
+    for (int it = 0; it < total; ++it) {
       // step `it` landed; the (up to AHEAD - 1) steps issued after it may still be in flight
-      wait_steps_behind<PPL, AHEAD>(n_it - 1 - it);
+      wait_steps_behind<PPL, AHEAD>(total - 1 - it);
       __builtin_amdgcn_s_barrier();
-      if (it + AHEAD < n_it && !(p.dbg & 1)) issue(it + AHEAD, stage);
+      if (it + AHEAD < total && !(p.dbg & 1)) issue(stage);
       stage = stage == NST - 1 ? 0 : stage + 1;
     }
     if constexpr (!GATED && !GROUPED) {
@@ -294,7 +310,6 @@ __device__ __forceinline__ void skinny_tile(const SkinnyParams& p, const int wg_
   // -------------------------------------------------------------------- consumer
   const int r16 = lane & 15, kg = lane >> 4;
   const int slab = wid % NSLAB, mh = wid / NSLAB;
-  const int n_base = tile * TR + 32 * slab;
   // fragment reads: image row 16 j + r16 -> (row >> 1) & 7 == r16 >> 1
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
   uint32_t frag[2];
@@ -302,13 +317,24 @@ __device__ __forceinline__ void skinny_tile(const SkinnyParams& p, const int wg_
   for (int u = 0; u < 2; ++u) frag[u] = lds0 + r16 * 128 + ((kperm(u, kg) ^ (r16 >> 1)) << 4);
   const uint32_t x_off = mh * (MTW * 2048), w_off = kXBytes + slab * 4096;
 
+  // D[n][m]: lane = column m (row r16 of m-tile j), rows n = 4 kg + r of the row group
+  const bool fused_reduce = !GATED && !GROUPED && p.S > 1 && p.cnt != nullptr;
+  // COH: the consumer of a chain takes fp32 slabs whatever the split (one slab at S == 1)
+  const bool slabs = COH ? true : p.S > 1;
+  const bool part_sc1 = fused_reduce || COH;
+  const __amdgpu_buffer_rsrc_t part_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.part, 0, part_sc1 ? (int)((int64_t)p.S * p.M * p.N * 4) : 0, 0x00020000);
+
   acc_t acc[2][MTW];
+  int stage = 0;
+  for (int ct = 0; ct < chain; ++ct) {   // GROUPED: the workgroup's tiles, one ring through all of them; else one pass
+  const int tile = tile0 + ct;
+  const int n_base = tile * TR + 32 * slab;
 #pragma unroll
   for (int g = 0; g < 2; ++g)
 #pragma unroll
     for (int j = 0; j < MTW; ++j) acc[g][j] = acc_t{0, 0, 0, 0};
 
-  int stage = 0;
   for (int it = 0; it < n_it; ++it) {
     __builtin_amdgcn_s_barrier();
     if (p.dbg & 2) continue;
@@ -333,12 +359,15 @@ __device__ __forceinline__ void skinny_tile(const SkinnyParams& p, const int wg_
     stage = stage == NST - 1 ? 0 : stage + 1;
   }
 
-  if (p.dbg & 8) return;
+  if (p.dbg & 8) {
+    if constexpr (GROUPED) continue;
+    else return;
+  }
   if constexpr (GATED) {
     // acc[0] = gate, acc[1] = up of output columns n .. n + 3.  Rounding as in the unfused pair: both GEMM outputs go
     // to the 16-bit grid first, SiLU and the product in fp32, one more rounding (norm_act.hip silu_mul_kernel)
     const int n = tile * (16 * NSLAB) + 16 * slab + 4 * kg;
-    if (n >= p.N) return;
+    if (n >= p.N) continue;
     const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
@@ -358,15 +387,8 @@ __device__ __forceinline__ void skinny_tile(const SkinnyParams& p, const int wg_
       q.y = E::pack(v[2], v[3]);
       store_out_b64<COH>(p.out + (int64_t)m * p.ldo + n, q);
     }
-    return;
+    continue;
   }
-  // D[n][m]: lane = column m (row r16 of m-tile j), rows n = 4 kg + r of the row group
-  const bool fused_reduce = !GATED && !GROUPED && p.S > 1 && p.cnt != nullptr;
-  // COH: the consumer of a chain takes fp32 slabs whatever the split (one slab at S == 1)
-  const bool slabs = COH ? true : p.S > 1;
-  const bool part_sc1 = fused_reduce || COH;
-  const __amdgpu_buffer_rsrc_t part_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(p.part, 0, part_sc1 ? (int)((int64_t)p.S * p.M * p.N * 4) : 0, 0x00020000);
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int n = n_base + 16 * g + 4 * kg;
@@ -472,6 +494,7 @@ __device__ __forceinline__ void skinny_tile(const SkinnyParams& p, const int wg_
       for (int j0 = 0; j0 < MTW; j0 += 2) reduce_batch(I2{}, I8{}, j0);
     }
   }
+  }   // chained tiles (the in-launch reduce above belongs to the one tile of an un-chained workgroup)
 }
 
 }  // namespace
