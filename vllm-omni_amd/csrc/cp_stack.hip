@@ -501,6 +501,7 @@ extern "C" int mi_cp_stack_decode(void* out, const void* x, const void* const* w
   if (head_dim != kCpHD || num_layers > kCpMaxLayers || num_q_heads != 2 * num_kv_heads) return MI_ERR_UNSUPPORTED;
   if (hidden % 64 || hidden > 1024 || intermediate % 64 || (num_q_heads * kCpHD) % 64) return MI_ERR_UNSUPPORTED;
   if (block_size > 64 || position >= block_size || position > 32) return MI_ERR_UNSUPPORTED;
+  if (rows > 4096) return MI_ERR_UNSUPPORTED;   // slab sets are addressed with 32-bit byte offsets
   if (cache_block_stride % 8 || cache_token_stride % 8 || cache_head_stride % 8) return MI_ERR_INVALID_ARG;
   if (((uintptr_t)out | (uintptr_t)x | (uintptr_t)workspace | (uintptr_t)final_norm) & 15) return MI_ERR_INVALID_ARG;
   if (workspace_bytes < mi_cp_stack_workspace_bytes(rows, hidden, num_q_heads, num_kv_heads, intermediate))
